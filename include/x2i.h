@@ -1,0 +1,133 @@
+/* x2i.h -- C ABI of libx2i_hip.so: the MI355X (gfx950) implementation of the X2I sampling hot path.
+ *
+ * The reference (OPPO-Mente-Lab/X2I) is pure Python and has NO FFI layer; the boundary it exposes for this
+ * path is a set of Python call signatures.  Each entry point below names the reference interface it stands
+ * behind (file:line in /root/reference); the ctypes binding that puts it behind the reference's call sites is
+ * x2i_amd/_lib.py, and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer owned by the caller (PyTorch allocates
+ *     inputs, outputs and workspace); the library borrows them for the duration of the call
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised (hipGraph-capturable)
+ *   - bf16 tensors are raw uint16 storage; "f32" means IEEE float
+ *   - every function returns 0 on success, a negative X2I_ERR_* code otherwise; x2i_last_error() returns a
+ *     thread-local message.  Nothing exits or throws across the boundary.
+ *   - one process per GPU; no global mutable state except per-handle objects (x2i_flux_*), which are not
+ *     re-entrant
+ */
+#ifndef X2I_H
+#define X2I_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X2I_ABI_VERSION 1
+
+#define X2I_OK 0
+#define X2I_ERR_ARG (-1)
+#define X2I_ERR_SHAPE (-2)
+#define X2I_ERR_ALIGN (-3)
+#define X2I_ERR_HIP (-4)
+#define X2I_ERR_STATE (-5)
+
+/* activation codes */
+#define X2I_ACT_NONE_ 0
+#define X2I_ACT_GELU_TANH_ 1 /* nn.GELU(approximate="tanh"): lightcontrol_flux.py:65, FeedForward "gelu-approximate" */
+#define X2I_ACT_GELU_ERF_ 2  /* nn.GELU(): utils/proj.py:19,23 */
+#define X2I_ACT_SILU_ 3
+
+typedef void* x2i_stream_t;
+
+int x2i_abi_version(void);
+const char* x2i_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * nn.Linear with fused epilogue.   C[z] = epi(A[z] W^T)
+ *   v = acc + bias[n]; v = act(v); if (res) v = res[z][m][n] + (gate ? gate[z][n] : 1) * v; C = v; C2 = act2(v)
+ * Stands behind: every nn.Linear on the path -- lightcontrol_flux.py:64,66,256,257,282; diffusers Attention
+ * to_q/k/v/add_*_proj/to_out/to_add_out and FeedForward (ctor args lightcontrol_flux.py:69-80,135-153);
+ * utils/proj.py:18-25.  The gate/residual form is `hidden + gate.unsqueeze(1) * linear(...)`
+ * (lightcontrol_flux.py:98-100,180-181,186-189,193-200).
+ * A: bf16 [M,K] (row stride lda, batch stride a_batch_stride elements); W: bf16 [N,K] (row stride ldw);
+ * C: bf16 (or f32 when out_f32) row stride ldc; C2 optional bf16 (same strides as C); gate: f32 [batch][N].
+ * res may alias C.  Fast path needs K % 64 == 0 and 16-byte aligned rows; anything else takes a slow
+ * generic kernel. */
+typedef struct x2i_gemm_args {
+  const void* A; int64_t a_batch_stride; int32_t lda;
+  const void* W; int32_t ldw;
+  const void* bias;
+  void* C; int64_t c_batch_stride; int32_t ldc;
+  void* C2; int32_t act2;
+  const float* gate; int64_t gate_batch_stride;
+  const void* res; int64_t res_batch_stride; int32_t ldr;
+  int32_t M, N, K, batch;
+  int32_t act; int32_t out_f32;
+} x2i_gemm_args;
+int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * F.scaled_dot_product_attention(q, k, v, dropout_p=0, is_causal=False) for head_dim 128 (diffusers
+ * FluxAttnProcessor2_0; reference call sites lightcontrol_flux.py:92-95,173-177).
+ * Q,K: bf16 [B,H,Spad,128]; VT: bf16 [B,H,128,Spad] (V pre-transposed by x2i_qkv_split); rows/cols >= S are
+ * zero padding (Spad % 128 == 0).  O: bf16 token-major, O[b][s][h*128 + d] with row stride ldo and batch
+ * stride o_batch_stride (elements) -- i.e. `transpose(1,2).reshape(B,-1,H*128)` is free. */
+int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
+                       int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
+
+/* RMSNorm(q,k) + RoPE + head split + V transpose, from fused QKV rows to attention layout.
+ * Stands behind FluxAttnProcessor2_0's view/transpose, norm_q/norm_k/norm_added_q/norm_added_k (RMSNorm, eps
+ * 1e-6), torch.cat([txt, img], dim=2) and apply_rotary_emb.
+ * Joint token s of batch b comes from qkv0 row b*S0+s if s < S0, else qkv1 row b*(S-S0)+(s-S0); a row is
+ * [q(H*128) | k(H*128) | v(H*128)] with stride ld.  nq0/nk0 are the RMSNorm weights for source 0
+ * (norm_added_q/k), nq1/nk1 for source 1 (norm_q/k).  cos/sin: f32 [S,128]. */
+int x2i_qkv_split_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t ld1, int32_t B, int32_t S, int32_t S0,
+                       int32_t H, const void* nq0, const void* nk0, const void* nq1, const void* nk1,
+                       const float* cos, const float* sin, void* Q, void* K, void* VT, int32_t Spad, float eps,
+                       x2i_stream_t stream);
+
+/* LayerNorm(elementwise_affine=False, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero / ZeroSingle /
+ * Continuous and `norm2(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]`, lightcontrol_flux.py:166-170,
+ * 183-184,196-197,89,542).  X,Y: bf16 [B][S][D] with row strides ldx/ldy and batch strides (elements).  Rows
+ * s < S0 use (shift0, scale0), the others (shift1, scale1); each is f32 [B][D] with batch stride mod_bs. */
+int x2i_ln_modulate_bf16(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64_t y_bs, int32_t ldy, int32_t B,
+                         int32_t S, int32_t D, int32_t S0, const float* shift0, const float* scale0,
+                         const float* shift1, const float* scale1, int64_t mod_bs, float eps, x2i_stream_t stream);
+
+/* nn.LayerNorm(D, eps) with affine weight/bias (utils/proj.py:17,29; model_internvl/proj.py norm0/norm1). */
+int x2i_ln_affine_bf16(const void* X, void* Y, int64_t rows, int32_t D, const void* weight, const void* bias,
+                       float eps, x2i_stream_t stream);
+
+/* Y[b][n] (+)= act_out( bias[n] + sum_k W[n][k] * act_in(X[b][k]) ), M = B <= 64 rows: the HBM-bound
+ * "skinny" linears -- AdaLayerNorm* modulation (SiLU in), time/text/guidance embedders (diffusers
+ * CombinedTimestep*Embeddings; lightcontrol_flux.py:249-254,452-456), ControlNeXt time embedding.
+ * X: f32 or bf16 [B,K]; W bf16 [N,K]; bias bf16 or NULL; Y f32 [B,N] (row stride ldy). */
+int x2i_skinny_linear(const void* X, int32_t x_is_bf16, const void* W, const void* bias, float* Y, int32_t ldy,
+                      int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out, int32_t accumulate,
+                      x2i_stream_t stream);
+
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(t f_k) | sin(t f_k)] */
+int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, int32_t round_bf16, x2i_stream_t stream);
+
+/* FlowMatchEulerDiscreteScheduler.step: x = bf16(f32(x) + dt[0] * f32(eps)); dt is a DEVICE scalar so the
+ * call can be captured in a hipGraph. */
+int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2i_stream_t stream);
+
+/* Projector layer fusion (utils/proj.py:62-72).  x: bf16 [B,C,S,H] -> y: bf16 [B,S,H]
+ *   conv5x5:   Conv2d(C->1, k=5, pad=2) over the (S,H) plane (:68-69); w f32 [C,5,5], bias f32 [1]
+ *   layer_mean: (cha_scale * x).mean(1) (:66-67) or plain mean (:70-71) when scale == NULL; scale f32 [C] */
+int x2i_proj_conv5x5_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t C, int32_t S,
+                          int32_t H, x2i_stream_t stream);
+int x2i_proj_layer_mean_bf16(const void* x, const float* scale, void* y, int32_t B, int32_t C, int64_t plane,
+                             x2i_stream_t stream);
+/* torch.mean(x1, 1): x f32 [B,S,N] -> y f32 [B,N] (utils/proj.py:32) */
+int x2i_seq_mean_f32(const float* x, float* y, int32_t B, int32_t S, int32_t N, x2i_stream_t stream);
+
+/* dtype casts used at the boundary */
+int x2i_cast_f32_to_bf16(const float* x, void* y, int64_t n, x2i_stream_t stream);
+int x2i_cast_bf16_to_f32(const void* x, float* y, int64_t n, x2i_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X2I_H */

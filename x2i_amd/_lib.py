@@ -1,0 +1,83 @@
+"""ctypes binding of libx2i_hip.so (C ABI: include/x2i.h).
+
+The product path has NO CPU or eager-PyTorch fallback: if the HIP library cannot be loaded, every entry point
+raises.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx2i_hip.so")
+
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
+
+
+class X2IError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("a_batch_stride", C.c_int64), ("lda", C.c_int32),
+        ("W", C.c_void_p), ("ldw", C.c_int32),
+        ("bias", C.c_void_p),
+        ("C", C.c_void_p), ("c_batch_stride", C.c_int64), ("ldc", C.c_int32),
+        ("C2", C.c_void_p), ("act2", C.c_int32),
+        ("gate", C.c_void_p), ("gate_batch_stride", C.c_int64),
+        ("res", C.c_void_p), ("res_batch_stride", C.c_int64), ("ldr", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+        ("act", C.c_int32), ("out_f32", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (restype is int for all but the two below); mirrors include/x2i.h exactly
+SIGNATURES = {
+    "x2i_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
+    "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
+    "x2i_ln_modulate_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
+    "x2i_ln_affine_bf16": [_vp, _vp, _i64, _i32, _vp, _vp, _f32, _vp],
+    "x2i_skinny_linear": [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "x2i_timestep_sinusoid": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "x2i_euler_step_bf16": [_vp, _vp, _i64, _vp, _vp],
+    "x2i_proj_conv5x5_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "x2i_proj_layer_mean_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _vp],
+    "x2i_seq_mean_f32": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "x2i_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "x2i_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (once).  Raises X2IError when it is missing -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise X2IError(
+            "x2i_amd: %s not found. Build it with `python -m x2i_amd.build` (needs hipcc); "
+            "there is no CPU fallback for the product path." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise X2IError("x2i_amd: cannot load %s: %s" % (LIB_PATH, e))
+    lib.x2i_abi_version.restype = C.c_int
+    lib.x2i_last_error.restype = C.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.x2i_abi_version() != 1:
+        raise X2IError("x2i_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().x2i_last_error().decode("utf-8", "replace")
+        raise X2IError("x2i %s failed (code %d): %s" % (what, rc, msg))

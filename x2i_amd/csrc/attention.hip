@@ -1,0 +1,227 @@
+// Flash attention forward for the FLUX joint text+image attention: head_dim 128, no mask, non-causal, bf16 in/out,
+// fp32 softmax statistics and accumulation.  Stands behind F.scaled_dot_product_attention as called by diffusers'
+// FluxAttnProcessor2_0 (reference call sites lightcontrol/lightcontrol_flux.py:92-95,173-177).
+//
+// CDNA4 mapping
+//   * one workgroup = NW waves, each wave owns 32 query rows (QBLK = 32*NW); K/V stream through LDS in 64-key tiles
+//   * "swapped" QK^T: S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so every lane ends up holding 32 scores of ONE
+//     query row (the other 32 live in lane^32): row max / row sum are 31 in-register ops + one cross-half exchange,
+//     never an LDS round trip
+//   * the key index fed to MFMA row i is kvmap(i) = i with bits 2,3 swapped: that makes each lane's 8-register groups
+//     contiguous in the key axis, so P^T is directly the B operand of the PV MFMA (no permlane / LDS shuffle) and the
+//     matching V^T A-operand fragment is one contiguous ds_read_b128
+//   * V arrives pre-transposed (VT [B,H,128,Spad], written by x2i_qkv_split), so both K and V^T tiles are plain
+//     row-major images filled by LDS-DMA (global_load_lds dwordx4); bank conflicts are removed with an XOR swizzle
+//     applied on the DMA source address and on the ds_read_b128 address (CDNA guide rule 21)
+//   * double-buffered tiles: DMA of tile t+1 overlaps the 32 MFMAs of tile t; one barrier per tile
+//   * O^T accumulates in 4 x f32x16; epilogue normalises by 1/l and writes token-major bf16 (8-byte stores)
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int KVB = 64;                  // keys per tile
+constexpr int KTILE = KVB * 128 * 2;     // 16 KiB  K  tile: [64 keys][128 d]
+constexpr int VTILE = 128 * KVB * 2;     // 16 KiB  V^T tile: [128 d][64 keys]
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (N > 0) {
+    sfor<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                           const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S,
+                                                           int Spad, int ldo, long long o_bs, float scale_log2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K 16K | VT 16K]
+  constexpr int NT = NW * 64;
+  constexpr int CH = 1024 / NT;  // 16-byte chunks per thread per tile (1024 chunks per 16 KiB tile)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;     // which half-wave
+  const int li = lane & 31;     // MFMA row/col index owned by this lane
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const long long bh = (long long)b * H + h;
+  const bf16_t* Qh = Q + bh * Spad * 128;
+  const bf16_t* Kh = K + bh * Spad * 128;
+  const bf16_t* Vh = VT + bh * 128 * Spad;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+li][ds*16 + hi*8 .. +8]
+  bf16x8_t qf[8];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8_t*)(Qh + (long long)(q0 + li) * 128 + ds * 16 + hi * 8);
+
+  // ---- DMA source offsets (elements) for this thread's chunks; LDS image is linear, swizzle goes on the source
+  int k_src[CH], v_src[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int p = j * NT + tid;
+    {  // K tile: row = key (256 B = 16 chunks); physical chunk c holds logical chunk c ^ (row & 15)
+      const int row = p >> 4, cphys = p & 15;
+      k_src[j] = row * 128 + ((cphys ^ (row & 15)) << 3);
+    }
+    {  // V^T tile: row = d (128 B = 8 chunks); physical chunk c holds logical chunk c ^ ((row >> 1) & 7)
+      const int row = p >> 3, cphys = p & 7;
+      v_src[j] = row * Spad + ((cphys ^ ((row >> 1) & 7)) << 3);
+    }
+  }
+  auto stage = [&](int buf, int kv0) {
+    char* kb = smem + buf * (KTILE + VTILE);
+    char* vb = kb + KTILE;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      glds16(Kh + (long long)kv0 * 128 + k_src[j], kb + (j * NT + wave * 64) * 16);
+      glds16(Vh + kv0 + v_src[j], vb + (j * NT + wave * 64) * 16);
+    }
+  };
+
+  // ---- per-lane LDS read offsets
+  // K fragment (A operand, sub-tile u, d-step ds): row = u*32 + kvmap(li), logical chunk = ds*2 + hi
+  const int kvm = (li & 0x13) | ((li & 4) << 1) | ((li & 8) >> 1);  // swap bits 2 and 3
+  const int k_row_off = kvm * 256;
+  const int k_swz = kvm & 15;
+  // V^T fragment (A operand, d-block db, sub-tile u, k-step t): row = db*32 + li, logical chunk = 4u + 2t + hi
+  const int v_row_off = li * 128;
+  const int v_swz = (li >> 1) & 7;
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  const int ntiles = (S + KVB - 1) / KVB;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * KVB);
+    const char* kb = smem + buf * (KTILE + VTILE);
+    const char* vb = kb + KTILE;
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 8; ++ds) {
+        const bf16x8_t kf = *(const bf16x8_t*)(kb + u * 32 * 256 + k_row_off + (((ds * 2 + hi) ^ k_swz) << 4));
+        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[u], 0, 0, 0);
+      }
+    }
+    // lane (q = li, hi), sub-tile u, reg r  <->  key = kv0 + u*32 + 16*(r>>3) + 8*hi + (r&7)
+    const int kv0 = t * KVB;
+    if (kv0 + KVB > S) {  // ragged last tile: mask keys >= S
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + u * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= S) sacc[u][r] = NEG_BIG;
+        }
+    }
+    // ---- online softmax (scores scaled into the exp2 domain)
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - m_new);
+        sacc[u][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    if (!__all(m_new == m_run)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    m_run = m_new;
+
+    // ---- P^T fragments (B operand): sub-tile u, k-step kt uses regs 8kt..8kt+7  (keys u*32+16kt+8hi+0..7)
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        union { bf16x8_t v; uint32_t w[4]; } cv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv.w[j] = pack_bf16x2(sacc[u][kt * 8 + 2 * j], sacc[u][kt * 8 + 2 * j + 1]);
+        pf[u][kt] = cv.v;
+      }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const bf16x8_t vf = *(const bf16x8_t*)(vb + db * 32 * 128 + v_row_off + (((4 * u + 2 * kt + hi) ^ v_swz) << 4));
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u][kt], oacc[db], 0, 0, 0);
+        }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA (issued by this wave) has landed
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (q = li, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_run;
+  const int q = q0 + li;
+  if (q < S) {
+    bf16_t* orow = O + (long long)b * o_bs + (long long)q * ldo + h * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hi;
+        const uint2 o2 = make_uint2(pack_bf16x2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
+                                    pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv));
+        *(uint2*)(orow + d) = o2;
+      }
+  }
+}
+
+}  // namespace
+
+int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
+                         long long o_bs, float scale, hipStream_t stream) {
+  if (!Q || !K || !VT || !O) return x2i_set_error(X2I_ERR_ARG, "attention: null pointer");
+  if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention: need Spad %% 128 == 0 and Spad >= S (S=%d Spad=%d)", S, Spad);
+  if (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)) return x2i_set_error(X2I_ERR_ALIGN, "attention: output rows must be 8-byte aligned");
+  constexpr int NW = 4;
+  const size_t shm = 2 * (KTILE + VTILE);
+  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));
+  const float scale_log2 = scale * 1.4426950408889634f;
+  dim3 grid((S + 32 * NW - 1) / (32 * NW), H, B);
+  hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
+                     (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);
+  return x2i_check_launch("attention");
+}

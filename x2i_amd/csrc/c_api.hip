@@ -1,0 +1,88 @@
+// extern "C" surface of libx2i_hip.so (declared in include/x2i.h): argument plumbing + error reporting only.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+int x2i_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int x2i_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString(e));
+  return X2I_OK;
+}
+
+extern "C" {
+
+int x2i_abi_version(void) { return X2I_ABI_VERSION; }
+const char* x2i_last_error(void) { return g_err; }
+
+int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream) { return x2i_launch_gemm(args, (hipStream_t)stream); }
+
+int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                       int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
+  return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream);
+}
+
+int x2i_qkv_split_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t ld1, int32_t B, int32_t S, int32_t S0, int32_t H,
+                       const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cos, const float* sin,
+                       void* Q, void* K, void* VT, int32_t Spad, float eps, x2i_stream_t stream) {
+  return x2i_launch_qkv_split(qkv0, qkv1, ld0, ld1, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, Q, K, VT, Spad, eps,
+                              (hipStream_t)stream);
+}
+
+int x2i_ln_modulate_bf16(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64_t y_bs, int32_t ldy, int32_t B, int32_t S,
+                         int32_t D, int32_t S0, const float* shift0, const float* scale0, const float* shift1,
+                         const float* scale1, int64_t mod_bs, float eps, x2i_stream_t stream) {
+  return x2i_launch_ln_modulate(X, x_bs, ldx, Y, y_bs, ldy, B, S, D, S0, shift0, scale0, shift1, scale1, mod_bs, eps,
+                                (hipStream_t)stream);
+}
+
+int x2i_ln_affine_bf16(const void* X, void* Y, int64_t rows, int32_t D, const void* weight, const void* bias, float eps,
+                       x2i_stream_t stream) {
+  return x2i_launch_ln_affine(X, Y, rows, D, weight, bias, eps, (hipStream_t)stream);
+}
+
+int x2i_skinny_linear(const void* X, int32_t x_is_bf16, const void* W, const void* bias, float* Y, int32_t ldy, int32_t B,
+                      int32_t N, int32_t K, int32_t act_in, int32_t act_out, int32_t accumulate, x2i_stream_t stream) {
+  return x2i_launch_skinny_linear(X, x_is_bf16, W, bias, Y, ldy, B, N, K, act_in, act_out, accumulate, (hipStream_t)stream);
+}
+
+int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, int32_t round_bf16, x2i_stream_t stream) {
+  return x2i_launch_timestep_sinusoid(t, out, B, dim, round_bf16, (hipStream_t)stream);
+}
+
+int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2i_stream_t stream) {
+  return x2i_launch_euler_step(x, eps, n, dt, (hipStream_t)stream);
+}
+
+int x2i_proj_conv5x5_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t C, int32_t S, int32_t H,
+                          x2i_stream_t stream) {
+  return x2i_launch_proj_conv5x5(x, w, bias, y, B, C, S, H, (hipStream_t)stream);
+}
+
+int x2i_proj_layer_mean_bf16(const void* x, const float* scale, void* y, int32_t B, int32_t C, int64_t plane, x2i_stream_t stream) {
+  return x2i_launch_layer_mean(x, scale, y, B, C, plane, (hipStream_t)stream);
+}
+
+int x2i_seq_mean_f32(const float* x, float* y, int32_t B, int32_t S, int32_t N, x2i_stream_t stream) {
+  return x2i_launch_seq_mean(x, y, B, S, N, (hipStream_t)stream);
+}
+
+int x2i_cast_f32_to_bf16(const float* x, void* y, int64_t n, x2i_stream_t stream) {
+  return x2i_launch_cast_f32_bf16(x, y, n, (hipStream_t)stream);
+}
+int x2i_cast_bf16_to_f32(const void* x, float* y, int64_t n, x2i_stream_t stream) {
+  return x2i_launch_cast_bf16_f32(x, y, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

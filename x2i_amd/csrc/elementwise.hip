@@ -1,0 +1,391 @@
+// HBM-bound kernels of the DiT step: LayerNorm+modulate, QKV split (RMSNorm + RoPE + V transpose), skinny
+// linears (AdaLN modulation / embedders), sinusoid, Euler step, casts.  All loads are 16-byte vectors, all
+// reductions are 64-lane wave shuffles (no LDS round trips) -- CDNA guide G13 / Appendix B.
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const bf16x8_t& v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32((bf16_t)v[i]);
+}
+__device__ __forceinline__ bf16x8_t pack8(const float (&f)[8]) {
+  bf16x8_t v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (short)f32_to_bf16(f[i]);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm (no affine) + modulate.  One wave per row; D % 8 == 0, D <= 64*8*MAXV.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // up to D = 4096
+
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ X, long long x_bs, int ldx, bf16_t* __restrict__ Y,
+                                                 long long y_bs, int ldy, int S, int D, int S0, const float* shift0,
+                                                 const float* scale0, const float* shift1, const float* scale1,
+                                                 long long mod_bs, const bf16_t* aw, const bf16_t* ab, float eps,
+                                                 long long total_rows) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const int b = (int)(row / S);
+  const int s = (int)(row - (long long)b * S);
+  const bf16_t* x = X + (long long)b * x_bs + (long long)s * ldx;
+  bf16_t* y = Y + (long long)b * y_bs + (long long)s * ldy;
+  const int nv = D >> 3;  // 16-byte chunks per row
+  float v[LN_MAXV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      unpack8(*(const bf16x8_t*)(x + c * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  const float* sh = nullptr;
+  const float* sc = nullptr;
+  if (!AFFINE) {
+    sh = (s < S0 ? shift0 : shift1) + (long long)b * mod_bs;
+    sc = (s < S0 ? scale0 : scale1) + (long long)b * mod_bs;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      float o[8];
+      if (AFFINE) {
+        float w[8], bb[8];
+        unpack8(*(const bf16x8_t*)(aw + c * 8), w);
+        unpack8(*(const bf16x8_t*)(ab + c * 8), bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * w[j] + bb[j];
+      } else {
+        const f32x4_t s0 = *(const f32x4_t*)(sc + c * 8), s1 = *(const f32x4_t*)(sc + c * 8 + 4);
+        const f32x4_t h0 = *(const f32x4_t*)(sh + c * 8), h1 = *(const f32x4_t*)(sh + c * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (v[i][j] - mean) * rstd * (1.f + s0[j]) + h0[j];
+          o[j + 4] = (v[i][j + 4] - mean) * rstd * (1.f + s1[j]) + h1[j];
+        }
+      }
+      *(bf16x8_t*)(y + c * 8) = pack8(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// q/k: RMSNorm(128) * w -> RoPE -> Q/K [B,H,Spad,128].  16 lanes x 8 elements per (token, head).
+// grid: (S, B); block 256 threads loops over 2*H*16 chunk-units of its token.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restrict__ qkv0, const bf16_t* __restrict__ qkv1, int ld0,
+                                                           int ld1, int S, int S0, int H, const bf16_t* nq0, const bf16_t* nk0,
+                                                           const bf16_t* nq1, const bf16_t* nk1, const float* __restrict__ cosp,
+                                                           const float* __restrict__ sinp, bf16_t* __restrict__ Q,
+                                                           bf16_t* __restrict__ K, int Spad, float eps) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const bool src0 = s < S0;
+  const bf16_t* row = src0 ? qkv0 + ((long long)b * S0 + s) * ld0 : qkv1 + ((long long)b * (S - S0) + (s - S0)) * ld1;
+  const int D = H * 128;
+  const int units = 2 * H * 16;
+  for (int u = threadIdx.x; u < units; u += 256) {
+    const int isk = u / (H * 16);
+    const int rem = u - isk * H * 16;
+    const int h = rem >> 4, c = rem & 15;
+    float x[8];
+    unpack8(*(const bf16x8_t*)(row + isk * D + h * 128 + c * 8), x);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+    // reduce over the 16 lanes of this (token, head)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float r = rsqrtf(ss * (1.f / 128.f) + eps);
+    const bf16_t* wn = isk ? (src0 ? nk0 : nk1) : (src0 ? nq0 : nq1);
+    float w[8];
+    unpack8(*(const bf16x8_t*)(wn + c * 8), w);
+    const float* cp = cosp + (long long)s * 128 + c * 8;
+    const float* sp = sinp + (long long)s * 128 + c * 8;
+    const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
+    const f32x4_t s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
+    float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+    float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
+      o[j] = a * cs[j] - bb * sn[j];
+      o[j + 1] = bb * cs[j + 1] + a * sn[j + 1];
+    }
+    bf16_t* dst = (isk ? K : Q) + (((long long)b * H + h) * Spad + s) * 128 + c * 8;
+    *(bf16x8_t*)dst = pack8(o);
+  }
+}
+
+// V [token][h*128+d] -> VT [B,H,128,Spad] through an LDS transpose; tile = 64 tokens x 128 d of one head.
+// grid: (Spad/64, H, B)
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv0, const bf16_t* __restrict__ qkv1, int ld0,
+                                                          int ld1, int S, int S0, int H, bf16_t* __restrict__ VT, int Spad) {
+  __shared__ bf16_t tile[64][136];  // +8 pad: row stride 272 B
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * 128;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + threadIdx.x;
+    const int tok = p >> 4, c = p & 15;
+    const int s = t0 + tok;
+    bf16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < S) {
+      const bf16_t* row = (s < S0) ? qkv0 + ((long long)b * S0 + s) * ld0 : qkv1 + ((long long)b * (S - S0) + (s - S0)) * ld1;
+      v = *(const bf16x8_t*)(row + 2 * D + h * 128 + c * 8);
+    }
+    *(bf16x8_t*)&tile[tok][c * 8] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + threadIdx.x;
+    const int d = p >> 3, c = p & 7;  // output row d, tokens c*8 .. c*8+7
+    bf16x8_t v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (short)tile[c * 8 + k][d];
+    *(bf16x8_t*)(VT + (((long long)b * H + h) * 128 + d) * Spad + t0 + c * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Skinny linear: Y[b][n] = act_out(bias[n] + sum_k W[n][k] act_in(X[b][k])), B <= 16 per launch chunk.
+// Each wave owns output rows n (strided); activations live in LDS as f32; weights stream once from HBM.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SK_MAXB = 8;
+
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restrict__ Xv, int x_is_bf16, const bf16_t* __restrict__ W,
+                                                            const bf16_t* __restrict__ bias, float* __restrict__ Y, int ldy, int N,
+                                                            int K, int act_in, int act_out, int accumulate, int rpw) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
+  for (int i = threadIdx.x; i < NB * K; i += 256) {
+    float v = x_is_bf16 ? bf16_to_f32(((const bf16_t*)Xv)[i]) : ((const float*)Xv)[i];
+    xs[i] = apply_act(v, act_in);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n_base = (blockIdx.x * 4 + wave) * rpw;  // 4 waves x rpw output rows each
+#pragma unroll 1
+  for (int rr = 0; rr < rpw; ++rr) {
+    const int n = n_base + rr;
+    if (n >= N) break;
+    const bf16_t* w = W + (long long)n * K;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float wf[8];
+      unpack8(*(const bf16x8_t*)(w + k), wf);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const f32x4_t x0 = *(const f32x4_t*)(xs + b * K + k), x1 = *(const f32x4_t*)(xs + b * K + k + 4);
+        acc[b] += wf[0] * x0[0] + wf[1] * x0[1] + wf[2] * x0[2] + wf[3] * x0[3] + wf[4] * x1[0] + wf[5] * x1[1] +
+                  wf[6] * x1[2] + wf[7] * x1[3];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = wave_sum(acc[b]);
+    if (lane == 0) {
+      const float bv = bias ? bf16_to_f32(bias[n]) : 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float v = apply_act(acc[b] + bv, act_out);
+        float* yp = Y + (long long)b * ldy + n;
+        *yp = accumulate ? (*yp + v) : v;
+      }
+    }
+  }
+}
+
+__global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim, int round_bf16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i - b * dim;
+  const int k = j < half ? j : j - half;
+  const float f = expf(-logf(10000.f) * (float)k / (float)half);
+  const float a = t[b] * f;
+  float v = j < half ? cosf(a) : sinf(a);
+  if (round_bf16) v = bf16_to_f32(f32_to_bf16(v));
+  out[i] = v;
+}
+
+__global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ eps, long long n8, const float* __restrict__ dt) {
+  const float d = dt[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float a[8], e[8];
+    unpack8(*(const bf16x8_t*)(x + i * 8), a);
+    unpack8(*(const bf16x8_t*)(eps + i * 8), e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = a[j] + d * e[j];
+    *(bf16x8_t*)(x + i * 8) = pack8(a);
+  }
+}
+
+__global__ void euler_tail_kernel(bf16_t* x, const bf16_t* eps, long long start, long long n, const float* dt) {
+  const long long i = start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = f32_to_bf16(bf16_to_f32(x[i]) + dt[0] * bf16_to_f32(eps[i]));
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = f32_to_bf16(x[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = bf16_to_f32(x[i]);
+}
+
+// x f32 [B,S,N] -> y f32 [B,N] mean over S.  grid (ceil(N/256), B)
+__global__ void seq_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int S, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (n >= N) return;
+  const float* p = x + (long long)b * S * N + n;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += p[(long long)s * N];
+  y[(long long)b * N + n] = acc / (float)S;
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+int x2i_launch_ln_modulate(const void* X, long long x_bs, int ldx, void* Y, long long y_bs, int ldy, int B, int S, int D,
+                           int S0, const float* shift0, const float* scale0, const float* shift1, const float* scale1,
+                           long long mod_bs, float eps, hipStream_t stream) {
+  if (!X || !Y || !shift1 || !scale1 || (S0 > 0 && (!shift0 || !scale0))) return x2i_set_error(X2I_ERR_ARG, "ln_modulate: null pointer");
+  if (D % 8 || D > 64 * 8 * LN_MAXV || B <= 0 || S <= 0) return x2i_set_error(X2I_ERR_SHAPE, "ln_modulate: D=%d must be a multiple of 8 and <= %d", D, 64 * 8 * LN_MAXV);
+  if (ldx % 8 || ldy % 8 || x_bs % 8 || y_bs % 8 || mod_bs % 4 || !al16(X) || !al16(Y)) return x2i_set_error(X2I_ERR_ALIGN, "ln_modulate: rows must be 16-byte aligned");
+  const long long rows = (long long)B * S;
+  hipLaunchKernelGGL(ln_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)X, x_bs, ldx,
+                     (bf16_t*)Y, y_bs, ldy, S, D, S0, shift0 ? shift0 : shift1, scale0 ? scale0 : scale1, shift1, scale1, mod_bs,
+                     (const bf16_t*)nullptr, (const bf16_t*)nullptr, eps, rows);
+  return x2i_check_launch("ln_modulate");
+}
+
+int x2i_launch_ln_affine(const void* X, void* Y, long long rows, int D, const void* w, const void* b, float eps, hipStream_t stream) {
+  if (!X || !Y || !w || !b) return x2i_set_error(X2I_ERR_ARG, "ln_affine: null pointer");
+  if (D % 8 || D > 64 * 8 * LN_MAXV || rows <= 0) return x2i_set_error(X2I_ERR_SHAPE, "ln_affine: D=%d unsupported", D);
+  if (!al16(X) || !al16(Y) || !al16(w) || !al16(b)) return x2i_set_error(X2I_ERR_ALIGN, "ln_affine: 16-byte alignment required");
+  hipLaunchKernelGGL(ln_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)X, (long long)0, D,
+                     (bf16_t*)Y, (long long)0, D, (int)1 << 30, D, 0, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (long long)0, (const bf16_t*)w, (const bf16_t*)b, eps, rows);
+  return x2i_check_launch("ln_affine");
+}
+
+int x2i_launch_qkv_split(const void* qkv0, const void* qkv1, int ld0, int ld1, int B, int S, int S0, int H, const void* nq0,
+                         const void* nk0, const void* nq1, const void* nk1, const float* cosp, const float* sinp, void* Q,
+                         void* K, void* VT, int Spad, float eps, hipStream_t stream) {
+  if (S0 < 0 || S0 > S || B <= 0 || S <= 0 || H <= 0) return x2i_set_error(X2I_ERR_SHAPE, "qkv_split: bad shape");
+  if ((S0 > 0 && (!qkv0 || !nq0 || !nk0)) || (S0 < S && (!qkv1 || !nq1 || !nk1)) || !cosp || !sinp || !Q || !K || !VT)
+    return x2i_set_error(X2I_ERR_ARG, "qkv_split: null pointer");
+  if (Spad % 128 || Spad < S) return x2i_set_error(X2I_ERR_SHAPE, "qkv_split: Spad=%d must be a multiple of 128 and >= S=%d", Spad, S);
+  if ((S0 > 0 && ld0 % 8) || (S0 < S && ld1 % 8)) return x2i_set_error(X2I_ERR_ALIGN, "qkv_split: ld must be a multiple of 8");
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(S, B), dim3(256), 0, stream, (const bf16_t*)qkv0, (const bf16_t*)qkv1, ld0, ld1, S,
+                     S0, H, (const bf16_t*)nq0, (const bf16_t*)nk0, (const bf16_t*)nq1, (const bf16_t*)nk1, cosp, sinp, (bf16_t*)Q,
+                     (bf16_t*)K, Spad, eps);
+  int rc = x2i_check_launch("qk_norm_rope");
+  if (rc) return rc;
+  hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, stream, (const bf16_t*)qkv0, (const bf16_t*)qkv1,
+                     ld0, ld1, S, S0, H, (bf16_t*)VT, Spad);
+  return x2i_check_launch("v_transpose");
+}
+
+int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const void* bias, float* Y, int ldy, int B, int N, int K,
+                             int act_in, int act_out, int accumulate, hipStream_t stream) {
+  if (!X || !W || !Y) return x2i_set_error(X2I_ERR_ARG, "skinny_linear: null pointer");
+  if (B <= 0 || N <= 0 || K <= 0 || K % 8) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: K=%d must be a multiple of 8", K);
+  if (!al16(W)) return x2i_set_error(X2I_ERR_ALIGN, "skinny_linear: W must be 16-byte aligned");
+  const int esz = x_is_bf16 ? 2 : 4;
+  for (int b0 = 0; b0 < B; b0 += SK_MAXB) {
+    const int nb = (B - b0) < SK_MAXB ? (B - b0) : SK_MAXB;
+    const void* xp = (const char*)X + (long long)b0 * K * esz;
+    float* yp = Y + (long long)b0 * ldy;
+    // many rows per block when N is huge (the 1M-row AdaLN modulation table) so the activations are staged once
+    const int rpw = N >= 65536 ? 16 : 2;
+    const dim3 grid((N + 4 * rpw - 1) / (4 * rpw)), block(256);
+    const size_t shm = (size_t)nb * K * 4;
+    if (shm > 160 * 1024) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: B*K too large for LDS");
+#define SK_CASE(NB)                                                                                                   \
+  case NB: {                                                                                                          \
+    hipError_t e = hipFuncSetAttribute((const void*)skinny_linear_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)shm);                                                                     \
+    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "skinny_linear: %s", hipGetErrorString(e));                \
+    hipLaunchKernelGGL(skinny_linear_kernel<NB>, grid, block, shm, stream, xp, x_is_bf16, (const bf16_t*)W,           \
+                       (const bf16_t*)bias, yp, ldy, N, K, act_in, act_out, accumulate, rpw);                         \
+  } break;
+    switch (nb) {
+      SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8)
+    }
+#undef SK_CASE
+    int rc = x2i_check_launch("skinny_linear");
+    if (rc) return rc;
+  }
+  return X2I_OK;
+}
+
+int x2i_launch_timestep_sinusoid(const float* t, float* out, int B, int dim, int round_bf16, hipStream_t stream) {
+  if (!t || !out || B <= 0 || dim <= 0 || dim % 2) return x2i_set_error(X2I_ERR_ARG, "timestep_sinusoid: bad argument");
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, stream, t, out, B, dim, round_bf16);
+  return x2i_check_launch("timestep_sinusoid");
+}
+
+int x2i_launch_euler_step(void* x, const void* eps, long long n, const float* dt, hipStream_t stream) {
+  if (!x || !eps || !dt || n <= 0) return x2i_set_error(X2I_ERR_ARG, "euler_step: bad argument");
+  const long long n8 = (al16(x) && al16(eps)) ? n / 8 : 0;
+  if (n8 > 0) {
+    const long long blocks = (n8 + 255) / 256;
+    hipLaunchKernelGGL(euler_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, (bf16_t*)x,
+                       (const bf16_t*)eps, n8, dt);
+  }
+  if (n8 * 8 < n) {
+    const long long rem = n - n8 * 8;
+    hipLaunchKernelGGL(euler_tail_kernel, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, (const bf16_t*)eps,
+                       n8 * 8, n, dt);
+  }
+  return x2i_check_launch("euler_step");
+}
+
+int x2i_launch_seq_mean(const float* x, float* y, int B, int S, int N, hipStream_t stream) {
+  if (!x || !y || B <= 0 || S <= 0 || N <= 0) return x2i_set_error(X2I_ERR_ARG, "seq_mean: bad argument");
+  hipLaunchKernelGGL(seq_mean_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, x, y, S, N);
+  return x2i_check_launch("seq_mean");
+}
+
+int x2i_launch_cast_f32_bf16(const float* x, void* y, long long n, hipStream_t stream) {
+  if (!x || !y || n <= 0) return x2i_set_error(X2I_ERR_ARG, "cast: bad argument");
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, x, (bf16_t*)y, n);
+  return x2i_check_launch("cast_f32_bf16");
+}
+int x2i_launch_cast_bf16_f32(const void* x, float* y, long long n, hipStream_t stream) {
+  if (!x || !y || n <= 0) return x2i_set_error(X2I_ERR_ARG, "cast: bad argument");
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, (const bf16_t*)x, y, n);
+  return x2i_check_launch("cast_bf16_f32");
+}

@@ -1,0 +1,299 @@
+// bf16 MFMA GEMM with fused epilogues for the FLUX DiT / projector linears.
+//
+//   C[z][m][n] = epi( sum_k A[z][m][k] * W[n][k] )         (nn.Linear layout: W is [N,K], K contiguous)
+//   v = acc + bias[n];  v = act(v);  if (res) v = res[z][m][n] + (gate ? gate[z][n] : 1) * v
+//
+// Replaces every nn.Linear on the hot path (reference: lightcontrol/lightcontrol_flux.py:64,66,256,257,282
+// and the diffusers Attention/FeedForward linears built at :69-80,:135-153; utils/proj.py:18-25).
+//
+// CDNA4 mapping (v1 "step-3" structure of the CDNA guide):
+//   * 128x128x64 block tile, 256 threads = 4 waves in 2(M) x 2(N), each wave 64x64 = 4x4 MFMA 16x16x32 tiles
+//   * operands staged HBM -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round trip); the buffer
+//     descriptor's num_records gives free zero-fill for ragged M / N edges
+//   * LDS image is lane-linear (DMA constraint), so the bank-conflict XOR swizzle is applied on the SOURCE
+//     chunk index and again on the ds_read_b128 address (same involution both sides)
+//   * double-buffered LDS, one barrier per K-step; next tile's DMA overlaps this tile's MFMAs
+//   * operands swapped (D = W_frag x A_frag) so each lane ends up with 4 consecutive n of one row m
+//     -> 8-byte bf16x4 stores and contiguous bias / gate / residual reads
+//   * grid is XCD-aware: consecutive tiles of a group-of-8 M band land on the same XCD's L2
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+struct GemmP {
+  const bf16_t* A; long long a_bs; int lda;
+  const bf16_t* W; int ldw;
+  const bf16_t* bias;
+  void* C; long long c_bs; int ldc;
+  bf16_t* C2; int act2;
+  const float* gate; long long gate_bs;
+  const bf16_t* res; long long r_bs; int ldr;
+  int M, N, K;
+  int act, out_f32;
+  int tilesM, tilesN;
+};
+
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
+                                           uint32_t koff_bytes, int wave) {
+  // 1024 16-byte chunks per tile; instruction j covers chunks [j*256 + wave*64, +64): LDS dest is wave-uniform
+  // base + lane*16 (added by hardware)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_tile + j * 4096 + wave * 1024),
+                                             16, voff[j], koff_bytes, 0, 0);
+  }
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// Epilogue variants are compile-time (ACT, RES, OUTF32, HASC2) so that the accumulator array is only ever indexed
+// with constants (a runtime-indexed ext_vector array is demoted to scratch memory by hipcc).
+template <int ACT, bool RES, bool OUTF32, bool HASC2>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][A 16K | B 16K]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.y;
+
+  // ---- XCD-aware tile id: block b runs on XCD b%8; give each XCD a contiguous run of logical tile ids
+  const int T = p.tilesM * p.tilesN;
+  int bid = blockIdx.x;
+  {
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // group-of-8 M bands, N fastest across the band
+  constexpr int GM = 8;
+  const int per_group = GM * p.tilesN;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsize = min(p.tilesM - first_m, GM);
+  const int tm = first_m + (bid % per_group) % gsize;
+  const int tn = (bid % per_group) / gsize;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16_t* Az = p.A + (long long)z * p.a_bs;
+  // buffer descriptors: num_records = bytes from base to the end of the last valid row
+  const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
+  __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  // per-thread source offsets of its 4 chunks per operand tile (row r, physical chunk c holds logical chunk c^swz)
+  uint32_t a_voff[4], w_voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pch = j * 256 + tid;
+    const int row = pch >> 3, cphys = pch & 7;
+    const int clog = cphys ^ ((row >> 1) & 7);
+    // rows past M/N: offset lands beyond num_records -> hardware returns 0
+    a_voff[j] = (uint32_t)(((long long)(m0 + row) * p.lda + clog * 8) * 2);
+    w_voff[j] = (uint32_t)(((long long)(n0 + row) * p.ldw + clog * 8) * 2);
+    if (m0 + row >= p.M) a_voff[j] = 0x80000000u;
+    if (n0 + row >= p.N) w_voff[j] = 0x80000000u;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: lane reads row (lane&15) (+16*i), logical chunk kk*4 + (lane>>4)
+  const int frow = lane & 15;
+  const int fswz = (frow >> 1) & 7;
+  uint32_t frag_off[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) frag_off[kk] = frow * 128 + (((kk * 4 + (lane >> 4)) ^ fswz) << 4);
+  const uint32_t a_frag_base = wm * 64 * 128;  // bytes: wave's first A row
+  const uint32_t b_frag_base = wn * 64 * 128;
+
+  const int nk = p.K / BK;
+  stage_tile(a_rsrc, smem, a_voff, 0, wave);
+  stage_tile(w_rsrc, smem + TILE_BYTES, w_voff, 0, wave);
+  // hipcc does not count LDS-DMA (buffer_load ... lds) as pending LDS writes at a barrier: wait explicitly
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+    if (kt + 1 < nk) {
+      char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
+      stage_tile(a_rsrc, nxt, a_voff, koff, wave);
+      stage_tile(w_rsrc, nxt + TILE_BYTES, w_voff, koff, wave);
+    }
+    const char* As = cur + a_frag_base;
+    const char* Bs = cur + TILE_BYTES + b_frag_base;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(As + i * 2048 + frag_off[kk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(Bs + j * 2048 + frag_off[kk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed
+    __syncthreads();                                  // ... everyone's has, and everyone is done reading `cur`
+  }
+
+  // ---- epilogue: lane owns m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4 + 0..3
+  const int mrow = m0 + wm * 64 + (lane & 15);
+  const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!RES || (p.ldr & 3) == 0);
+  static_for<4>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = ncol + j * 16;
+    if (n < p.N) {
+      const bool full = vec_ok && (n + 3 < p.N);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (full) {
+        if (p.bias) {
+          const uint2 b2 = *(const uint2*)(p.bias + n);
+          bv[0] = __uint_as_float(b2.x << 16); bv[1] = __uint_as_float(b2.x & 0xffff0000u);
+          bv[2] = __uint_as_float(b2.y << 16); bv[3] = __uint_as_float(b2.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            if (p.bias) bv[r] = bf16_to_f32(p.bias[n + r]);
+            if (gz) gv[r] = gz[n + r];
+          }
+        }
+      }
+      static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = mrow + i * 16;
+        if (m < p.M) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
+          const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
+          if (full) {
+            if constexpr (RES) {
+              const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
+              v[0] = __uint_as_float(r2.x << 16) + gv[0] * v[0];
+              v[1] = __uint_as_float(r2.x & 0xffff0000u) + gv[1] * v[1];
+              v[2] = __uint_as_float(r2.y << 16) + gv[2] * v[2];
+              v[3] = __uint_as_float(r2.y & 0xffff0000u) + gv[3] * v[3];
+            }
+            if constexpr (OUTF32) {
+              *(f32x4_t*)((float*)p.C + coff) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+              *(uint2*)((bf16_t*)p.C + coff) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+            if constexpr (HASC2) {
+              *(uint2*)(p.C2 + coff) = make_uint2(pack_bf16x2(apply_act(v[0], p.act2), apply_act(v[1], p.act2)),
+                                                  pack_bf16x2(apply_act(v[2], p.act2), apply_act(v[3], p.act2)));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (n + r < p.N) {
+                float x = v[r];
+                if constexpr (RES) x = bf16_to_f32(rz[(long long)m * p.ldr + n + r]) + gv[r] * x;
+                if constexpr (OUTF32) ((float*)p.C)[coff + r] = x;
+                else ((bf16_t*)p.C)[coff + r] = f32_to_bf16(x);
+                if constexpr (HASC2) p.C2[coff + r] = f32_to_bf16(apply_act(x, p.act2));
+              }
+            }
+          }
+        }
+      });
+    }
+  });
+}
+
+// Correct-for-any-shape fallback (K not a multiple of 64, unaligned leading dims): one thread per output.
+// Only ever used for tiny problems (e.g. the 3-channel first ControlNeXt conv, reduced-width tests).
+__global__ void gemm_naive_kernel(GemmP p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  const int z = blockIdx.z;
+  if (n >= p.N || m >= p.M) return;
+  const bf16_t* a = p.A + (long long)z * p.a_bs + (long long)m * p.lda;
+  const bf16_t* w = p.W + (long long)n * p.ldw;
+  float acc = 0.f;
+  for (int k = 0; k < p.K; ++k) acc = fmaf(bf16_to_f32(a[k]), bf16_to_f32(w[k]), acc);
+  float v = acc + (p.bias ? bf16_to_f32(p.bias[n]) : 0.f);
+  v = apply_act(v, p.act);
+  if (p.res) {
+    const float g = p.gate ? p.gate[(long long)z * p.gate_bs + n] : 1.f;
+    v = bf16_to_f32(p.res[(long long)z * p.r_bs + (long long)m * p.ldr + n]) + g * v;
+  }
+  const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
+  if (p.out_f32) ((float*)p.C)[coff] = v;
+  else ((bf16_t*)p.C)[coff] = f32_to_bf16(v);
+  if (p.C2) p.C2[coff] = f32_to_bf16(apply_act(v, p.act2));
+}
+
+}  // namespace
+
+int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
+  if (!a || !a->A || !a->W || !a->C) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
+  if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
+  GemmP p;
+  p.A = (const bf16_t*)a->A; p.a_bs = a->a_batch_stride; p.lda = a->lda;
+  p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
+  p.bias = (const bf16_t*)a->bias;
+  p.C = a->C; p.c_bs = a->c_batch_stride; p.ldc = a->ldc;
+  p.C2 = (bf16_t*)a->C2; p.act2 = a->act2;
+  p.gate = a->gate; p.gate_bs = a->gate_batch_stride;
+  p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
+  p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
+  const bool fast = (a->K % BK == 0) && (a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) &&
+                    (((uintptr_t)a->W & 15) == 0) && ((a->a_batch_stride & 7) == 0) &&
+                    ((long long)a->M * a->lda * 2 < 0x7f000000LL) && ((long long)a->N * a->ldw * 2 < 0x7f000000LL);
+  typedef void (*kern_t)(GemmP);
+  kern_t kern = nullptr;
+  const bool res = p.res != nullptr, c2 = p.C2 != nullptr, f32 = p.out_f32 != 0;
+  if (!res && !f32 && !c2) {
+    switch (p.act) {
+      case X2I_ACT_NONE: kern = gemm_bf16_kernel<X2I_ACT_NONE, false, false, false>; break;
+      case X2I_ACT_GELU_TANH: kern = gemm_bf16_kernel<X2I_ACT_GELU_TANH, false, false, false>; break;
+      case X2I_ACT_GELU_ERF: kern = gemm_bf16_kernel<X2I_ACT_GELU_ERF, false, false, false>; break;
+      case X2I_ACT_SILU: kern = gemm_bf16_kernel<X2I_ACT_SILU, false, false, false>; break;
+    }
+  } else if (p.act == X2I_ACT_NONE) {
+    if (res && !f32 && !c2) kern = gemm_bf16_kernel<X2I_ACT_NONE, true, false, false>;
+    else if (!res && f32 && !c2) kern = gemm_bf16_kernel<X2I_ACT_NONE, false, true, false>;
+    else if (!res && !f32 && c2) kern = gemm_bf16_kernel<X2I_ACT_NONE, false, false, true>;
+  }
+  if (fast && kern) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    dim3 grid(p.tilesM * p.tilesN, a->batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+  } else {
+    dim3 grid((a->N + 127) / 128, a->M, a->batch);
+    hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(128), 0, stream, p);
+  }
+  return x2i_check_launch("gemm");
+}

@@ -1,0 +1,58 @@
+// Shared device/host helpers for the X2I HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define X2I_OK 0
+#define X2I_ERR_ARG (-1)
+#define X2I_ERR_SHAPE (-2)
+#define X2I_ERR_ALIGN (-3)
+#define X2I_ERR_HIP (-4)
+#define X2I_ERR_STATE (-5)
+
+// host side: record an error string (thread-local) and return the code
+int x2i_set_error(int code, const char* fmt, ...);
+int x2i_check_launch(const char* what);
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// activation codes shared by every kernel and by the C ABI (include/x2i.h)
+enum { X2I_ACT_NONE = 0, X2I_ACT_GELU_TANH = 1, X2I_ACT_GELU_ERF = 2, X2I_ACT_SILU = 3 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case X2I_ACT_GELU_TANH: return gelu_tanh_f(v);
+    case X2I_ACT_GELU_ERF: return gelu_erf_f(v);
+    case X2I_ACT_SILU: return silu_f(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

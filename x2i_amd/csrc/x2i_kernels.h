@@ -1,0 +1,26 @@
+// Internal launcher declarations (host side). Each launcher enqueues on `stream` and returns an X2I_* code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/x2i.h"
+
+int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream);
+int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
+                         long long o_bs, float scale, hipStream_t stream);
+int x2i_launch_qkv_split(const void* qkv0, const void* qkv1, int ld0, int ld1, int B, int S, int S0, int H,
+                         const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cosp,
+                         const float* sinp, void* Q, void* K, void* VT, int Spad, float eps, hipStream_t stream);
+int x2i_launch_ln_modulate(const void* X, long long x_bs, int ldx, void* Y, long long y_bs, int ldy, int B, int S, int D,
+                           int S0, const float* shift0, const float* scale0, const float* shift1, const float* scale1,
+                           long long mod_bs, float eps, hipStream_t stream);
+int x2i_launch_ln_affine(const void* X, void* Y, long long rows, int D, const void* w, const void* b, float eps,
+                         hipStream_t stream);
+int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const void* bias, float* Y, int ldy, int B,
+                             int N, int K, int act_in, int act_out, int accumulate, hipStream_t stream);
+int x2i_launch_timestep_sinusoid(const float* t, float* out, int B, int dim, int round_bf16, hipStream_t stream);
+int x2i_launch_euler_step(void* x, const void* eps, long long n, const float* dt, hipStream_t stream);
+int x2i_launch_proj_conv5x5(const void* x, const float* w, const float* bias, void* y, int B, int C, int S, int H,
+                            hipStream_t stream);
+int x2i_launch_layer_mean(const void* x, const float* scale, void* y, int B, int C, long long plane, hipStream_t stream);
+int x2i_launch_seq_mean(const float* x, float* y, int B, int S, int N, hipStream_t stream);
+int x2i_launch_cast_f32_bf16(const float* x, void* y, long long n, hipStream_t stream);
+int x2i_launch_cast_bf16_f32(const void* x, float* y, long long n, hipStream_t stream);

@@ -1,0 +1,183 @@
+"""Thin torch-tensor wrappers over the C ABI (include/x2i.h).  PyTorch only supplies device memory and the current
+HIP stream; every computation happens in libx2i_hip.so.  All wrappers enqueue on torch's current stream, so they can
+be captured with torch.cuda.graph().
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_SILU, GemmArgs, check  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _req(t, dtype, name):
+    if t.device.type != "cuda":
+        raise _lib.X2IError("x2i_amd: %s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise _lib.X2IError("x2i_amd: %s must be %s (got %s)" % (name, dtype, t.dtype))
+
+
+def pad128(n):
+    return (n + 127) // 128 * 128
+
+
+def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=None, c_batch_stride=0, ldc=None,
+         act=ACT_NONE, gate=None, gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, out2=None, act2=ACT_NONE,
+         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None):
+    """C = epi(A W^T).  A, out, res may be sub-views addressed as (tensor, element offset, row stride, batch stride)."""
+    lib = _lib.load()
+    _req(A, torch.bfloat16, "A")
+    _req(W, torch.bfloat16, "W")
+    N = W.shape[0] if N is None else N
+    K = W.shape[1] if K is None else K
+    if M is None:
+        M = A.numel() // A.shape[-1]
+    lda = A.shape[-1] if lda is None else lda
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        if batch > 1:
+            c_batch_stride = M * N
+    ldc = N if ldc is None else ldc
+    esz_c = 4 if out_f32 else 2
+    a = GemmArgs()
+    a.A = A.data_ptr() + a_offset * 2
+    a.a_batch_stride = a_batch_stride
+    a.lda = lda
+    a.W = W.data_ptr()
+    a.ldw = W.stride(0)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C = out.data_ptr() + c_offset * esz_c
+    a.c_batch_stride = c_batch_stride
+    a.ldc = ldc
+    a.C2 = (out2.data_ptr() + c_offset * 2) if out2 is not None else None
+    a.act2 = act2
+    a.gate = gate.data_ptr() if gate is not None else None
+    a.gate_batch_stride = gate_batch_stride
+    a.res = (res.data_ptr() + res_offset * 2) if res is not None else None
+    a.res_batch_stride = res_batch_stride
+    a.ldr = (ldc if ldr is None else ldr)
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.act = act
+    a.out_f32 = 1 if out_f32 else 0
+    check(lib.x2i_gemm_bf16(C.byref(a), _stream()), "gemm")
+    return out
+
+
+def attention(Q, K, VT, out, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0):
+    lib = _lib.load()
+    check(lib.x2i_attention_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), B, H, S, Spad, ldo,
+                                 o_batch_stride, scale, _stream()), "attention")
+    return out
+
+
+def qkv_split(qkv0, qkv1, ld0, ld1, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, Q, K, VT, Spad, eps=1e-6):
+    lib = _lib.load()
+    check(lib.x2i_qkv_split_bf16(_p(qkv0), _p(qkv1), ld0, ld1, B, S, S0, H, _p(nq0), _p(nk0), _p(nq1), _p(nk1), _p(cos),
+                                 _p(sin), _p(Q), _p(K), _p(VT), Spad, eps, _stream()), "qkv_split")
+
+
+def ln_modulate(X, Y, B, S, D, S0, shift0, scale0, shift1, scale1, mod_bs, eps=1e-6, x_bs=None, ldx=None, y_bs=None,
+                ldy=None, x_offset=0, y_offset=0):
+    lib = _lib.load()
+    ldx = D if ldx is None else ldx
+    ldy = D if ldy is None else ldy
+    x_bs = S * ldx if x_bs is None else x_bs
+    y_bs = S * ldy if y_bs is None else y_bs
+    check(lib.x2i_ln_modulate_bf16(C.c_void_p(X.data_ptr() + 2 * x_offset), x_bs, ldx, C.c_void_p(Y.data_ptr() + 2 * y_offset),
+                                   y_bs, ldy, B, S, D, S0, _p(shift0), _p(scale0), _p(shift1), _p(scale1), mod_bs, eps,
+                                   _stream()), "ln_modulate")
+    return Y
+
+
+def ln_affine(X, weight, bias, eps, out=None):
+    lib = _lib.load()
+    _req(X, torch.bfloat16, "X")
+    D = X.shape[-1]
+    out = torch.empty_like(X) if out is None else out
+    check(lib.x2i_ln_affine_bf16(_p(X), _p(out), X.numel() // D, D, _p(weight), _p(bias), eps, _stream()), "ln_affine")
+    return out
+
+
+def skinny_linear(X, W, bias=None, out=None, act_in=ACT_NONE, act_out=ACT_NONE, accumulate=False, ldy=None):
+    lib = _lib.load()
+    _req(W, torch.bfloat16, "W")
+    B, K = X.shape
+    N = W.shape[0]
+    if X.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.X2IError("skinny_linear: X must be f32 or bf16")
+    if out is None:
+        out = torch.empty((B, N), device=X.device, dtype=torch.float32)
+    ldy = out.stride(0) if ldy is None else ldy
+    check(lib.x2i_skinny_linear(_p(X), 1 if X.dtype == torch.bfloat16 else 0, _p(W), _p(bias), _p(out), ldy, B, N, K, act_in,
+                                act_out, 1 if accumulate else 0, _stream()), "skinny_linear")
+    return out
+
+
+def timestep_sinusoid(t, dim, round_bf16=False):
+    lib = _lib.load()
+    _req(t, torch.float32, "t")
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    check(lib.x2i_timestep_sinusoid(_p(t), _p(out), t.shape[0], dim, 1 if round_bf16 else 0, _stream()), "timestep_sinusoid")
+    return out
+
+
+def euler_step_(x, eps, dt):
+    """x <- bf16(f32(x) + dt * f32(eps)) in place; dt is a 1-element f32 DEVICE tensor."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    _req(eps, torch.bfloat16, "eps")
+    _req(dt, torch.float32, "dt")
+    check(lib.x2i_euler_step_bf16(_p(x), _p(eps), x.numel(), _p(dt), _stream()), "euler_step")
+    return x
+
+
+def proj_conv5x5(x, w, bias, out=None):
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    _req(w, torch.float32, "w")
+    B, Cc, S, H = x.shape
+    out = torch.empty((B, S, H), device=x.device, dtype=torch.bfloat16) if out is None else out
+    check(lib.x2i_proj_conv5x5_bf16(_p(x), _p(w), _p(bias), _p(out), B, Cc, S, H, _stream()), "proj_conv5x5")
+    return out
+
+
+def proj_layer_mean(x, scale, out=None):
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    B, Cc, S, H = x.shape
+    out = torch.empty((B, S, H), device=x.device, dtype=torch.bfloat16) if out is None else out
+    check(lib.x2i_proj_layer_mean_bf16(_p(x), _p(scale), _p(out), B, Cc, S * H, _stream()), "proj_layer_mean")
+    return out
+
+
+def seq_mean(x):
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    B, S, N = x.shape
+    out = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    check(lib.x2i_seq_mean_f32(_p(x), _p(out), B, S, N, _stream()), "seq_mean")
+    return out
+
+
+def to_bf16(x):
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib.x2i_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "cast")
+    return out
+
+
+def to_f32(x):
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib.x2i_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _stream()), "cast")
+    return out
