@@ -1,0 +1,148 @@
+"""Model-level parity on the GPU: x2i_amd modules (HIP path through the C ABI) against
+  (a) the committed golden fixtures produced by the reference's own code (fp32 weights), and
+  (b) the CPU oracle evaluated in fp32 on the SAME bf16-rounded weights/inputs the HIP path sees.
+Tolerances: whole-model rel-L2 <= 2e-2 vs (b), <= 3e-2 vs (a) (adds weight rounding);
+4-step final latents <= 5e-2."""
+import pytest
+import torch
+
+from oracle import flux as OF
+from oracle import projector as OP
+from oracle import sampler as OS
+from tests.util import golden, rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf_round(sd):
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def make_model(cfg, sd):
+    from x2i_amd.flux import FluxTransformer2DModel
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    missing, unexpected = m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    assert not missing and not unexpected
+    return m
+
+
+@pytest.mark.parametrize("name", ["flux_tiny_schnell", "flux_tiny_dev_control"])
+def test_transformer_forward_vs_reference_golden(name):
+    t, meta = golden(name)
+    cfg = meta["cfg"]
+    sd = OF.random_flux_state_dict(cfg, seed=meta["weight_seed"], std=meta["weight_std"])
+    m = make_model(cfg, sd)
+    guidance = t.get("guidance")
+    kw = dict(hidden_states=t["hidden"].to(DEV), encoder_hidden_states=t["enc"].to(DEV), pooled_projections=t["pooled"].to(DEV),
+              timestep=t["timestep"].to(DEV), img_ids=t["img_ids"].to(DEV), txt_ids=t["txt_ids"].to(DEV),
+              guidance=None if guidance is None else guidance.to(DEV), return_dict=False)
+    out = m(**kw)[0]
+    assert out.shape == t["out"].shape and out.dtype == torch.bfloat16
+    # (b) oracle on bf16-rounded weights and inputs, no control branch
+    rb = lambda x: x.to(torch.bfloat16).float()
+    ref = OF.flux_forward(bf_round(sd), cfg, rb(t["hidden"]), rb(t["enc"]), rb(t["pooled"]), t["timestep"], t["img_ids"],
+                          t["txt_ids"], guidance=guidance)
+    assert rel_l2(out, ref) < 2e-2
+    if name == "flux_tiny_schnell":  # (a) the reference's own output
+        assert rel_l2(out, t["out"]) < 3e-2
+
+
+def test_full_width_one_plus_one_blocks_vs_oracle():
+    """D = 3072, 24 heads (the real FLUX width), 1 double + 1 single block, ragged short sequence."""
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=1, num_single_layers=1)
+    sd = OF.random_flux_state_dict(cfg, seed=7, std=0.02)
+    m = make_model(cfg, sd)
+    B, St, h2, w2 = 2, 24, 6, 10
+    hidden, enc, pooled = seeded((B, h2 * w2, 64), 1), seeded((B, St, 4096), 2), seeded((B, 768), 3)
+    ts = torch.tensor([0.5, 0.25])
+    img_ids, txt_ids = OS.prepare_latent_image_ids(h2, w2), torch.zeros(St, 3)
+    out = m(hidden_states=hidden.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV),
+            timestep=ts.to(DEV), img_ids=img_ids.to(DEV), txt_ids=txt_ids.to(DEV), return_dict=False)[0]
+    rb = lambda x: x.to(torch.bfloat16).float()
+    ref = OF.flux_forward(bf_round(sd), cfg, rb(hidden), rb(enc), rb(pooled), ts, img_ids, txt_ids)
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_state_dict_roundtrip_matches_reference_keys():
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32,
+               guidance_embeds=True)
+    sd = OF.random_flux_state_dict(cfg, seed=3)
+    m = make_model(cfg, sd)
+    got = m.state_dict()
+    assert set(got) == set(sd)
+    for k in sd:
+        assert torch.equal(got[k].cpu(), sd[k].to(torch.bfloat16)), k
+
+
+def test_pipeline_four_steps_vs_oracle_sampler():
+    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+    t, meta = golden("flux_tiny_schnell")
+    cfg = meta["cfg"]
+    sd = OF.random_flux_state_dict(cfg, seed=meta["weight_seed"], std=meta["weight_std"])
+    m = make_model(cfg, sd)
+    pipe = FluxPipeline(m, FlowMatchEulerDiscreteScheduler(**OS.SCHEDULER_SCHNELL))
+    pe, pooled = seeded((2, 40, 128), 5).bfloat16(), seeded((2, 64), 6).bfloat16()
+    noise = OS.pack_latents(torch.randn((2, 16, 16, 24), generator=torch.Generator().manual_seed(0))).bfloat16()
+    got = pipe(prompt_embeds=pe.to(DEV), pooled_prompt_embeds=pooled.to(DEV), num_inference_steps=4, guidance_scale=3.5,
+               height=128, width=192, output_type="latent", latents=noise.to(DEV)).images
+    assert got.shape == (2, 96, 64) and got.dtype == torch.bfloat16
+    # oracle: same bf16 inputs, bf16-rounded weights, fp32 transformer math, bf16 scheduler storage as diffusers does
+    sdr = bf_round(sd)
+    lat = noise.clone()
+    ts, sig = OS.flow_match_sigmas(4, OS.SCHEDULER_SCHNELL, lat.shape[1])
+    img_ids, txt_ids = OS.prepare_latent_image_ids(8, 12), torch.zeros(40, 3)
+    for i, tt in enumerate(ts):
+        # bf16 timestep arithmetic exactly as the reference's bf16 run does it: pipeline `t.to(bf16) / 1000`, model
+        # `timestep.to(bf16) * 1000` (750 becomes 752) -- reproduced here with the same torch bf16 ops on the CPU
+        t1000 = ((tt.expand(2).to(torch.bfloat16) / 1000) * 1000).float()
+        eps = OF.flux_forward(sdr, cfg, lat.float(), pe.float(), pooled.float(), t1000 / 1000, img_ids, txt_ids)
+        lat = OS.euler_step(lat, eps.bfloat16(), sig[i], sig[i + 1])
+    assert rel_l2(got, lat) < 5e-2
+    # graph replay gives the same latents as the eager launch sequence
+    got2 = pipe(prompt_embeds=pe.to(DEV), pooled_prompt_embeds=pooled.to(DEV), num_inference_steps=4, height=128, width=192,
+                output_type="latent", latents=noise.to(DEV), use_graph=True).images
+    assert torch.equal(got2, got)
+    got3 = pipe(prompt_embeds=pe.to(DEV), pooled_prompt_embeds=pooled.to(DEV), num_inference_steps=4, height=128, width=192,
+                output_type="latent", latents=noise.to(DEV), use_graph=True).images
+    assert torch.equal(got3, got)
+    unp = FluxPipeline._unpack_latents(got, 128, 192, 16)
+    assert unp.shape == (2, 16, 16, 24)
+
+
+@pytest.mark.parametrize("name", ["proj_qwen3b", "proj_qwen7b", "proj_internvl1b", "proj_internvl4b", "proj_minicpm",
+                                  "proj_internvl1b_mean"])
+def test_projector_vs_reference_golden(name):
+    import x2i_amd.proj as XP
+    t, meta = golden(name)
+    kind = meta["kind"]
+    sd = OP.random_proj_state_dict(kind, seed=meta["weight_seed"], use_scale=True if "drop" in meta else None)
+    for k in meta.get("drop", []):
+        sd.pop(k)
+    C = OP.FACTORIES[kind]["in_channels"]
+    make = {
+        "qwen3b": lambda: XP.create_proj3_qwen3b(in_channels=C, use_t5=False, use_scale=False, use_cnn=True),
+        "qwen7b": lambda: XP.create_proj3_qwen7b(in_channels=C, use_t5=False, use_scale=False, use_cnn=True),
+        "internvl1b": lambda: XP.create_proj_internvl1b(in_channels=C, use_t5=False, use_scale="cha_scale" in sd,
+                                                        use_cnn=False if "drop" in meta else True),
+        "internvl4b": lambda: XP.create_proj_internvl4b(in_channels=C, use_t5=False, use_scale=False),
+        "minicpm": lambda: XP.create_proj_minicpm(in_channels=C, use_t5=False, use_scale=False, use_cnn=True),
+    }[kind]
+    proj = make()
+    proj.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    x = seeded(meta["input_shape"], meta["input_seed"], meta["input_scale"])
+    x1, x2 = proj(x.to(DEV))
+    assert x1.shape == t["x1"].shape and x2.shape == t["x2"].shape
+    # (a) reference output (fp32 weights / inputs)
+    assert rel_l2(x2, t["x2"]) < 2e-2 and rel_l2(x1, t["x1"]) < 2e-2
+    # (b) oracle on the bf16-rounded weights and inputs
+    r1, r2 = OP.proj7exp(bf_round(sd), x.to(torch.bfloat16).float())
+    assert rel_l2(x2, r2) < 1e-2 and rel_l2(x1, r1) < 1e-2
+
+
+def test_projector_rejects_dead_t5_path():
+    import x2i_amd.proj as XP
+    with pytest.raises(NotImplementedError):
+        XP.create_proj3_qwen7b(in_channels=29, use_t5=True, use_scale=False, use_cnn=True)

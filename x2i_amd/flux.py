@@ -1,0 +1,447 @@
+"""FLUX / shuttle-3 diffusion transformer on the HIP path.
+
+Mirrors the reference interface (diffusers 0.31 `FluxTransformer2DModel` as called at
+infer/inference_qwenvl.py:72-73,188-197 and train/train_qwenvl.py:578-587; in-repo composition
+lightcontrol/lightcontrol_flux.py:208-553): same constructor arguments, same state-dict key names
+(SURVEY.md Appendix B), same forward signature.  Everything numeric runs in libx2i_hip.so through x2i_amd.ops; this
+module only owns device memory and sequences kernel launches on the current HIP stream.
+
+Data layout in HBM (all bf16 unless noted)
+  X    [B, S, D]        joint residual stream, text tokens FIRST (S = S_txt + S_img) -- the reference's
+                        torch.cat([encoder_hidden_states, hidden_states], dim=1) (lightcontrol_flux.py:510) is free
+  NRM  [B, S, D]        LayerNorm+modulate output (A operand of the next GEMM)
+  QKV  [B*S, 3D]        fused q|k|v rows (double blocks: text rows then image rows)
+  Q,K  [B, H, Spad, 128], VT [B, H, 128, Spad]   attention operands (Spad = ceil128(S), zero padded)
+  CAT  [B*S, 5D]        single blocks: cols [0,D) attention out, [D,5D) GELU(proj_mlp) -- torch.cat(..., dim=2)
+                        (lightcontrol_flux.py:97) is never materialised separately
+  MOD  [B, Ntot] f32    every AdaLayerNorm* linear of the step in ONE skinny GEMM (temb is block-independent)
+Weights are stored fused (q|k|v, q|k|v|proj_mlp, all AdaLN linears) and exposed under the reference's parameter
+names as views, so load_state_dict() of a diffusers checkpoint fills the fused storage directly.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU_TANH, ACT_NONE, ACT_SILU
+
+
+class _P(nn.Module):
+    """A bag of parameters with reference names (weight / bias); values are views into fused storage."""
+
+    def __init__(self, **tensors):
+        super().__init__()
+        for k, v in tensors.items():
+            self.register_parameter(k, nn.Parameter(v, requires_grad=False))
+
+
+class _Seq(nn.Module):
+    """ModuleList-like container whose children are named by integers but may be sparse (e.g. net.0 / net.2)."""
+
+    def __init__(self, items):
+        super().__init__()
+        for k, v in items.items():
+            self.add_module(str(k), v)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+class FluxTransformer2DModel(nn.Module):
+    """Drop-in for diffusers' FluxTransformer2DModel (constructor: lightcontrol_flux.py:230-242)."""
+
+    def __init__(self, patch_size: int = 1, in_channels: int = 64, num_layers: int = 19, num_single_layers: int = 38,
+                 attention_head_dim: int = 128, num_attention_heads: int = 24, joint_attention_dim: int = 4096,
+                 pooled_projection_dim: int = 768, guidance_embeds: bool = False, axes_dims_rope=(16, 56, 56),
+                 device="cuda", dtype=torch.bfloat16):
+        super().__init__()
+        if attention_head_dim != 128:
+            raise ValueError("x2i_amd: the HIP attention kernel is built for attention_head_dim == 128 (FLUX)")
+        if dtype != torch.bfloat16:
+            raise ValueError("x2i_amd: the HIP path computes in bf16 (fp32 statistics/accumulation)")
+        if sum(axes_dims_rope) != attention_head_dim:
+            raise ValueError("sum(axes_dims_rope) must equal attention_head_dim")
+        self.config = _Config(patch_size=patch_size, in_channels=in_channels, num_layers=num_layers,
+                              num_single_layers=num_single_layers, attention_head_dim=attention_head_dim,
+                              num_attention_heads=num_attention_heads, joint_attention_dim=joint_attention_dim,
+                              pooled_projection_dim=pooled_projection_dim, guidance_embeds=guidance_embeds,
+                              axes_dims_rope=tuple(axes_dims_rope))
+        self.out_channels = in_channels
+        D = self.inner_dim = num_attention_heads * attention_head_dim
+        H = num_attention_heads
+        dev = torch.device(device)
+        self._fused = {}
+        self._views = []  # (param, fused name, index expression)
+
+        def store(name, *shape):
+            t = torch.empty(shape, device=dev, dtype=dtype)
+            self._fused[name] = t
+            return t
+
+        def view(name, sl):
+            t = self._fused[name][sl]
+            p = nn.Parameter(t, requires_grad=False)
+            self._views.append((p, name, sl))
+            return p
+
+        def lin_from(wname, bname, r0, r1):
+            m = nn.Module()
+            m.register_parameter("weight", view(wname, slice(r0, r1)))
+            m.register_parameter("bias", view(bname, slice(r0, r1)))
+            return m
+
+        def lin(prefix, out_f, in_f):
+            store(prefix + ".w", out_f, in_f)
+            store(prefix + ".b", out_f)
+            return lin_from(prefix + ".w", prefix + ".b", 0, out_f)
+
+        def norm_w(prefix):
+            store(prefix, 128)
+            m = nn.Module()
+            m.register_parameter("weight", view(prefix, slice(0, 128)))
+            return m
+
+        # ---- embedders (lightcontrol_flux.py:247-257)
+        self.x_embedder = lin("x_embedder", D, in_channels)
+        self.context_embedder = lin("context_embedder", D, joint_attention_dim)
+        tte = nn.Module()
+        for nm, in_f in (("timestep_embedder", 256), ("guidance_embedder", 256), ("text_embedder", pooled_projection_dim)):
+            if nm == "guidance_embedder" and not guidance_embeds:
+                continue
+            e = nn.Module()
+            e.add_module("linear_1", lin(f"tte.{nm}.1", D, in_f))
+            e.add_module("linear_2", lin(f"tte.{nm}.2", D, D))
+            tte.add_module(nm, e)
+        self.time_text_embed = tte
+
+        # ---- one modulation table for every AdaLayerNorm linear (norm1, norm1_context, norm, norm_out)
+        self._mod_rows = num_layers * 12 * D + num_single_layers * 3 * D + 2 * D
+        store("mod.w", self._mod_rows, D)
+        store("mod.b", self._mod_rows)
+
+        def mod_lin(r0, n):
+            m = nn.Module()
+            m.add_module("linear", lin_from("mod.w", "mod.b", r0, r0 + n))
+            return m
+
+        # ---- double-stream blocks (lightcontrol_flux.py:108-157)
+        blocks = []
+        for i in range(num_layers):
+            p = f"d{i}"
+            blk = nn.Module()
+            off = i * 12 * D
+            blk.add_module("norm1", mod_lin(off, 6 * D))
+            blk.add_module("norm1_context", mod_lin(off + 6 * D, 6 * D))
+            store(p + ".qkv.w", 3 * D, D), store(p + ".qkv.b", 3 * D)
+            store(p + ".cqkv.w", 3 * D, D), store(p + ".cqkv.b", 3 * D)
+            attn = nn.Module()
+            for j, nm in enumerate(("to_q", "to_k", "to_v")):
+                attn.add_module(nm, lin_from(p + ".qkv.w", p + ".qkv.b", j * D, (j + 1) * D))
+            for j, nm in enumerate(("add_q_proj", "add_k_proj", "add_v_proj")):
+                attn.add_module(nm, lin_from(p + ".cqkv.w", p + ".cqkv.b", j * D, (j + 1) * D))
+            for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                attn.add_module(nm, norm_w(p + "." + nm))
+            attn.add_module("to_out", _Seq({0: lin(p + ".to_out", D, D)}))
+            attn.add_module("to_add_out", lin(p + ".to_add_out", D, D))
+            blk.add_module("attn", attn)
+            for ffn in ("ff", "ff_context"):
+                g0 = nn.Module()
+                g0.add_module("proj", lin(f"{p}.{ffn}.0", 4 * D, D))
+                ff = nn.Module()
+                ff.add_module("net", _Seq({0: g0, 2: lin(f"{p}.{ffn}.2", D, 4 * D)}))
+                blk.add_module(ffn, ff)
+            blocks.append(blk)
+        self.transformer_blocks = nn.ModuleList(blocks)
+
+        # ---- single-stream blocks (lightcontrol_flux.py:45-80): q|k|v|proj_mlp fused along N
+        singles = []
+        base = num_layers * 12 * D
+        for i in range(num_single_layers):
+            p = f"s{i}"
+            blk = nn.Module()
+            blk.add_module("norm", mod_lin(base + i * 3 * D, 3 * D))
+            store(p + ".in.w", 7 * D, D), store(p + ".in.b", 7 * D)
+            attn = nn.Module()
+            for j, nm in enumerate(("to_q", "to_k", "to_v")):
+                attn.add_module(nm, lin_from(p + ".in.w", p + ".in.b", j * D, (j + 1) * D))
+            for nm in ("norm_q", "norm_k"):
+                attn.add_module(nm, norm_w(p + "." + nm))
+            blk.add_module("attn", attn)
+            blk.add_module("proj_mlp", lin_from(p + ".in.w", p + ".in.b", 3 * D, 7 * D))
+            blk.add_module("proj_out", lin(p + ".proj_out", D, 5 * D))
+            singles.append(blk)
+        self.single_transformer_blocks = nn.ModuleList(singles)
+
+        # ---- output head (lightcontrol_flux.py:281-282)
+        self.norm_out = mod_lin(base + num_single_layers * 3 * D, 2 * D)
+        self.proj_out = lin("proj_out", patch_size * patch_size * self.out_channels, D)
+        self._ws = {}
+        self._H = H
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    @property
+    def device(self):
+        return self._fused["proj_out.w"].device
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views of fused storage: move the storage, then re-point the views
+        for k in list(self._fused):
+            new = fn(self._fused[k])
+            if new.dtype != torch.bfloat16:
+                raise ValueError("x2i_amd FluxTransformer2DModel is bf16-only")
+            self._fused[k] = new
+        for p, name, sl in self._views:
+            p.data = self._fused[name][sl]
+        self._ws = {}
+        return self
+
+    @torch.no_grad()
+    def init_random_(self, seed=0, std=0.02):
+        """Random-init weights in place on the device (bench / smoke; there are no checkpoints offline)."""
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        for k, t in self._fused.items():
+            if k.endswith("norm_q") or k.endswith("norm_k") or k.endswith("norm_added_q") or k.endswith("norm_added_k"):
+                t.copy_(1.0 + 0.1 * torch.randn(t.shape, device=t.device, generator=gen))
+            else:
+                # fill in chunks to bound fp32 temporaries
+                flat = t.view(-1)
+                step = 1 << 26
+                for s in range(0, flat.numel(), step):
+                    n = min(step, flat.numel() - s)
+                    flat[s:s + n].copy_(std * torch.randn(n, device=t.device, generator=gen))
+        return self
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B, St, Si):
+        key = (B, St, Si)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        D, H = self.inner_dim, self._H
+        S = St + Si
+        Spad = ops.pad128(S)
+        dev = self.device
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        ws = dict(
+            S=S, Spad=Spad,
+            X=torch.empty((B, S, D), **bf), NRM=torch.empty((B, S, D), **bf), QKV=torch.empty((B * S, 3 * D), **bf),
+            Q=torch.zeros((B, H, Spad, 128), **bf), K=torch.zeros((B, H, Spad, 128), **bf),
+            VT=torch.zeros((B, H, 128, Spad), **bf), ATT=torch.empty((B, S, D), **bf),
+            CAT=torch.empty((B * S, 5 * D), **bf), NRMF=torch.empty((B * Si, D), **bf),
+            MOD=torch.empty((B, self._mod_rows), device=dev, dtype=torch.float32),
+            TEMB=torch.empty((B, D), device=dev, dtype=torch.float32),
+            COND=torch.empty((B, D), device=dev, dtype=torch.float32),
+            H1=torch.empty((B, D), device=dev, dtype=torch.float32),
+        )
+        self._ws = {key: ws}  # keep one shape resident
+        return ws
+
+    # ------------------------------------------------------------------ forward pieces
+    @torch.no_grad()
+    def prepare_conditioning(self, encoder_hidden_states, pooled_projections, txt_ids, img_ids, guidance=None):
+        """Step-invariant work hoisted out of the denoising loop: context_embedder, RoPE tables, and the
+        text/guidance halves of the conditioning embedding ("step-invariant -> hoist")."""
+        cfg = self.config
+        D = self.inner_dim
+        enc = encoder_hidden_states
+        B, St, Kj = enc.shape
+        if txt_ids.ndim == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.ndim == 3:
+            img_ids = img_ids[0]
+        Si = img_ids.shape[0]
+        ws = self._workspace(B, St, Si)
+        S = ws["S"]
+        f = self._fused
+        enc = enc.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        # context_embedder -> text rows of X (kept in CTX so that X can be rebuilt every step)
+        ctx = torch.empty((B, St, D), device=self.device, dtype=torch.bfloat16)
+        ops.gemm(enc, f["context_embedder.w"], f["context_embedder.b"], out=ctx, M=B * St)
+        # RoPE tables: FluxPosEmbed semantics (float64 frequencies), computed once with torch on the device
+        ids = torch.cat((txt_ids.to(self.device), img_ids.to(self.device)), dim=0)
+        cos, sin = _flux_pos_embed(ids, cfg.axes_dims_rope)
+        # conditioning: text_embedder(pooled) [+ guidance_embedder(guidance*1000)]
+        cond = ws["COND"]
+        pooled = pooled_projections.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        h1 = ops.skinny_linear(pooled, f["tte.text_embedder.1.w"], f["tte.text_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
+        ops.skinny_linear(h1, f["tte.text_embedder.2.w"], f["tte.text_embedder.2.b"], out=cond)
+        if cfg.guidance_embeds:
+            if guidance is None:
+                raise ValueError("guidance is required when config.guidance_embeds is True")
+            # `guidance.to(hidden_states.dtype) * 1000` (lightcontrol_flux.py:449): rounding follows the caller's dtype
+            g = (guidance.to(device=self.device, dtype=pooled_projections.dtype) * 1000).float().contiguous()
+            gp = ops.timestep_sinusoid(g, 256, round_bf16=pooled_projections.dtype == torch.bfloat16)
+            h1 = ops.skinny_linear(gp, f["tte.guidance_embedder.1.w"], f["tte.guidance_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
+            ops.skinny_linear(h1, f["tte.guidance_embedder.2.w"], f["tte.guidance_embedder.2.b"], out=cond, accumulate=True)
+        return dict(B=B, St=St, Si=Si, ctx=ctx, cos=cos, sin=sin, cond=cond, ws=ws,
+                    round_bf16=pooled_projections.dtype == torch.bfloat16)
+
+    @torch.no_grad()
+    def denoise(self, state, hidden_states, timestep, control=None):
+        """One transformer evaluation given prepared conditioning.  `control`: optional callable(i, timestep_x1000)
+        returning the [B, S_img, D] bf16 tensor added to the image stream after double block i, or None."""
+        cfg = self.config
+        f = self._fused
+        ws = state["ws"]
+        B, St, Si = state["B"], state["St"], state["Si"]
+        S, Spad = ws["S"], ws["Spad"]
+        D, H = self.inner_dim, self._H
+        X, NRM, QKV, Q, K, VT, ATT, CAT, MOD = (ws[k] for k in ("X", "NRM", "QKV", "Q", "K", "VT", "ATT", "CAT", "MOD"))
+        Ntot = self._mod_rows
+        hs = hidden_states.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        # ---- embed: text rows <- cached context embedding, image rows <- x_embedder(latents)
+        X[:, :St].copy_(state["ctx"])
+        ops.gemm(hs, f["x_embedder.w"], f["x_embedder.b"], out=X, M=Si, batch=B, a_batch_stride=Si * cfg.in_channels,
+                 lda=cfg.in_channels, c_batch_stride=S * D, ldc=D, c_offset=St * D)
+        # ---- temb = timestep_embedder(Timesteps(t*1000)) + cond   (lightcontrol_flux.py:447,452-456)
+        # `timestep.to(hidden_states.dtype) * 1000` -- in the reference's bf16 run this multiply rounds to bf16
+        # (750 -> 752); we follow the dtype the caller hands us, exactly as the reference module does.
+        t1000 = (timestep.to(device=self.device, dtype=hidden_states.dtype) * 1000).float().contiguous()
+        tp = ops.timestep_sinusoid(t1000, 256, round_bf16=state["round_bf16"])
+        h1 = ops.skinny_linear(tp, f["tte.timestep_embedder.1.w"], f["tte.timestep_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
+        temb = ws["TEMB"]
+        temb.copy_(state["cond"])
+        ops.skinny_linear(h1, f["tte.timestep_embedder.2.w"], f["tte.timestep_embedder.2.b"], out=temb, accumulate=True)
+        # ---- every AdaLN modulation vector of this step in one HBM-bound pass over 27% of the weights
+        ops.skinny_linear(temb, f["mod.w"], f["mod.b"], out=MOD, act_in=ACT_SILU)
+        cos, sin = state["cos"], state["sin"]
+        scale = 1.0 / math.sqrt(128.0)
+
+        def mod(off):
+            return MOD[:, off:]
+
+        qkv_txt = QKV  # rows [0, B*St)
+        qkv_img_off = B * St * 3 * D
+        # ---- double-stream blocks (lightcontrol_flux.py:159-204)
+        for i in range(cfg.num_layers):
+            p = f"d{i}"
+            oi = i * 12 * D
+            oc = oi + 6 * D
+            ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
+            ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=QKV, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                     a_offset=St * D, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
+            ops.gemm(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], out=QKV, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                     c_batch_stride=St * 3 * D, ldc=3 * D)
+            ops.qkv_split(qkv_txt, QKV.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"],
+                          f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
+            ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
+            # hidden += gate_msa * to_out(attn_img) ; enc += c_gate_msa * to_add_out(attn_txt)
+            ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                     a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
+                     res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
+            ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=X, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                     c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
+                     gate_batch_stride=Ntot)
+            # feed-forward of both streams
+            ops.ln_modulate(X, NRM, B, S, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oi + 3 * D), mod(oi + 4 * D), Ntot)
+            ffh_img_off = B * St * 4 * D
+            ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=CAT, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                     a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ffh_img_off, act=ACT_GELU_TANH)
+            ops.gemm(CAT, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D,
+                     a_offset=ffh_img_off, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D,
+                     ldr=D, res_offset=St * D, gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
+            ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=CAT, M=St, batch=B, a_batch_stride=S * D,
+                     lda=D, c_batch_stride=St * 4 * D, ldc=4 * D, act=ACT_GELU_TANH)
+            ops.gemm(CAT, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=X, M=St, batch=B,
+                     a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D,
+                     gate=mod(oc + 5 * D), gate_batch_stride=Ntot)
+            if control is not None:
+                c = control(i, t1000)
+                if c is not None:
+                    X[:, St:].add_(c)  # lightcontrol_flux.py:504-507 (scale == 1.0)
+        # ---- single-stream blocks on the joint sequence (lightcontrol_flux.py:82-104)
+        base = cfg.num_layers * 12 * D
+        for i in range(cfg.num_single_layers):
+            p = f"s{i}"
+            o = base + i * 3 * D
+            ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
+            w, bias = f[p + ".in.w"], f[p + ".in.b"]
+            ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)
+            ops.gemm(NRM, w[3 * D:], bias[3 * D:], out=CAT, M=B * S, N=4 * D, ldc=5 * D, c_offset=D, act=ACT_GELU_TANH)
+            ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
+                          Q, K, VT, Spad)
+            ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+            ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D,
+                     lda=5 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(o + 2 * D),
+                     gate_batch_stride=Ntot)
+        # ---- norm_out (AdaLayerNormContinuous: scale first, then shift) + proj_out on the image tokens (:540-543)
+        o = base + cfg.num_single_layers * 3 * D
+        NRMF = ws["NRMF"]
+        ops.ln_modulate(X, NRMF, B, Si, D, 0, None, None, mod(o + D), mod(o), Ntot, x_bs=S * D, ldx=D, y_bs=Si * D, ldy=D,
+                        x_offset=St * D)
+        out = torch.empty((B, Si, self.out_channels * cfg.patch_size ** 2), device=self.device, dtype=torch.bfloat16)
+        ops.gemm(NRMF, f["proj_out.w"], f["proj_out.b"], out=out, M=B * Si)
+        return out
+
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,
+                txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict: bool = True):
+        """diffusers signature; returns (sample,) when return_dict=False (train/train_qwenvl.py:578-587 takes [0])."""
+        state = self.prepare_conditioning(encoder_hidden_states, pooled_projections, txt_ids, img_ids, guidance)
+        out = self.denoise(state, hidden_states, timestep)
+        if not return_dict:
+            return (out,)
+        return Transformer2DModelOutput(sample=out)
+
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_config(cls, config, **kw):
+        keys = ("patch_size", "in_channels", "num_layers", "num_single_layers", "attention_head_dim",
+                "num_attention_heads", "joint_attention_dim", "pooled_projection_dim", "guidance_embeds", "axes_dims_rope")
+        return cls(**{k: config[k] for k in keys if k in config}, **kw)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder: Optional[str] = None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+        """Load a diffusers-format FLUX transformer directory (config.json + *.safetensors shards)."""
+        import glob
+        import json
+        import os
+
+        from safetensors import safe_open
+
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "config.json")) as fh:
+            cfg = json.load(fh)
+        model = cls.from_config(cfg, device=device, dtype=torch_dtype)
+        own = dict(model.named_parameters())
+        seen = set()
+        for shard in sorted(glob.glob(os.path.join(d, "*.safetensors"))):
+            with safe_open(shard, framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    if k not in own:
+                        raise KeyError(f"unexpected key {k} in {shard}")
+                    own[k].data.copy_(sf.get_tensor(k))
+                    seen.add(k)
+        missing = set(own) - seen
+        if missing:
+            raise KeyError(f"missing keys in checkpoint: {sorted(missing)[:8]} ...")
+        return model
+
+
+class _Config(dict):
+    """config object with attribute access (`transformer.config.in_channels`, `.guidance_embeds`)."""
+
+    __getattr__ = dict.__getitem__
+
+
+class Transformer2DModelOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+def _flux_pos_embed(ids, axes_dim, theta=10000):
+    """FluxPosEmbed: float64 frequencies, repeat-interleaved, returned as fp32 [S,128].
+    Step-invariant table built once per prompt with torch on the device (host plumbing, not a hot kernel)."""
+    pos = ids.float()
+    cos_out, sin_out = [], []
+    for i, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=ids.device)[: d // 2] / d))
+        ang = torch.outer(pos[:, i].to(torch.float64), freqs)
+        cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+        sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos_out, dim=-1).contiguous(), torch.cat(sin_out, dim=-1).contiguous()

@@ -1,0 +1,240 @@
+"""Sampling pipeline with the call surface the reference's inference scripts use on diffusers' FluxPipeline
+(infer/inference_qwenvl.py:72-73,188-217; restated semantics: SURVEY.md Appendix A.1):
+
+    pipeline = FluxPipeline(transformer, scheduler)
+    latents = pipeline(prompt_embeds=..., pooled_prompt_embeds=..., num_inference_steps=4, guidance_scale=3.5,
+                       height=1024, width=1024, output_type="latent"[, generator=...][, latents=...]).images
+    latents = FluxPipeline._unpack_latents(latents, height, width, vae_scale_factor)
+
+The loop body (transformer + Euler update) runs entirely in libx2i_hip.so; with `use_graph=True` the whole N-step
+loop is captured once into a hipGraph (per shape) and replayed -- timesteps and sigma deltas are device-side inputs.
+Batch > 1 and batch sharding over ranks (x2i_amd.dist) are this build's extension along the axis the API already has
+(`prompt_embeds.shape[0]`).
+"""
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """diffusers 0.31 FlowMatchEulerDiscreteScheduler (the subset FluxPipeline drives): set_timesteps(sigmas=, mu=)
+    and step().  Config keys as in scheduler/scheduler_config.json of the checkpoint."""
+
+    def __init__(self, num_train_timesteps: int = 1000, shift: float = 1.0, use_dynamic_shifting: bool = False,
+                 base_shift: float = 0.5, max_shift: float = 1.15, base_image_seq_len: int = 256,
+                 max_image_seq_len: int = 4096):
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=use_dynamic_shifting,
+                           base_shift=base_shift, max_shift=max_shift, base_image_seq_len=base_image_seq_len,
+                           max_image_seq_len=max_image_seq_len)
+        ts = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        sig = ts / num_train_timesteps
+        if not use_dynamic_shifting:
+            sig = shift * sig / (1 + (shift - 1) * sig)
+        self.sigma_min, self.sigma_max = float(sig[-1]), float(sig[0])
+        self.timesteps = torch.from_numpy(sig * num_train_timesteps)
+        self.sigmas = torch.from_numpy(sig)
+        self._step_index = None
+
+    @classmethod
+    def from_config(cls, cfg):
+        keys = ("num_train_timesteps", "shift", "use_dynamic_shifting", "base_shift", "max_shift", "base_image_seq_len",
+                "max_image_seq_len")
+        return cls(**{k: cfg[k] for k in keys if k in cfg})
+
+    @staticmethod
+    def time_shift(mu, sigma, t):
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        c = self.config
+        if c.use_dynamic_shifting and mu is None:
+            raise ValueError(" you have a pass a value for `mu` when `use_dynamic_shifting` is set to be `True`")
+        if sigmas is None:
+            ts = np.linspace(self.sigma_max * c.num_train_timesteps, self.sigma_min * c.num_train_timesteps, num_inference_steps)
+            sigmas = ts / c.num_train_timesteps
+        sigmas = np.asarray(sigmas, dtype=np.float64)
+        if c.use_dynamic_shifting:
+            sigmas = self.time_shift(mu, 1.0, sigmas)
+        else:
+            sigmas = c.shift * sigmas / (1 + (c.shift - 1) * sigmas)
+        sigmas = torch.from_numpy(np.asarray(sigmas)).to(dtype=torch.float32, device=device)
+        self.timesteps = (sigmas * c.num_train_timesteps).to(device=device)
+        self.sigmas = torch.cat([sigmas, torch.zeros(1, device=sigmas.device)])
+        self._step_index = 0
+
+    def step(self, model_output, timestep, sample, return_dict=False):
+        """x <- bf16(f32(x) + (sigma_next - sigma) * eps), on the HIP path."""
+        i = self._step_index
+        dt = (self.sigmas[i + 1] - self.sigmas[i]).reshape(1).to(device=sample.device, dtype=torch.float32)
+        if sample.dtype == torch.bfloat16 and model_output.dtype == torch.bfloat16:
+            prev = ops.euler_step_(sample.clone(), model_output.contiguous(), dt)
+        else:  # fp32 latents in, model dtype out (diffusers casts to model_output.dtype)
+            prev = (sample.to(torch.float32) + dt * model_output).to(model_output.dtype)
+        self._step_index += 1
+        return (prev,)
+
+
+def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4096, base_shift: float = 0.5,
+                    max_shift: float = 1.16):
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+class FluxPipelineOutput:
+    def __init__(self, images):
+        self.images = images
+
+
+class FluxPipeline:
+    """`transformer`: x2i_amd.flux.FluxTransformer2DModel; `scheduler`: FlowMatchEulerDiscreteScheduler."""
+
+    def __init__(self, transformer, scheduler=None, vae=None, control_nets=None):
+        self.transformer = transformer
+        self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
+        self.vae = vae
+        self.vae_scale_factor = 16  # diffusers 0.31: 2 ** len(vae.config.block_out_channels) == 16 for FLUX
+        self.default_sample_size = 64
+        self.control_nets = control_nets
+        self._graphs = {}
+
+    def to(self, device):
+        self.transformer.to(device)
+        return self
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    # ---- static helpers with the reference's names (copies: train/train_qwenvl.py:216-234, train_lightcontrol.py:403-410)
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        latents = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2)
+        latents = latents.permute(0, 2, 4, 1, 3, 5)
+        return latents.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        batch_size, num_patches, channels = latents.shape
+        height = height // vae_scale_factor
+        width = width // vae_scale_factor
+        latents = latents.view(batch_size, height, width, channels // 4, 2, 2)
+        latents = latents.permute(0, 3, 1, 4, 2, 5)
+        return latents.reshape(batch_size, channels // (2 * 2), height * 2, width * 2)
+
+    @staticmethod
+    def _prepare_latent_image_ids(batch_size, height, width, device, dtype):
+        """height/width are the PACKED grid sizes (diffusers 0.31 convention)."""
+        ids = torch.zeros(height, width, 3)
+        ids[..., 1] = ids[..., 1] + torch.arange(height)[:, None]
+        ids[..., 2] = ids[..., 2] + torch.arange(width)[None, :]
+        return ids.reshape(height * width, 3).to(device=device, dtype=dtype)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        height = 2 * (int(height) // self.vae_scale_factor)
+        width = 2 * (int(width) // self.vae_scale_factor)
+        ids = self._prepare_latent_image_ids(batch_size, height // 2, width // 2, device, dtype)
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype), ids
+        shape = (batch_size, num_channels_latents, height, width)
+        gdev = generator.device if generator is not None else device
+        noise = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)  # randn_tensor semantics
+        return self._pack_latents(noise, batch_size, num_channels_latents, height, width), ids
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds=None, pooled_prompt_embeds=None, num_inference_steps: int = 28,
+                 guidance_scale: float = 3.5, height: Optional[int] = None, width: Optional[int] = None,
+                 output_type: str = "latent", generator=None, latents=None, guided_hint=None, use_graph: bool = False,
+                 return_dict: bool = True, **unused):
+        if prompt_embeds is None or pooled_prompt_embeds is None:
+            raise ValueError("x2i_amd FluxPipeline is driven by prompt_embeds/pooled_prompt_embeds (no text encoders), "
+                             "as every reference inference script does")
+        if output_type != "latent":
+            raise ValueError('only output_type="latent" is on the hot path (VAE decode is the caller\'s, as in the reference)')
+        tr = self.transformer
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        if height % 16 or width % 16:
+            raise ValueError("height and width must be multiples of 16")
+        device = tr.device
+        dtype = prompt_embeds.dtype
+        B = prompt_embeds.shape[0]
+        prompt_embeds = prompt_embeds.to(device)
+        pooled_prompt_embeds = pooled_prompt_embeds.to(device)
+        txt_ids = torch.zeros(prompt_embeds.shape[1], 3, device=device, dtype=dtype)
+        C = tr.config.in_channels // 4
+        latents, img_ids = self.prepare_latents(B, C, height, width, dtype, device, generator, latents)
+        sc = self.scheduler.config
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        mu = calculate_shift(latents.shape[1], sc.base_image_seq_len, sc.max_image_seq_len, sc.base_shift, sc.max_shift)
+        self.scheduler.set_timesteps(sigmas=sigmas, device=device, mu=mu)
+        timesteps = self.scheduler.timesteps
+        guidance = None
+        if tr.config.guidance_embeds:
+            guidance = torch.full([1], guidance_scale, device=device, dtype=torch.float32).expand(B)
+        hint = guided_hint.to(device) if (self.control_nets is not None and guided_hint is not None) else None
+        latents = latents.contiguous()
+        if latents.dtype != torch.bfloat16:
+            # fp32 callers (parity tests): keep the scheduler arithmetic in fp32 like diffusers does
+            state = tr.prepare_conditioning(prompt_embeds, pooled_prompt_embeds, txt_ids, img_ids, guidance)
+            control = self._control_fn(hint)
+            for i, t in enumerate(timesteps):
+                ts = t.expand(B).to(latents.dtype)
+                noise = tr.denoise(state, latents, ts / 1000, control=control)
+                latents = self.scheduler.step(noise.to(latents.dtype), t, latents)[0]
+            return FluxPipelineOutput(latents) if return_dict else (latents,)
+
+        dts = (self.scheduler.sigmas[1:] - self.scheduler.sigmas[:-1]).to(device=device, dtype=torch.float32).contiguous()
+        tvals = [(t.expand(B).to(torch.bfloat16) / 1000).contiguous() for t in timesteps]
+
+        def body(pe, pooled, lat, hnt):
+            """prepare + N x (transformer, Euler) -- every launch goes to the current stream (graph-capturable)."""
+            state = tr.prepare_conditioning(pe, pooled, txt_ids, img_ids, guidance)
+            control = self._control_fn(hnt)
+            for i in range(len(tvals)):
+                noise = tr.denoise(state, lat, tvals[i], control=control)
+                ops.euler_step_(lat, noise, dts[i:i + 1])
+
+        if not use_graph:
+            latents = latents.clone()
+            body(prompt_embeds, pooled_prompt_embeds, latents, hint)
+            return FluxPipelineOutput(latents) if return_dict else (latents,)
+
+        key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = dict(pe=prompt_embeds.clone(), pooled=pooled_prompt_embeds.clone(), lat=latents.clone(),
+                          hint=None if hint is None else hint.clone())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up: lazy allocations, kernel attributes
+                body(static["pe"], static["pooled"], static["lat"], static["hint"])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body(static["pe"], static["pooled"], static["lat"], static["hint"])
+            entry = (graph, static, dts, tvals)  # keep device-side schedule tensors alive with the graph
+            self._graphs = {key: entry}
+        graph, static = entry[0], entry[1]
+        static["pe"].copy_(prompt_embeds)
+        static["pooled"].copy_(pooled_prompt_embeds)
+        static["lat"].copy_(latents)
+        if hint is not None:
+            static["hint"].copy_(hint)
+        graph.replay()
+        out = static["lat"].clone()
+        return FluxPipelineOutput(out) if return_dict else (out,)
+
+    def _control_fn(self, hint):
+        if hint is None:
+            return None
+        from .lightcontrol import make_control_fn
+        return make_control_fn(self.control_nets, hint)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__

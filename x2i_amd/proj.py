@@ -1,0 +1,154 @@
+"""MLLM -> T5-slot / CLIP-slot alignment projector on the HIP path.
+
+Same surface as the reference's utils/proj.py (class names, factory names and arguments, state-dict keys, return
+order): `pooled, prompt_embeds = proj(text_embeddings)` with text_embeddings [B, C, S, H]
+(infer/inference_qwenvl.py:77-94,179).  `use_t5=True` is dead code in the reference (T5Stack is never imported,
+utils/proj.py:42,46) and is rejected here.
+
+Kernel chain (all in libx2i_hip.so):
+  layer fusion   proj_conv5x5 | proj_layer_mean           HBM-bound, reads the 78-106 MB/sample input once
+  LayerNorm(H)   ln_affine                                 wave-per-row
+  Linear+GELU    gemm (GELU-erf epilogue)                  MFMA
+  Linear         gemm, dual output: x2 and GELU(x2)        MFMA (second output feeds fc without an extra pass)
+  fc Linear      gemm -> f32 [B,S,768], then seq_mean      MFMA + tiny reduction
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU_ERF, ACT_NONE
+
+
+def _param(*shape, device, dtype):
+    return nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
+
+
+class _LN(nn.Module):
+    def __init__(self, dim, device, dtype):
+        super().__init__()
+        self.weight = _param(dim, device=device, dtype=dtype)
+        self.bias = _param(dim, device=device, dtype=dtype)
+
+
+class _Lin(nn.Module):
+    def __init__(self, i, o, bias, device, dtype):
+        super().__init__()
+        self.weight = _param(o, i, device=device, dtype=dtype)
+        if bias:
+            self.bias = _param(o, device=device, dtype=dtype)
+        else:
+            self.bias = None
+
+
+class _Sparse(nn.Module):
+    def __init__(self, items):
+        super().__init__()
+        for k, v in items.items():
+            self.add_module(str(k), v)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+class MLP3(nn.Module):
+    """utils/proj.py:14-33.  Keys: layernorm.{weight,bias}, projector.{0,2}.weight, fc.1.{weight,bias}."""
+
+    def __init__(self, in_dim=4096, out_dim=4096, hidden_dim=4096, out_dim1=768, layer_norm_eps=1e-5, use_residual=True,
+                 device="cuda", dtype=torch.bfloat16):
+        super().__init__()
+        self.eps = layer_norm_eps
+        self.layernorm = _LN(in_dim, device, dtype)
+        self.projector = _Sparse({0: _Lin(in_dim, hidden_dim, False, device, dtype), 2: _Lin(hidden_dim, hidden_dim, False, device, dtype)})
+        self.fc = _Sparse({1: _Lin(out_dim, out_dim1, True, device, dtype)})
+
+    @torch.no_grad()
+    def forward(self, x):
+        B, S, H = x.shape
+        x = x.to(torch.bfloat16).contiguous()
+        xn = ops.ln_affine(x, self.layernorm.weight, self.layernorm.bias, self.eps)  # :29
+        h = ops.gemm(xn, self.projector[0].weight, act=ACT_GELU_ERF, M=B * S)  # :18-19
+        x2 = torch.empty((B, S, self.projector[2].weight.shape[0]), device=x.device, dtype=torch.bfloat16)
+        g2 = torch.empty_like(x2)
+        ops.gemm(h, self.projector[2].weight, out=x2, out2=g2, act2=ACT_GELU_ERF, M=B * S)  # :20 and the GELU of :23
+        x1_tok = ops.gemm(g2, self.fc[1].weight, self.fc[1].bias, M=B * S, out_f32=True)  # :24
+        x1 = ops.seq_mean(x1_tok.view(B, S, -1))  # :32
+        return x1.to(torch.bfloat16), x2
+
+
+class Proj7Exp(nn.Module):
+    """utils/proj.py:35-72 with use_t5=False.  Keys: conv.{weight,bias} | cha_scale, mlp.*"""
+
+    def __init__(self, in_channels=25, kernel_size=5, input_dim=896, output_dim0=768, output_dim1=4096, num_layers=2,
+                 num_heads=12, norm_eps=1e-6, head_dim=64, use_t5=True, use_scale=True, use_cnn=True, device="cuda",
+                 dtype=torch.bfloat16):
+        super().__init__()
+        if use_t5:
+            raise NotImplementedError(
+                "use_t5=True is dead code in the reference (utils/proj.py:42 raises NameError: T5Config); "
+                "every inference script passes use_t5=False")
+        if kernel_size != 5:
+            raise ValueError("the HIP layer-fusion kernel implements the reference's 5x5 convolution")
+        self.use_t5, self.use_scale, self.use_cnn = use_t5, use_scale, use_cnn
+        if use_scale:
+            self.cha_scale = _param(1, in_channels, 1, 1, device=device, dtype=dtype)
+        elif use_cnn:
+            conv = nn.Module()
+            conv.weight = _param(1, in_channels, kernel_size, kernel_size, device=device, dtype=dtype)
+            conv.bias = _param(1, device=device, dtype=dtype)
+            self.conv = conv
+        self.mlp = MLP3(input_dim, output_dim1, output_dim1, output_dim0, norm_eps, device=device, dtype=dtype)
+
+    @torch.no_grad()
+    def forward(self, x):
+        B, C, S, H = x.shape
+        x = x.to(torch.bfloat16).contiguous()
+        if self.use_scale:
+            x = ops.proj_layer_mean(x, self.cha_scale.float().reshape(-1).contiguous())  # :66-67
+        elif self.use_cnn:
+            x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())  # :68-69
+        else:
+            x = ops.proj_layer_mean(x, None)  # :70-71
+        return self.mlp(x)  # :72
+
+    @torch.no_grad()
+    def init_random_(self, seed=0):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n, p in self.named_parameters():
+            if n.endswith("layernorm.weight"):
+                v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+            elif p.dim() >= 2:
+                fan_in = p[0].numel()
+                v = torch.randn(p.shape, generator=g) / fan_in ** 0.5
+            else:
+                v = 0.02 * torch.randn(p.shape, generator=g)
+            p.copy_(v)
+        return self
+
+
+# ---- factories: names, arguments and per-model dimensions as utils/proj.py:74-96 (prints dropped)
+def create_proj3_qwen3b(in_channels, use_t5=True, use_scale=True, use_cnn=False, **kw):
+    use_cnn = False if use_scale else use_cnn
+    return Proj7Exp(in_channels=in_channels, kernel_size=5, input_dim=2048, output_dim0=768, output_dim1=4096, num_layers=2,
+                    num_heads=28, norm_eps=1e-6, head_dim=128, use_t5=use_t5, use_scale=use_scale, use_cnn=use_cnn, **kw)
+
+
+def create_proj3_qwen7b(in_channels, use_t5=True, use_scale=True, use_cnn=False, **kw):
+    use_cnn = False if use_scale else use_cnn
+    return Proj7Exp(in_channels=in_channels, kernel_size=5, input_dim=3584, output_dim0=768, output_dim1=4096, num_layers=2,
+                    num_heads=28, norm_eps=1e-6, head_dim=128, use_t5=use_t5, use_scale=use_scale, use_cnn=use_cnn, **kw)
+
+
+def create_proj_internvl1b(in_channels, use_t5=True, use_scale=True, use_cnn=True, **kw):
+    return Proj7Exp(in_channels=in_channels, kernel_size=5, input_dim=896, output_dim0=768, output_dim1=4096, num_layers=2,
+                    num_heads=12, norm_eps=1e-6, head_dim=64, use_t5=use_t5, use_scale=use_scale, use_cnn=use_cnn, **kw)
+
+
+def create_proj_internvl4b(in_channels, use_t5=True, use_scale=False, use_cnn=True, **kw):
+    return Proj7Exp(in_channels=in_channels, kernel_size=5, input_dim=2048, output_dim0=768, output_dim1=4096, num_layers=2,
+                    num_heads=16, norm_eps=1e-6, head_dim=128, use_t5=use_t5, use_scale=use_scale, use_cnn=use_cnn, **kw)
+
+
+def create_proj_minicpm(in_channels, use_t5=True, use_scale=True, use_cnn=False, **kw):
+    use_cnn = False if use_scale else use_cnn
+    return Proj7Exp(in_channels=in_channels, kernel_size=5, input_dim=3584, output_dim0=768, output_dim1=4096, num_layers=2,
+                    num_heads=28, norm_eps=1e-6, head_dim=128, use_t5=use_t5, use_scale=use_scale, use_cnn=use_cnn, **kw)
