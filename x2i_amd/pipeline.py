@@ -191,9 +191,13 @@ class FluxPipeline:
         dts = (self.scheduler.sigmas[1:] - self.scheduler.sigmas[:-1]).to(device=device, dtype=torch.float32).contiguous()
         tvals = [(t.expand(B).to(torch.bfloat16) / 1000).contiguous() for t in timesteps]
 
+        # every tensor the captured launches read lives in `aux` so that it stays alive (and in place) with the graph
+        aux = dict(txt_ids=txt_ids, img_ids=img_ids, guidance=guidance, dts=dts, tvals=tvals,
+                   ws=tr._workspace(B, prompt_embeds.shape[1], latents.shape[1]))
+
         def body(pe, pooled, lat, hnt):
             """prepare + N x (transformer, Euler) -- every launch goes to the current stream (graph-capturable)."""
-            state = tr.prepare_conditioning(pe, pooled, txt_ids, img_ids, guidance)
+            state = tr.prepare_conditioning(pe, pooled, aux["txt_ids"], aux["img_ids"], aux["guidance"])
             control = self._control_fn(hnt)
             for i in range(len(tvals)):
                 noise = tr.denoise(state, lat, tvals[i], control=control)
@@ -217,7 +221,7 @@ class FluxPipeline:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 body(static["pe"], static["pooled"], static["lat"], static["hint"])
-            entry = (graph, static, dts, tvals)  # keep device-side schedule tensors alive with the graph
+            entry = (graph, static, aux)  # ids / guidance / schedule tensors must outlive the call: the graph reads them
             self._graphs = {key: entry}
         graph, static = entry[0], entry[1]
         static["pe"].copy_(prompt_embeds)
