@@ -1,0 +1,75 @@
+"""The N>1 path (batch sharding + one all-gather of the final latents) on 2 CPU processes with gloo."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeOut:
+    def __init__(self, images):
+        self.images = images
+
+
+def _fake_pipeline(prompt_embeds=None, pooled_prompt_embeds=None, latents=None, guided_hint=None, **kw):
+    # deterministic per-sample function: no cross-sample term, like the real sampler
+    return _FakeOut(latents * 2 + prompt_embeds.mean(dim=(1, 2))[:, None, None] + pooled_prompt_embeds.sum(1)[:, None, None])
+
+
+def _worker(rank, world, port, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from x2i_amd import dist as xd
+    r, w = xd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    pe, pooled, lat = torch.randn((total, 5, 8), generator=g), torch.randn((total, 4), generator=g), torch.randn((total, 6, 3), generator=g)
+    full = xd.sample_sharded(_fake_pipeline, pe, pooled, latents=lat)
+    want = _fake_pipeline(pe, pooled, lat).images
+    ok = torch.equal(full, want)
+    lo, hi = xd.shard_range(total, rank, world)
+    out.put((rank, ok, lo, hi))
+    torch.distributed.destroy_process_group()
+
+
+def _run(total, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def test_even_batch_two_ranks():
+    res = _run(4)
+    assert all(ok for _, ok, _, _ in res)
+    assert [(lo, hi) for _, _, lo, hi in res] == [(0, 2), (2, 4)]
+
+
+def test_uneven_batch_two_ranks():
+    res = _run(5)
+    assert all(ok for _, ok, _, _ in res)
+    assert [(lo, hi) for _, _, lo, hi in res] == [(0, 3), (3, 5)]
+
+
+def test_shard_range_covers_everything():
+    from x2i_amd.dist import shard_range
+    for n in range(0, 20):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

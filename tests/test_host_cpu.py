@@ -1,0 +1,116 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the host modules mirror the
+reference's parameter tree, the scheduler/pipeline helpers match the oracle and the reference goldens, and the product
+path refuses to run without the HIP device (no silent fallback)."""
+import math
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import flux as OF
+from oracle import projector as OP
+from oracle import sampler as OS
+from tests.util import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from x2i_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "x2i.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(x2i_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/x2i.h but not exported by libx2i_hip.so"
+    bound = set(_lib.SIGNATURES) | {"x2i_abi_version", "x2i_last_error"}
+    assert declared == bound, (declared ^ bound)
+    assert lib.x2i_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    from x2i_amd import ops
+    from x2i_amd._lib import X2IError
+    with pytest.raises(X2IError):
+        ops.gemm(torch.zeros((64, 64), dtype=torch.bfloat16), torch.zeros((64, 64), dtype=torch.bfloat16))
+    with pytest.raises(X2IError):
+        ops.ln_affine(torch.zeros((4, 64), dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16),
+                      torch.zeros(64, dtype=torch.bfloat16), 1e-6)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "x2i_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+@pytest.mark.parametrize("guidance", [False, True])
+def test_transformer_parameter_tree_matches_reference(guidance):
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG, guidance_embeds=guidance)
+    m = FluxTransformer2DModel(**cfg, device="meta")
+    want = OF.flux_param_shapes(cfg)  # strict-loaded into the reference module tree by make_golden.py
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    n = sum(math.prod(s) for s in got.values())
+    assert abs(n / 1e9 - (11.901 if guidance else 11.891)) < 0.002
+    assert m.config.in_channels == 64 and m.config.guidance_embeds == guidance and m.dtype == torch.bfloat16
+
+
+def test_fused_storage_is_filled_through_reference_names():
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG, num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=64,
+               pooled_projection_dim=32)
+    sd = {k: v.bfloat16() for k, v in OF.random_flux_state_dict(cfg, seed=5).items()}
+    m = FluxTransformer2DModel(**cfg, device="cpu")
+    m.load_state_dict(sd, strict=True)
+    D = 256
+    assert torch.equal(m._fused["s0.in.w"][:D], sd["single_transformer_blocks.0.attn.to_q.weight"])
+    assert torch.equal(m._fused["s0.in.w"][3 * D:], sd["single_transformer_blocks.0.proj_mlp.weight"])
+    assert torch.equal(m._fused["d0.cqkv.w"][2 * D:], sd["transformer_blocks.0.attn.add_v_proj.weight"])
+    assert torch.equal(m._fused["mod.w"][6 * D:12 * D], sd["transformer_blocks.0.norm1_context.linear.weight"])
+    assert torch.equal(m._fused["mod.b"][-2 * D:], sd["norm_out.linear.bias"])
+    with pytest.raises(ValueError):
+        FluxTransformer2DModel(attention_head_dim=64, device="meta")
+
+
+@pytest.mark.parametrize("kind", list(OP.FACTORIES))
+def test_projector_parameter_tree_matches_reference(kind):
+    import x2i_amd.proj as XP
+    C = OP.FACTORIES[kind]["in_channels"]
+    make = dict(qwen3b=XP.create_proj3_qwen3b, qwen7b=XP.create_proj3_qwen7b, internvl1b=XP.create_proj_internvl1b,
+                internvl4b=XP.create_proj_internvl4b, minicpm=XP.create_proj_minicpm)[kind]
+    use_scale = kind == "internvl1b"
+    p = make(in_channels=C, use_t5=False, use_scale=use_scale, use_cnn=True, device="meta")
+    want = OP.random_proj_state_dict(kind, seed=0)
+    assert {k: tuple(v.shape) for k, v in p.state_dict().items()} == {k: tuple(v.shape) for k, v in want.items()}
+
+
+def test_scheduler_and_helpers_match_oracle_and_reference():
+    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler, calculate_shift
+    for sc, n, seq in ((OS.SCHEDULER_SCHNELL, 4, 4096), (OS.SCHEDULER_DEV, 20, 4096), (OS.SCHEDULER_DEV, 28, 1024)):
+        s = FlowMatchEulerDiscreteScheduler(**sc)
+        import numpy as np
+        mu = calculate_shift(seq, sc["base_image_seq_len"], sc["max_image_seq_len"], sc["base_shift"], sc["max_shift"])
+        s.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu)
+        ts, sig = OS.flow_match_sigmas(n, sc, seq)
+        assert torch.allclose(s.sigmas, sig, atol=1e-7) and torch.allclose(s.timesteps, ts, atol=1e-4)
+    t, meta = golden("helpers")
+    assert torch.equal(FluxPipeline._pack_latents(t["lat"], 2, 16, 8, 12), t["packed"])
+    assert torch.equal(FluxPipeline._unpack_latents(t["packed"], 64, 96, 16), t["unpacked"])
+    assert torch.equal(FluxPipeline._prepare_latent_image_ids(2, 4, 6, "cpu", torch.float32), t["ids"])
+    assert abs(calculate_shift(4096) - float(t["shifts"][2])) < 1e-12
+
+
+def test_scheduler_step_fp32_path_on_cpu():
+    from x2i_amd.pipeline import FlowMatchEulerDiscreteScheduler
+    import numpy as np
+    s = FlowMatchEulerDiscreteScheduler()
+    s.set_timesteps(sigmas=np.linspace(1.0, 0.25, 4))
+    x, e = torch.randn(2, 8, 4), torch.randn(2, 8, 4)
+    y = s.step(e, s.timesteps[0], x)[0]
+    assert torch.allclose(y, x - 0.25 * e)
