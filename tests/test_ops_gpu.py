@@ -39,6 +39,21 @@ def test_gemm_plain_bias(ops, M, N, K):
     assert rel_l2(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (700, 520, 320), (1024, 1024, 3072)])
+def test_gemm_both_tile_kernels(ops, monkeypatch, tile, M, N, K):
+    """Force the 128x128 and the 256x256 pipelined kernels on the same problems (ragged edges, 1..48 K-tiles)."""
+    monkeypatch.setenv("X2I_GEMM_TILE", tile)
+    A, W, b = bf(seeded((M, K), 40)), bf(seeded((N, K), 41, 0.05)), bf(seeded((N,), 42))
+    res = bf(seeded((M, N), 43))
+    gate = seeded((1, N), 44)
+    out = ops.gemm(g(A), g(W), g(b), act=1)
+    assert rel_l2(out, F.gelu(F.linear(A.float(), W.float(), b.float()), approximate="tanh")) < 1e-2
+    out = g(res).clone()
+    ops.gemm(g(A), g(W), g(b), out=out, res=out, gate=g(gate))
+    assert rel_l2(out, res.float() + gate * F.linear(A.float(), W.float(), b.float())) < 1e-2
+
+
 def test_gemm_detects_transposes_identity_times_asymmetric():
     from x2i_amd import ops
     K = N = 128

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Launch a handful of GEMM / attention kernels at FLUX shapes (for rocprofv3 --pmc passes)."""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from x2i_amd import ops
+
+B, D, H, S = 4, 3072, 24, 4608
+def rnd(*s, scale=1.0):
+    return (torch.randn(*s, device="cuda") * scale).bfloat16()
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "gemm"):
+    for (M, N, K) in [(B * S, 7 * D, D), (B * S, D, 5 * D), (B * 4096, 3 * D, D)]:
+        A, W, b = rnd(M, K), rnd(N, K, scale=0.02), rnd(N)
+        out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            ops.gemm(A, W, b, out=out)
+        torch.cuda.synchronize()
+if which in ("all", "attn"):
+    Spad = ops.pad128(S)
+    Q, K_, VT = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)
+    O = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128))
+    torch.cuda.synchronize()

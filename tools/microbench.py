@@ -42,8 +42,11 @@ def main():
         A, W, b = rnd(M, K), rnd(N, K, scale=0.02), rnd(N)
         out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
         act = 1 if "gelu" in name else 0
-        t = timeit(lambda: ops.gemm(A, W, b, out=out, act=act))
-        print(f"gemm {name:12s} M={M:6d} N={N:6d} K={K:6d}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
+        for tile in ("128", "256"):
+            os.environ["X2I_GEMM_TILE"] = tile
+            t = timeit(lambda: ops.gemm(A, W, b, out=out, act=act))
+            print(f"gemm[{tile}] {name:12s} M={M:6d} N={N:6d} K={K:6d}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
+        os.environ.pop("X2I_GEMM_TILE")
         del A, W, out
     # attention
     Spad = ops.pad128(S)

@@ -18,6 +18,7 @@
 //   * grid is XCD-aware: consecutive tiles of a group-of-8 M band land on the same XCD's L2
 #include "x2i_common.h"
 #include "x2i_kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -55,6 +56,82 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<N - 1>(f);
     f(std::integral_constant<int, N - 1>{});
   }
+}
+
+// Shared epilogue: the wave owns MT x NT 16x16 accumulator tiles; lane owns row m = mrow + i*16 and the four
+// consecutive columns n = ncol + j*16 + 0..3 of each tile (operands were swapped in the MFMA).
+template <int ACT, bool RES, bool OUTF32, bool HASC2, int MT, int NT>
+__device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT][NT], int z, int mrow, int ncol) {
+  // ---- epilogue: lane owns m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4 + 0..3
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!RES || (p.ldr & 3) == 0);
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = ncol + j * 16;
+    if (n < p.N) {
+      const bool full = vec_ok && (n + 3 < p.N);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (full) {
+        if (p.bias) {
+          const uint2 b2 = *(const uint2*)(p.bias + n);
+          bv[0] = __uint_as_float(b2.x << 16); bv[1] = __uint_as_float(b2.x & 0xffff0000u);
+          bv[2] = __uint_as_float(b2.y << 16); bv[3] = __uint_as_float(b2.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            if (p.bias) bv[r] = bf16_to_f32(p.bias[n + r]);
+            if (gz) gv[r] = gz[n + r];
+          }
+        }
+      }
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = mrow + i * 16;
+        if (m < p.M) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
+          const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
+          if (full) {
+            if constexpr (RES) {
+              const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
+              v[0] = __uint_as_float(r2.x << 16) + gv[0] * v[0];
+              v[1] = __uint_as_float(r2.x & 0xffff0000u) + gv[1] * v[1];
+              v[2] = __uint_as_float(r2.y << 16) + gv[2] * v[2];
+              v[3] = __uint_as_float(r2.y & 0xffff0000u) + gv[3] * v[3];
+            }
+            if constexpr (OUTF32) {
+              *(f32x4_t*)((float*)p.C + coff) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+              *(uint2*)((bf16_t*)p.C + coff) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+            if constexpr (HASC2) {
+              *(uint2*)(p.C2 + coff) = make_uint2(pack_bf16x2(apply_act(v[0], p.act2), apply_act(v[1], p.act2)),
+                                                  pack_bf16x2(apply_act(v[2], p.act2), apply_act(v[3], p.act2)));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (n + r < p.N) {
+                float x = v[r];
+                if constexpr (RES) x = bf16_to_f32(rz[(long long)m * p.ldr + n + r]) + gv[r] * x;
+                if constexpr (OUTF32) ((float*)p.C)[coff + r] = x;
+                else ((bf16_t*)p.C)[coff + r] = f32_to_bf16(x);
+                if constexpr (HASC2) p.C2[coff + r] = f32_to_bf16(apply_act(x, p.act2));
+              }
+            }
+          }
+        }
+      });
+    }
+  });
 }
 
 // Epilogue variants are compile-time (ACT, RES, OUTF32, HASC2) so that the accumulator array is only ever indexed
@@ -155,78 +232,139 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     __syncthreads();                                  // ... everyone's has, and everyone is done reading `cur`
   }
 
-  // ---- epilogue: lane owns m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4 + 0..3
-  const int mrow = m0 + wm * 64 + (lane & 15);
-  const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
-  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
-  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
-  const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!RES || (p.ldr & 3) == 0);
-  static_for<4>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int n = ncol + j * 16;
-    if (n < p.N) {
-      const bool full = vec_ok && (n + 3 < p.N);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
-      if (full) {
-        if (p.bias) {
-          const uint2 b2 = *(const uint2*)(p.bias + n);
-          bv[0] = __uint_as_float(b2.x << 16); bv[1] = __uint_as_float(b2.x & 0xffff0000u);
-          bv[2] = __uint_as_float(b2.y << 16); bv[3] = __uint_as_float(b2.y & 0xffff0000u);
-        }
-        if (gz) {
-          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
-          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
-        }
-      } else {
+  epilogue_store<ACT, RES, OUTF32, HASC2, 4, 4>(p, acc, z, m0 + wm * 64 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 256x256x64 pipelined kernel (8 waves, 1 workgroup per CU, 128 KiB LDS) for the large DiT GEMMs.
+//
+// A K-tile (64 deep) is staged as FOUR 16 KiB units -- A[256 rows][k 0..31], W[256][0..31], A[256][32..63],
+// W[256][32..63] -- and consumed in four phases of 16 MFMAs per wave: (k-half 0, m-half 0), (0,1), (1,0), (1,1).
+// Phase p of tile t also issues the LDS-DMA of unit p of tile t+1 into the other LDS buffer, so a unit is needed
+// >= 3 phases after it was issued: the main loop only ever waits with a COUNTED `s_waitcnt vmcnt(4)` (two younger
+// units stay in flight across the barrier) and never drains the load queue.  Two barriers per K-tile (phases 0 and 2:
+// the points where freshly landed units are first read).  Wave (wm, wn) owns rows wm*128.., cols wn*64..: 8x4 MFMA
+// tiles = 128 accumulator registers; per K-tile it issues 24 ds_read_b128 for 64 MFMAs.
+// Unit image: [256 rows][4 chunks of 16 B]; 4 rows share a 256-byte bank row, so the conflict-free swizzle is
+// chunk ^ (3 * ((row >> 3) & 1)) (derived for the ds_read_b128 lane groups {0-3,12-15,20-27}, ...).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int UNIT_BYTES = 256 * 32 * 2;        // 16 KiB
+constexpr int TILE2_BYTES = 4 * UNIT_BYTES;     // 64 KiB per K-tile
+constexpr int SMEM2_BYTES = 2 * TILE2_BYTES;    // 128 KiB
+
+__device__ __forceinline__ void stage_unit(__amdgpu_buffer_rsrc_t rsrc, char* lds_unit, const uint32_t (&voff)[2],
+                                           uint32_t koff_bytes, int wave) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r < p.N) {
-            if (p.bias) bv[r] = bf16_to_f32(p.bias[n + r]);
-            if (gz) gv[r] = gz[n + r];
-          }
-        }
+  for (int j = 0; j < 2; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_unit + j * 8192 + wave * 1024),
+                                             16, voff[j], koff_bytes, 0, 0);
+}
+
+template <int ACT, bool RES, bool OUTF32, bool HASC2>
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A.k0 | W.k0 | A.k1 | W.k1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int z = blockIdx.y;
+
+  const int T = p.tilesM * p.tilesN;
+  int bid = blockIdx.x;
+  {
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 4;  // 4 x 8 tile patch per XCD (32 CUs)
+  const int per_group = GM * p.tilesN;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsize = min(p.tilesM - first_m, GM);
+  const int tm = first_m + (bid % per_group) % gsize;
+  const int tn = (bid % per_group) / gsize;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const bf16_t* Az = p.A + (long long)z * p.a_bs;
+  const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
+  __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  uint32_t a_voff[2], w_voff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pch = j * 512 + tid;
+    const int row = pch >> 2, cphys = pch & 3;
+    const int clog = cphys ^ (3 * ((row >> 3) & 1));
+    a_voff[j] = (uint32_t)(((long long)(m0 + row) * p.lda + clog * 8) * 2);
+    w_voff[j] = (uint32_t)(((long long)(n0 + row) * p.ldw + clog * 8) * 2);
+    if (m0 + row >= p.M) a_voff[j] = 0x80000000u;
+    if (n0 + row >= p.N) w_voff[j] = 0x80000000u;
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment address inside a unit: row r -> r*64 bytes, logical chunk (lane>>4) -> physical chunk ^ (3*((r>>3)&1));
+  // all fragment rows of a lane are (lane&15) + multiple of 16, so the swizzle term is lane-constant
+  const int frow = lane & 15;
+  const uint32_t frag = frow * 64 + (((lane >> 4) ^ (3 * ((frow >> 3) & 1))) << 4);
+  const uint32_t a_base = wm * 128 * 64 + frag;  // + i*1024 per m-tile
+  const uint32_t b_base = wn * 64 * 64 + frag;   // + j*1024 per n-tile
+
+  const int nk = p.K / BK;
+  // prologue: all four units of tile 0
+  stage_unit(a_rsrc, smem + 0 * UNIT_BYTES, a_voff, 0, wave);
+  stage_unit(w_rsrc, smem + 1 * UNIT_BYTES, w_voff, 0, wave);
+  stage_unit(a_rsrc, smem + 2 * UNIT_BYTES, a_voff, 64, wave);
+  stage_unit(w_rsrc, smem + 3 * UNIT_BYTES, w_voff, 64, wave);
+
+  bf16x8_t wf[4], af[8];
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * TILE2_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * TILE2_BYTES;
+    const bool more = (kt + 1 < nk);
+    const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int kh = ph >> 1, mh = ph & 1;
+      if (mh == 0) {
+        // units (A.kh, W.kh) of this tile are about to be read for the first time: everything issued >= 3 phases ago
+        // must have landed (at most the two younger units = 4 loads may still be in flight), for every wave
+        if (kh == 0 || more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
-      static_for<4>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int m = mrow + i * 16;
-        if (m < p.M) {
-          float v[4];
+      if (more) {
+        if (ph == 0) stage_unit(a_rsrc, nxt + 0 * UNIT_BYTES, a_voff, koff, wave);
+        if (ph == 1) stage_unit(w_rsrc, nxt + 1 * UNIT_BYTES, w_voff, koff, wave);
+        if (ph == 2) stage_unit(a_rsrc, nxt + 2 * UNIT_BYTES, a_voff, koff + 64, wave);
+        if (ph == 3) stage_unit(w_rsrc, nxt + 3 * UNIT_BYTES, w_voff, koff + 64, wave);
+      }
+      const char* Au = cur + (2 * kh) * UNIT_BYTES + a_base;
+      const char* Wu = cur + (2 * kh + 1) * UNIT_BYTES + b_base;
+      if (mh == 0) {
+        // both m-halves' A fragments are read now (same units): phase mh=1 then starts straight on the MFMA pipe
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
-          const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
-          if (full) {
-            if constexpr (RES) {
-              const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
-              v[0] = __uint_as_float(r2.x << 16) + gv[0] * v[0];
-              v[1] = __uint_as_float(r2.x & 0xffff0000u) + gv[1] * v[1];
-              v[2] = __uint_as_float(r2.y << 16) + gv[2] * v[2];
-              v[3] = __uint_as_float(r2.y & 0xffff0000u) + gv[3] * v[3];
-            }
-            if constexpr (OUTF32) {
-              *(f32x4_t*)((float*)p.C + coff) = (f32x4_t){v[0], v[1], v[2], v[3]};
-            } else {
-              *(uint2*)((bf16_t*)p.C + coff) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
-            if constexpr (HASC2) {
-              *(uint2*)(p.C2 + coff) = make_uint2(pack_bf16x2(apply_act(v[0], p.act2), apply_act(v[1], p.act2)),
-                                                  pack_bf16x2(apply_act(v[2], p.act2), apply_act(v[3], p.act2)));
-            }
-          } else {
+        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(Wu + j * 1024);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (n + r < p.N) {
-                float x = v[r];
-                if constexpr (RES) x = bf16_to_f32(rz[(long long)m * p.ldr + n + r]) + gv[r] * x;
-                if constexpr (OUTF32) ((float*)p.C)[coff + r] = x;
-                else ((bf16_t*)p.C)[coff + r] = f32_to_bf16(x);
-                if constexpr (HASC2) p.C2[coff + r] = f32_to_bf16(apply_act(x, p.act2));
-              }
-            }
-          }
-        }
-      });
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(Au + i * 1024);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[mh * 4 + i], acc[mh * 4 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
-  });
+  }
+  epilogue_store<ACT, RES, OUTF32, HASC2, 8, 4>(p, acc, z, m0 + wm * 128 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
 }
 
 // Correct-for-any-shape fallback (K not a multiple of 64, unaligned leading dims): one thread per output.
@@ -272,21 +410,40 @@ int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
                     (((uintptr_t)a->W & 15) == 0) && ((a->a_batch_stride & 7) == 0) &&
                     ((long long)a->M * a->lda * 2 < 0x7f000000LL) && ((long long)a->N * a->ldw * 2 < 0x7f000000LL);
   typedef void (*kern_t)(GemmP);
-  kern_t kern = nullptr;
+  kern_t kern = nullptr, kern2 = nullptr;
   const bool res = p.res != nullptr, c2 = p.C2 != nullptr, f32 = p.out_f32 != 0;
+#define X2I_PICK(A_, R_, F_, C_)                         \
+  {                                                      \
+    kern = gemm_bf16_kernel<A_, R_, F_, C_>;             \
+    kern2 = gemm256_bf16_kernel<A_, R_, F_, C_>;         \
+  }
   if (!res && !f32 && !c2) {
     switch (p.act) {
-      case X2I_ACT_NONE: kern = gemm_bf16_kernel<X2I_ACT_NONE, false, false, false>; break;
-      case X2I_ACT_GELU_TANH: kern = gemm_bf16_kernel<X2I_ACT_GELU_TANH, false, false, false>; break;
-      case X2I_ACT_GELU_ERF: kern = gemm_bf16_kernel<X2I_ACT_GELU_ERF, false, false, false>; break;
-      case X2I_ACT_SILU: kern = gemm_bf16_kernel<X2I_ACT_SILU, false, false, false>; break;
+      case X2I_ACT_NONE: X2I_PICK(X2I_ACT_NONE, false, false, false) break;
+      case X2I_ACT_GELU_TANH: X2I_PICK(X2I_ACT_GELU_TANH, false, false, false) break;
+      case X2I_ACT_GELU_ERF: X2I_PICK(X2I_ACT_GELU_ERF, false, false, false) break;
+      case X2I_ACT_SILU: X2I_PICK(X2I_ACT_SILU, false, false, false) break;
     }
   } else if (p.act == X2I_ACT_NONE) {
-    if (res && !f32 && !c2) kern = gemm_bf16_kernel<X2I_ACT_NONE, true, false, false>;
-    else if (!res && f32 && !c2) kern = gemm_bf16_kernel<X2I_ACT_NONE, false, true, false>;
-    else if (!res && !f32 && c2) kern = gemm_bf16_kernel<X2I_ACT_NONE, false, false, true>;
+    if (res && !f32 && !c2) X2I_PICK(X2I_ACT_NONE, true, false, false)
+    else if (!res && f32 && !c2) X2I_PICK(X2I_ACT_NONE, false, true, false)
+    else if (!res && !f32 && c2) X2I_PICK(X2I_ACT_NONE, false, false, true)
   }
-  if (fast && kern) {
+#undef X2I_PICK
+  // tile choice: the 256^2 pipelined kernel needs enough tiles to fill 256 CUs (1 workgroup per CU)
+  const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
+  const int force = force_env ? atoi(force_env) : 0;
+  const long long tiles256 = (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) * a->batch;
+  bool use256 = tiles256 >= 768 && a->M >= 256 && a->N >= 256;  // >= 3 full rounds of 256 CUs, else 128^2 tiles fill better
+  if (force == 128) use256 = false;
+  if (force == 256) use256 = true;
+  if (fast && kern && use256) {
+    p.tilesM = (a->M + BM2 - 1) / BM2; p.tilesN = (a->N + BN2 - 1) / BN2;
+    hipError_t e = hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
+    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    dim3 grid(p.tilesM * p.tilesN, a->batch);
+    hipLaunchKernelGGL(kern2, grid, dim3(512), SMEM2_BYTES, stream, p);
+  } else if (fast && kern) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     dim3 grid(p.tilesM * p.tilesN, a->batch);
