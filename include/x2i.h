@@ -36,6 +36,7 @@ extern "C" {
 #define X2I_ACT_GELU_TANH_ 1 /* nn.GELU(approximate="tanh"): lightcontrol_flux.py:65, FeedForward "gelu-approximate" */
 #define X2I_ACT_GELU_ERF_ 2  /* nn.GELU(): utils/proj.py:19,23 */
 #define X2I_ACT_SILU_ 3
+#define X2I_ACT_RELU_ 4
 
 typedef void* x2i_stream_t;
 
@@ -61,10 +62,37 @@ typedef struct x2i_gemm_args {
   void* C2; int32_t act2;
   const float* gate; int64_t gate_batch_stride;
   const void* res; int64_t res_batch_stride; int32_t ldr;
+  const float* bias2; int64_t bias2_batch_stride; /* optional f32 [batch][N] added before act (time-embedding bias) */
   int32_t M, N, K, batch;
   int32_t act; int32_t out_f32;
 } x2i_gemm_args;
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * nn.Conv2d as an implicit GEMM on NHWC bf16 activations (ControlNeXt hint encoder, lightcontrol_flux.py:593-668,
+ * diffusers ResnetBlock2D / Downsample2D convs).  `args` is the GEMM view: A = input [batch][H][W][Cin] (a_batch_stride
+ * = H*W*Cin; lda unused), W = weight repacked to [Cout][KH][KW][Cin] (ldw = KH*KW*Cin), M = OH*OW per batch,
+ * N = Cout, K = KH*KW*Cin, C = output [batch][OH*OW][Cout] (NHWC) with the usual epilogue (bias, bias2 = per-sample
+ * time-embedding term, ReLU, residual add).  Cin must be a multiple of 64; zero padding comes from the buffer
+ * descriptor's out-of-range rule.  The 3-channel stem conv has its own entry point below. */
+typedef struct x2i_conv_desc {
+  int32_t H, W, Cin, KH, KW, stride, pad;
+} x2i_conv_desc;
+int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
+
+/* Conv2d(3 -> Cout, k=3, stride=2, pad=1) on an NHWC bf16 image (lightcontrol_flux.py:594); w f32 [Cout][3][3][3]
+ * (ky,kx,ci), bias f32 [Cout]; y NHWC bf16 [B][H/2][W/2][Cout], Cout % 16 == 0 and <= 64. */
+int x2i_conv_stem_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W,
+                       int32_t Cout, x2i_stream_t stream);
+
+/* nn.GroupNorm(G, C, eps) on NHWC bf16 [B][HW][C] with fused epilogue: y = act(GN(x + pre_add[b][c]) * w + b) + post_add
+ * (ControlNeXt embedding GN+ReLU :595-602; ResnetBlock2D norm1/norm2 + SiLU with the time-embedding term added before
+ * norm2; mid block conv->ReLU->GN ... + x :632-653,744).  pre_add: f32 [B][C] or NULL; post_add: bf16 like x or NULL.
+ * `partial` is caller-owned scratch of x2i_groupnorm_scratch_floats(B, G) floats. */
+int64_t x2i_groupnorm_scratch_floats(int32_t B, int32_t G);
+int x2i_groupnorm_nhwc_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight,
+                            const void* bias, float eps, int32_t act, const float* pre_add, const void* post_add,
+                            float* partial, x2i_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * F.scaled_dot_product_attention(q, k, v, dropout_p=0, is_causal=False) for head_dim 128 (diffusers

@@ -1,0 +1,149 @@
+"""LightControl / ControlNeXt on the HIP path: conv + GroupNorm kernels against torch fp32 primitives, the hint encoder
+against the reference-generated golden, the transformer with control injection against the reference's own
+lightcontrol_flux.py output (Row L of SURVEY.md section 8), and the N-step sampler against the oracle sampler."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import flux as OF
+from oracle import sampler as OS
+from tests.util import golden, rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,p,H,W", [(64, 64, 3, 1, 1, 20, 28), (64, 128, 3, 1, 1, 16, 16), (128, 128, 3, 2, 1, 32, 48),
+                                                (128, 256, 1, 1, 0, 18, 10), (256, 320, 2, 2, 0, 16, 24), (256, 256, 3, 1, 1, 8, 12)])
+def test_conv2d_implicit_gemm(Cin, Cout, k, s, p, H, W):
+    from x2i_amd import ops
+    B = 2
+    x = bf(seeded((B, Cin, H, W), 1))
+    w = bf(seeded((Cout, Cin, k, k), 2) / (Cin * k * k) ** 0.5)
+    b = bf(seeded((Cout,), 3))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+    out = ops.conv2d_nhwc(xn, wp, b.to(DEV), H, W, Cin, Cout, k, k, s, p)
+    ref = F.conv2d(x.float(), w.float(), b.float(), stride=s, padding=p)
+    assert out.shape == (B, ref.shape[2], ref.shape[3], Cout)
+    assert rel_l2(out.permute(0, 3, 1, 2), ref) < 1e-2
+    # epilogue: per-sample bias2 + ReLU, and residual add
+    b2 = seeded((B, Cout), 4)
+    out = ops.conv2d_nhwc(xn, wp, b.to(DEV), H, W, Cin, Cout, k, k, s, p, act=ops.ACT_RELU, bias2=b2.to(DEV))
+    assert rel_l2(out.permute(0, 3, 1, 2), F.relu(ref + b2[:, :, None, None])) < 1e-2
+    res = bf(seeded(tuple(out.shape), 5))
+    out = ops.conv2d_nhwc(xn, wp, b.to(DEV), H, W, Cin, Cout, k, k, s, p, res=res.to(DEV))
+    assert rel_l2(out.permute(0, 3, 1, 2), ref + res.float().permute(0, 3, 1, 2)) < 1e-2
+
+
+def test_conv_stem():
+    from x2i_amd import ops
+    x = bf(torch.rand((2, 3, 36, 52), generator=torch.Generator().manual_seed(1)) * 2 - 1)
+    w, b = seeded((64, 3, 3, 3), 2) / 27 ** 0.5, seeded((64,), 3)
+    out = ops.conv_stem(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), 64)
+    ref = F.conv2d(x.float(), w, b, stride=2, padding=1)
+    assert rel_l2(out.permute(0, 3, 1, 2), ref) < 5e-3
+
+
+@pytest.mark.parametrize("C,G,act", [(64, 2, 4), (128, 4, 3), (256, 8, 0), (128, 2, 4)])
+def test_groupnorm_nhwc(C, G, act):
+    from x2i_amd import ops
+    B, H, W = 2, 14, 18
+    x = bf(seeded((B, C, H, W), 1, 2.0) + 0.3)
+    w, b = bf(1 + 0.1 * seeded((C,), 2)), bf(0.1 * seeded((C,), 3))
+    pre, post = seeded((B, C), 4), bf(seeded((B, C, H, W), 5))
+    fn = {0: lambda t: t, 3: F.silu, 4: F.relu}[act]
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = ops.groupnorm_nhwc(xn, w.to(DEV), b.to(DEV), G, 1e-6, act=act)
+    assert rel_l2(out.permute(0, 3, 1, 2), fn(F.group_norm(x.float(), G, w.float(), b.float(), 1e-6))) < 5e-3
+    out = ops.groupnorm_nhwc(xn, w.to(DEV), b.to(DEV), G, 1e-5, act=act, pre_add=pre.to(DEV),
+                             post_add=post.permute(0, 2, 3, 1).contiguous().to(DEV))
+    ref = fn(F.group_norm(x.float() + pre[:, :, None, None], G, w.float(), b.float(), 1e-5)) + post.float()
+    assert rel_l2(out.permute(0, 3, 1, 2), ref) < 5e-3
+
+
+def _load_cnext(seed, out_channels=3072):
+    from x2i_amd.lightcontrol import ControlNeXtModel
+    sd = OF.random_controlnext_state_dict(seed=seed, out_channels=out_channels)
+    m = ControlNeXtModel(device=DEV, control_out_channels=out_channels)
+    m.load_state_dict({k: bf(v) for k, v in sd.items()}, strict=True)
+    return m, sd
+
+
+def test_controlnext_vs_reference_golden():
+    t, meta = golden("controlnext_full")
+    m, sd = _load_cnext(meta["weight_seed"])
+    o = m(t["hint"].to(DEV), t["timestep"].to(DEV))
+    assert o["scale"] == meta["scale"] and o["out"].shape == t["out"].shape
+    assert rel_l2(o["out"], t["out"]) < 3e-2  # reference ran fp32 weights
+    ref = OF.controlnext_forward({k: rb(v) for k, v in sd.items()}, "", rb(t["hint"]), t["timestep"])
+    assert rel_l2(o["out"], ref["out"]) < 2e-2
+
+
+def test_transformer_with_control_vs_reference_golden():
+    """The reference's own FluxTransformer2DModel.forward(guided_hint=, control_nets=) output (tests/golden)."""
+    from x2i_amd.lightcontrol import FluxTransformer2DModel
+    t, meta = golden("flux_tiny_dev_control")
+    cfg = meta["cfg"]
+    sd = OF.random_flux_state_dict(cfg, seed=meta["weight_seed"], std=meta["weight_std"])
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: bf(v) for k, v in sd.items()}, strict=True)
+    nets, csds = [], []
+    for s in meta["control_seeds"]:
+        n, csd = _load_cnext(s, meta["control_out_channels"])
+        nets.append(n)
+        csds.append({k: rb(v) for k, v in csd.items()})
+    kw = dict(hidden_states=t["hidden"].to(DEV), encoder_hidden_states=t["enc"].to(DEV), pooled_projections=t["pooled"].to(DEV),
+              timestep=t["timestep"].to(DEV), img_ids=t["img_ids"].to(DEV), txt_ids=t["txt_ids"].to(DEV),
+              guidance=t["guidance"].to(DEV), guided_hint=t["hint"].to(DEV))
+    out = m(**kw, control_nets=nets, return_dict=False)
+    assert torch.is_tensor(out) and out.shape == t["out"].shape  # bare tensor, as lightcontrol_flux.py:549-550
+    assert rel_l2(out, t["out"]) < 3e-2
+    ref = OF.flux_forward({k: rb(v) for k, v in sd.items()}, cfg, rb(t["hidden"]), rb(t["enc"]), rb(t["pooled"]), t["timestep"],
+                          t["img_ids"], t["txt_ids"], guidance=t["guidance"], guided_hint=rb(t["hint"]), control_sds=csds)
+    assert rel_l2(out, ref) < 2e-2
+    out0 = m(**kw, control_nets=[], return_dict=False)
+    assert rel_l2(out0, out) > 1e-3  # the control branch is really injected
+    with pytest.raises(TypeError):
+        m(**kw, control_nets=None)
+
+
+def test_lightcontrol_sampler_vs_oracle():
+    from x2i_amd.lightcontrol import FluxTransformer2DModel, LightControlSampler
+    t, meta = golden("flux_tiny_dev_control")
+    cfg = meta["cfg"]
+    sd = OF.random_flux_state_dict(cfg, seed=meta["weight_seed"], std=meta["weight_std"])
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: bf(v) for k, v in sd.items()}, strict=True)
+    nets, csds = [], []
+    for s in meta["control_seeds"]:
+        n, csd = _load_cnext(s, meta["control_out_channels"])
+        nets.append(n)
+        csds.append({k: rb(v) for k, v in csd.items()})
+    sampler = LightControlSampler(m, nets)
+    pe, pooled, hint = bf(t["enc"]), bf(t["pooled"]), bf(t["hint"])
+    noise = bf(OS.pack_latents(torch.randn((2, 16, 16, 24), generator=torch.Generator().manual_seed(3))))
+    got = sampler(pe.to(DEV), pooled.to(DEV), hint.to(DEV), num_inference_steps=3, guidance_scale=3.5, height=128, width=192,
+                  latents=noise.to(DEV))
+    # oracle, dev schedule (dynamic shift), bf16 timestep arithmetic reproduced with torch bf16 ops
+    sdr = {k: rb(v) for k, v in sd.items()}
+    lat = noise.clone()
+    ts, sig = OS.flow_match_sigmas(3, OS.SCHEDULER_DEV, lat.shape[1])
+    gd = torch.full([2], 3.5)
+    for i, tt in enumerate(ts):
+        t1000 = ((tt.expand(2).to(torch.bfloat16) / 1000) * 1000).float()
+        eps = OF.flux_forward(sdr, cfg, lat.float(), pe.float(), pooled.float(), t1000 / 1000, t["img_ids"], t["txt_ids"],
+                              guidance=(gd.bfloat16() * 1000).float() / 1000, guided_hint=hint.float(), control_sds=csds)
+        lat = OS.euler_step(lat, eps.bfloat16(), sig[i], sig[i + 1])
+    assert rel_l2(got, lat) < 5e-2
+    got2 = sampler(pe.to(DEV), pooled.to(DEV), hint.to(DEV), num_inference_steps=3, height=128, width=192, latents=noise.to(DEV),
+                   use_graph=True)
+    assert torch.equal(got2, got)

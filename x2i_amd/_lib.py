@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx2i_hip.so")
 
-ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
 
 
 class X2IError(RuntimeError):
@@ -25,9 +25,15 @@ class GemmArgs(C.Structure):
         ("C2", C.c_void_p), ("act2", C.c_int32),
         ("gate", C.c_void_p), ("gate_batch_stride", C.c_int64),
         ("res", C.c_void_p), ("res_batch_stride", C.c_int64), ("ldr", C.c_int32),
+        ("bias2", C.c_void_p), ("bias2_batch_stride", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("act", C.c_int32), ("out_f32", C.c_int32),
     ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("stride", C.c_int32), ("pad", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -35,6 +41,9 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> argtypes (restype is int for all but the two below); mirrors include/x2i.h exactly
 SIGNATURES = {
     "x2i_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "x2i_conv2d_nhwc_bf16": [C.POINTER(GemmArgs), C.POINTER(ConvDesc), _vp],
+    "x2i_conv_stem_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "x2i_groupnorm_nhwc_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
     "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
     "x2i_ln_modulate_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
@@ -67,6 +76,8 @@ def load():
         raise X2IError("x2i_amd: cannot load %s: %s" % (LIB_PATH, e))
     lib.x2i_abi_version.restype = C.c_int
     lib.x2i_last_error.restype = C.c_char_p
+    lib.x2i_groupnorm_scratch_floats.argtypes = [_i32, _i32]
+    lib.x2i_groupnorm_scratch_floats.restype = C.c_int64
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.argtypes = argtypes

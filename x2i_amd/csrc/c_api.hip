@@ -28,6 +28,24 @@ const char* x2i_last_error(void) { return g_err; }
 
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream) { return x2i_launch_gemm(args, (hipStream_t)stream); }
 
+int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream) {
+  if (!conv) return x2i_set_error(X2I_ERR_ARG, "conv2d: null descriptor");
+  return x2i_launch_gemm_conv(args, conv, (hipStream_t)stream);
+}
+
+int x2i_conv_stem_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cout,
+                       x2i_stream_t stream) {
+  return x2i_launch_conv_stem(x, w, bias, y, B, H, W, Cout, (hipStream_t)stream);
+}
+
+int64_t x2i_groupnorm_scratch_floats(int32_t B, int32_t G) { return x2i_groupnorm_scratch(B, G); }
+
+int x2i_groupnorm_nhwc_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight,
+                            const void* bias, float eps, int32_t act, const float* pre_add, const void* post_add, float* partial,
+                            x2i_stream_t stream) {
+  return x2i_launch_groupnorm(x, y, B, HW, C, G, weight, bias, eps, act, pre_add, post_add, partial, (hipStream_t)stream);
+}
+
 int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
                        int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
   return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream);

@@ -1,0 +1,183 @@
+// ControlNeXt hint-encoder kernels that are not GEMM-shaped (the 3x3 / 2x2 / 1x1 convolutions with Cin >= 64 run as
+// implicit GEMMs in gemm.hip):
+//   conv_stem_kernel   Conv2d(3 -> 64, k3, s2, p1) on the NHWC hint image     (lightcontrol_flux.py:594)
+//   gn_partial_kernel  per-(sample, group) partial sums over a slab of pixels   } nn.GroupNorm on NHWC bf16 with fused
+//   gn_apply_kernel    finish statistics, normalise, affine, activation, adds   } pre-add / activation / residual
+// All HBM-bound: 16-byte loads, fp32 statistics, deterministic two-stage reduction (no atomics).
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+
+namespace {
+
+constexpr int GN_SLABS = 128;  // partial-sum slabs per sample
+
+// one thread = one output pixel x 16 output channels
+__global__ __launch_bounds__(256) void conv_stem_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int H, int W,
+                                                        int Cout, long long total) {
+  __shared__ float wsh[64 * 27];
+  for (int i = threadIdx.x; i < Cout * 27; i += 256) wsh[i] = w[i];
+  __syncthreads();
+  const int groups = Cout / 16;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cg = (int)(gid % groups);
+  const long long pix = gid / groups;
+  const int OH = H / 2, OW = W / 2;
+  const int ox = (int)(pix % OW);
+  const int oy = (int)((pix / OW) % OH);
+  const int b = (int)(pix / ((long long)OW * OH));
+  float in[27];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const bf16_t* px = x + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) in[(ky * 3 + kx) * 3 + c] = ok ? bf16_to_f32(px[c]) : 0.f;
+    }
+  float o[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const float* wc = wsh + (cg * 16 + c) * 27;
+    float a = bias ? bias[cg * 16 + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a += wc[k] * in[k];
+    o[c] = a;
+  }
+  bf16_t* yp = y + pix * Cout + cg * 16;
+  union { bf16x8_t v; uint32_t u[4]; } lo, hi;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lo.u[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+    hi.u[j] = pack_bf16x2(o[8 + 2 * j], o[8 + 2 * j + 1]);
+  }
+  *(bf16x8_t*)yp = lo.v;
+  *(bf16x8_t*)(yp + 8) = hi.v;
+}
+
+// grid (GN_SLABS, B); each thread owns one 8-channel chunk position (tid % (C/8)) and strides over pixels, so its partial
+// sums belong to a single group; block reduces per group through LDS.  partial layout: [B][GN_SLABS][G][2]
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, const float* __restrict__ pre_add,
+                                                         float* __restrict__ partial, long long HW, int C, int G) {
+  __shared__ float red[256][2];
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int cpp = C / 8;                   // chunks per pixel
+  const int ppi = 256 / cpp;               // pixels per block iteration (C/8 divides 256 for C in {64,128,256})
+  const int chunk = threadIdx.x % cpp, psub = threadIdx.x / cpp;
+  const long long per = (HW + GN_SLABS - 1) / GN_SLABS;
+  const long long p0 = (long long)slab * per, p1 = min(HW, p0 + per);
+  float add[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pre_add) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) add[j] = pre_add[(long long)b * C + chunk * 8 + j];
+  }
+  float s = 0.f, ss = 0.f;
+  const bf16_t* xb = x + (long long)b * HW * C;
+  for (long long pbase = p0 + psub; pbase < p1; pbase += ppi) {
+    const bf16x8_t v = *(const bf16x8_t*)(xb + pbase * C + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf16_to_f32((bf16_t)v[j]) + add[j];
+      s += f;
+      ss += f * f;
+    }
+  }
+  red[threadIdx.x][0] = s;
+  red[threadIdx.x][1] = ss;
+  __syncthreads();
+  // thread g < G sums the threads whose chunk lies in group g
+  if (threadIdx.x < G) {
+    const int cpg = cpp / G;  // chunks per group
+    float a = 0.f, bq = 0.f;
+    for (int t = 0; t < 256; ++t) {
+      if ((t % cpp) / cpg == (int)threadIdx.x) {
+        a += red[t][0];
+        bq += red[t][1];
+      }
+    }
+    float* o = partial + (((long long)b * GN_SLABS + slab) * G + threadIdx.x) * 2;
+    o[0] = a;
+    o[1] = bq;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long HW, int C, int G,
+                                                       const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias, float eps,
+                                                       int act, const float* __restrict__ pre_add,
+                                                       const bf16_t* __restrict__ post_add, const float* __restrict__ partial) {
+  __shared__ float mean_s[32], rstd_s[32];
+  const int b = blockIdx.y;
+  if (threadIdx.x < G) {
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < GN_SLABS; ++s) {
+      const float* pp = partial + (((long long)b * GN_SLABS + s) * G + threadIdx.x) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+    const float n = (float)HW * (float)(C / G);
+    const float m = a / n;
+    const float var = fmaxf(q / n - m * m, 0.f);
+    mean_s[threadIdx.x] = m;
+    rstd_s[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int cpp = C / 8;
+  const long long total = HW * cpp;
+  const bf16_t* xb = x + (long long)b * HW * C;
+  bf16_t* yb = y + (long long)b * HW * C;
+  const bf16_t* ab = post_add ? post_add + (long long)b * HW * C : nullptr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int chunk = (int)(i % cpp);
+    const int c0 = chunk * 8;
+    const int g = c0 / (C / G);
+    const float m = mean_s[g], r = rstd_s[g];
+    const bf16x8_t v = *(const bf16x8_t*)(xb + i * 8);
+    const bf16x8_t wv = *(const bf16x8_t*)(w + c0), bv = *(const bf16x8_t*)(bias + c0);
+    bf16x8_t pa = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ab) pa = *(const bf16x8_t*)(ab + i * 8);
+    bf16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = bf16_to_f32((bf16_t)v[j]);
+      if (pre_add) f += pre_add[(long long)b * C + c0 + j];
+      f = (f - m) * r * bf16_to_f32((bf16_t)wv[j]) + bf16_to_f32((bf16_t)bv[j]);
+      f = apply_act(f, act);
+      if (ab) f += bf16_to_f32((bf16_t)pa[j]);
+      o[j] = (short)f32_to_bf16(f);
+    }
+    *(bf16x8_t*)(yb + i * 8) = o;
+  }
+}
+
+}  // namespace
+
+int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, hipStream_t stream) {
+  if (!x || !w || !y) return x2i_set_error(X2I_ERR_ARG, "conv_stem: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || Cout % 16 || Cout > 64 || Cout <= 0)
+    return x2i_set_error(X2I_ERR_SHAPE, "conv_stem: need even H,W and Cout in {16,32,48,64}");
+  const long long total = (long long)B * (H / 2) * (W / 2) * (Cout / 16);
+  hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, w, bias,
+                     (bf16_t*)y, H, W, Cout, total);
+  return x2i_check_launch("conv_stem");
+}
+
+long long x2i_groupnorm_scratch(int B, int G) { return (long long)B * GN_SLABS * G * 2; }
+
+int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
+                         const float* pre_add, const void* post_add, float* partial, hipStream_t stream) {
+  if (!x || !y || !w || !b || !partial) return x2i_set_error(X2I_ERR_ARG, "groupnorm: null pointer");
+  if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || G <= 0 || G > 32 || (C / 8) % G)
+    return x2i_set_error(X2I_ERR_SHAPE, "groupnorm: unsupported C=%d G=%d (need C/8 | 256 and G | C/8)", C, G);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SLABS, B), dim3(256), 0, stream, (const bf16_t*)x, pre_add, partial, HW, C, G);
+  int rc = x2i_check_launch("groupnorm_partial");
+  if (rc) return rc;
+  const long long total = HW * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,
+                     (const bf16_t*)w, (const bf16_t*)b, eps, act, pre_add, (const bf16_t*)post_add, partial);
+  return x2i_check_launch("groupnorm_apply");
+}

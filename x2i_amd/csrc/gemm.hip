@@ -34,9 +34,12 @@ struct GemmP {
   bf16_t* C2; int act2;
   const float* gate; long long gate_bs;
   const bf16_t* res; long long r_bs; int ldr;
+  const float* bias2; long long bias2_bs;  // optional f32 per-batch additive vector [batch][N]
   int M, N, K;
   int act, out_f32;
   int tilesM, tilesN;
+  // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
+  int cH, cW, cCin, cOW, cKW, cStride, cPad;
 };
 
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
@@ -72,6 +75,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
     if (n < p.N) {
       const bool full = vec_ok && (n + 3 < p.N);
       float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
       if (full) {
         if (p.bias) {
           const uint2 b2 = *(const uint2*)(p.bias + n);
@@ -82,12 +86,17 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
           const f32x4_t g4 = *(const f32x4_t*)(gz + n);
           gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
         }
+        if (b2) {
+          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+          bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r < p.N) {
             if (p.bias) bv[r] = bf16_to_f32(p.bias[n + r]);
             if (gz) gv[r] = gz[n + r];
+            if (b2) bv[r] += b2[n + r];
           }
         }
       }
@@ -136,7 +145,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
 
 // Epilogue variants are compile-time (ACT, RES, OUTF32, HASC2) so that the accumulator array is only ever indexed
 // with constants (a runtime-indexed ext_vector array is demoted to scratch memory by hipcc).
-template <int ACT, bool RES, bool OUTF32, bool HASC2>
+template <int ACT, bool RES, bool OUTF32, bool HASC2, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][A 16K | B 16K]
   const int tid = threadIdx.x;
@@ -164,13 +173,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 
   const bf16_t* Az = p.A + (long long)z * p.a_bs;
   // buffer descriptors: num_records = bytes from base to the end of the last valid row
-  const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t a_bytes = CONV ? (uint32_t)((long long)p.cH * p.cW * p.cCin * 2)
+                                : (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
 
   // per-thread source offsets of its 4 chunks per operand tile (row r, physical chunk c holds logical chunk c^swz)
   uint32_t a_voff[4], w_voff[4];
+  int c_oy[4], c_ox[4], c_cl[4];  // CONV: output pixel of each chunk row, logical chunk
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int pch = j * 256 + tid;
@@ -181,7 +192,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     w_voff[j] = (uint32_t)(((long long)(n0 + row) * p.ldw + clog * 8) * 2);
     if (m0 + row >= p.M) a_voff[j] = 0x80000000u;
     if (n0 + row >= p.N) w_voff[j] = 0x80000000u;
+    if (CONV) {
+      const int m = m0 + row;
+      c_oy[j] = (m < p.M) ? m / p.cOW : -100000;  // invalid rows never pass the bounds test below
+      c_ox[j] = m - (m / p.cOW) * p.cOW;
+      c_cl[j] = clog * 8;
+    }
   }
+  // CONV: gather addresses for K-tile kt = one filter tap (ky,kx) and a 64-channel slice of the NHWC input;
+  // out-of-image taps (zero padding) are mapped beyond num_records so the DMA writes zeros
+  auto conv_offsets = [&](int kt) {
+    const int kbase = kt * BK;
+    const int tap = kbase / p.cCin, c0 = kbase - tap * p.cCin;
+    const int ky = tap / p.cKW, kx = tap - ky * p.cKW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = c_oy[j] * p.cStride + ky - p.cPad, ix = c_ox[j] * p.cStride + kx - p.cPad;
+      const bool ok = (iy >= 0) && (iy < p.cH) && (ix >= 0) && (ix < p.cW);
+      a_voff[j] = ok ? (uint32_t)((((long long)iy * p.cW + ix) * p.cCin + c0 + c_cl[j]) * 2) : 0x80000000u;
+    }
+  };
+  if (CONV) conv_offsets(0);
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -210,7 +241,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
       const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
-      stage_tile(a_rsrc, nxt, a_voff, koff, wave);
+      if (CONV) conv_offsets(kt + 1);
+      stage_tile(a_rsrc, nxt, a_voff, CONV ? 0u : koff, wave);
       stage_tile(w_rsrc, nxt + TILE_BYTES, w_voff, koff, wave);
     }
     const char* As = cur + a_frag_base;
@@ -378,7 +410,7 @@ __global__ void gemm_naive_kernel(GemmP p) {
   const bf16_t* w = p.W + (long long)n * p.ldw;
   float acc = 0.f;
   for (int k = 0; k < p.K; ++k) acc = fmaf(bf16_to_f32(a[k]), bf16_to_f32(w[k]), acc);
-  float v = acc + (p.bias ? bf16_to_f32(p.bias[n]) : 0.f);
+  float v = acc + (p.bias ? bf16_to_f32(p.bias[n]) : 0.f) + (p.bias2 ? p.bias2[(long long)z * p.bias2_bs + n] : 0.f);
   v = apply_act(v, p.act);
   if (p.res) {
     const float g = p.gate ? p.gate[(long long)z * p.gate_bs + n] : 1.f;
@@ -392,8 +424,11 @@ __global__ void gemm_naive_kernel(GemmP p) {
 
 }  // namespace
 
-int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
+int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) { return x2i_launch_gemm_conv(a, nullptr, stream); }
+
+int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream) {
   if (!a || !a->A || !a->W || !a->C) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
+  const bool conv = cd != nullptr;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
   GemmP p;
@@ -404,18 +439,30 @@ int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
   p.C2 = (bf16_t*)a->C2; p.act2 = a->act2;
   p.gate = a->gate; p.gate_bs = a->gate_batch_stride;
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
+  p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = 0;
+  if (conv) {
+    if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
+      return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
+    const int OH = (cd->H + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = (cd->W + 2 * cd->pad - cd->KW) / cd->stride + 1;
+    if (a->M != OH * OW || a->K != cd->KH * cd->KW * cd->Cin)
+      return x2i_set_error(X2I_ERR_SHAPE, "conv: M=%d K=%d do not match OH*OW=%d, KH*KW*Cin=%d", a->M, a->K, OH * OW, cd->KH * cd->KW * cd->Cin);
+    if ((long long)cd->H * cd->W * cd->Cin * 2 >= 0x7f000000LL) return x2i_set_error(X2I_ERR_SHAPE, "conv: image too large");
+    p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad;
+  }
   p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
-  const bool fast = (a->K % BK == 0) && (a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) &&
+  const bool fast = (a->K % BK == 0) && (conv || a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) &&
                     (((uintptr_t)a->W & 15) == 0) && ((a->a_batch_stride & 7) == 0) &&
-                    ((long long)a->M * a->lda * 2 < 0x7f000000LL) && ((long long)a->N * a->ldw * 2 < 0x7f000000LL);
+                    (conv || (long long)a->M * a->lda * 2 < 0x7f000000LL) && ((long long)a->N * a->ldw * 2 < 0x7f000000LL);
   typedef void (*kern_t)(GemmP);
   kern_t kern = nullptr, kern2 = nullptr;
   const bool res = p.res != nullptr, c2 = p.C2 != nullptr, f32 = p.out_f32 != 0;
-#define X2I_PICK(A_, R_, F_, C_)                         \
-  {                                                      \
-    kern = gemm_bf16_kernel<A_, R_, F_, C_>;             \
-    kern2 = gemm256_bf16_kernel<A_, R_, F_, C_>;         \
+#define X2I_PICK(A_, R_, F_, C_)                                       \
+  {                                                                    \
+    kern = conv ? gemm_bf16_kernel<A_, R_, F_, C_, true>               \
+                : gemm_bf16_kernel<A_, R_, F_, C_, false>;             \
+    kern2 = gemm256_bf16_kernel<A_, R_, F_, C_>;                       \
   }
   if (!res && !f32 && !c2) {
     switch (p.act) {
@@ -423,6 +470,7 @@ int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
       case X2I_ACT_GELU_TANH: X2I_PICK(X2I_ACT_GELU_TANH, false, false, false) break;
       case X2I_ACT_GELU_ERF: X2I_PICK(X2I_ACT_GELU_ERF, false, false, false) break;
       case X2I_ACT_SILU: X2I_PICK(X2I_ACT_SILU, false, false, false) break;
+      case X2I_ACT_RELU: X2I_PICK(X2I_ACT_RELU, false, false, false) break;
     }
   } else if (p.act == X2I_ACT_NONE) {
     if (res && !f32 && !c2) X2I_PICK(X2I_ACT_NONE, true, false, false)
@@ -434,7 +482,7 @@ int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
   const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
   const int force = force_env ? atoi(force_env) : 0;
   const long long tiles256 = (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) * a->batch;
-  bool use256 = tiles256 >= 768 && a->M >= 256 && a->N >= 256;  // >= 3 full rounds of 256 CUs, else 128^2 tiles fill better
+  bool use256 = !conv && tiles256 >= 768 && a->M >= 256 && a->N >= 256;  // >= 3 full rounds of 256 CUs, else 128^2 tiles fill better
   if (force == 128) use256 = false;
   if (force == 256) use256 = true;
   if (fast && kern && use256) {
@@ -448,6 +496,8 @@ int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) {
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     dim3 grid(p.tilesM * p.tilesN, a->batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, stream, p);
+  } else if (conv) {
+    return x2i_set_error(X2I_ERR_SHAPE, "conv: unsupported epilogue/alignment combination");
   } else {
     dim3 grid((a->N + 127) / 128, a->M, a->batch);
     hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(128), 0, stream, p);

@@ -40,13 +40,14 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // activation codes shared by every kernel and by the C ABI (include/x2i.h)
-enum { X2I_ACT_NONE = 0, X2I_ACT_GELU_TANH = 1, X2I_ACT_GELU_ERF = 2, X2I_ACT_SILU = 3 };
+enum { X2I_ACT_NONE = 0, X2I_ACT_GELU_TANH = 1, X2I_ACT_GELU_ERF = 2, X2I_ACT_SILU = 3, X2I_ACT_RELU = 4 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case X2I_ACT_GELU_TANH: return gelu_tanh_f(v);
     case X2I_ACT_GELU_ERF: return gelu_erf_f(v);
     case X2I_ACT_SILU: return silu_f(v);
+    case X2I_ACT_RELU: return fmaxf(v, 0.f);
     default: return v;
   }
 }

@@ -4,6 +4,12 @@
 #include "../../include/x2i.h"
 
 int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream);
+int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream);
+int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout,
+                         hipStream_t stream);
+long long x2i_groupnorm_scratch(int B, int G);
+int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps,
+                         int act, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                          long long o_bs, float scale, hipStream_t stream);
 int x2i_launch_qkv_split(const void* qkv0, const void* qkv1, int ld0, int ld1, int B, int S, int S0, int H,

@@ -284,8 +284,8 @@ class FluxTransformer2DModel(nn.Module):
 
     @torch.no_grad()
     def denoise(self, state, hidden_states, timestep, control=None):
-        """One transformer evaluation given prepared conditioning.  `control`: optional callable(i, timestep_x1000)
-        returning the [B, S_img, D] bf16 tensor added to the image stream after double block i, or None."""
+        """One transformer evaluation given prepared conditioning.  `control`: optional callable
+        (i, timestep_x1000, X, St, S, D) that adds control net i's output into the image rows of X after double block i."""
         cfg = self.config
         f = self._fused
         ws = state["ws"]
@@ -352,9 +352,9 @@ class FluxTransformer2DModel(nn.Module):
                      a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D,
                      gate=mod(oc + 5 * D), gate_batch_stride=Ntot)
             if control is not None:
-                c = control(i, t1000)
-                if c is not None:
-                    X[:, St:].add_(c)  # lightcontrol_flux.py:504-507 (scale == 1.0)
+                # hidden_states += control_nets[i](guided_hint, timestep)['out'] * 1.0 (lightcontrol_flux.py:504-507),
+                # fused into the last ControlNeXt conv's epilogue (residual add into the image rows of X)
+                control(i, t1000, X, St, S, D)
         # ---- single-stream blocks on the joint sequence (lightcontrol_flux.py:82-104)
         base = cfg.num_layers * 12 * D
         for i in range(cfg.num_single_layers):

@@ -1,0 +1,237 @@
+"""LightControl (ControlNeXt) instruction-edit branch on the HIP path.
+
+Mirrors lightcontrol/lightcontrol_flux.py: `ControlNeXtModel` (:575-749) with the reference's parameter names, and a
+`FluxTransformer2DModel` whose forward takes `guided_hint=` / `control_nets=` and, with return_dict=False, returns the
+BARE tensor (:549-550; train_lightcontrol.py:732-746 relies on it).  The reference ships no LightControl inference
+script; `LightControlSampler` is this build's counterpart of the per-step call in train_lightcontrol.py:732-743 plus the
+FLUX.1-dev Euler schedule (SURVEY.md "Row L").
+
+Activations are NHWC bf16; convolutions with Cin >= 64 are implicit GEMMs on the MFMA kernel (weights repacked once to
+[Cout][ky][kx][Cin]); GroupNorm / ReLU / SiLU / time-embedding adds / residuals are fused around them.
+Everything up to the first ResnetBlock's conv1 does not depend on the timestep and is cached per hint image
+(`prepare_hint`): 135 of the 437 GFLOP per model per image are paid once per sample instead of once per step.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .flux import FluxTransformer2DModel as _BaseFlux
+from .ops import ACT_NONE, ACT_RELU, ACT_SILU
+
+
+def _param(*shape, device, dtype=torch.bfloat16):
+    return nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, device):
+        super().__init__()
+        self.weight = _param(cout, cin, k, k, device=device)
+        self.bias = _param(cout, device=device)
+        self.k = k
+        self._packed = None
+
+    def packed(self):
+        """[Cout, ky, kx, Cin] bf16, K-contiguous for the implicit GEMM (repacked once; reference layout is OIHW)."""
+        if self._packed is None or self._packed.device != self.weight.device:
+            self._packed = self.weight.permute(0, 2, 3, 1).reshape(self.weight.shape[0], -1).contiguous()
+        return self._packed
+
+
+class _Affine(nn.Module):
+    def __init__(self, c, device):
+        super().__init__()
+        self.weight = _param(c, device=device)
+        self.bias = _param(c, device=device)
+
+
+class _Lin(nn.Module):
+    def __init__(self, i, o, device):
+        super().__init__()
+        self.weight = _param(o, i, device=device)
+        self.bias = _param(o, device=device)
+
+
+class _Sparse(nn.Module):
+    def __init__(self, items):
+        super().__init__()
+        for k, v in items.items():
+            self.add_module(str(k), v)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout, device):
+        super().__init__()
+        self.norm1 = _Affine(cin, device)
+        self.conv1 = _Conv(cin, cout, 3, device)
+        self.time_emb_proj = _Lin(256, cout, device)
+        self.norm2 = _Affine(cout, device)
+        self.conv2 = _Conv(cout, cout, 3, device)
+        if cin != cout:
+            self.conv_shortcut = _Conv(cin, cout, 1, device)
+
+
+class _Down(nn.Module):
+    def __init__(self, c, device):
+        super().__init__()
+        self.conv = _Conv(c, c, 3, device)
+
+
+class ControlNeXtModel(nn.Module):
+    """lightcontrol_flux.py:575-749.  forward(sample [B,3,H,W], timestep) -> {"out": [B,out_ch,H/16,W/16], "scale": 1.0}.
+    `out_channels` generalises the hard-coded 3072 (:661-668) so reduced-width models can be tested."""
+
+    def __init__(self, in_channels=(128, 128), out_channels=(128, 256), groups=(4, 8), time_embed_dim=256,
+                 final_out_channels=320, device="cuda", control_out_channels=3072):
+        super().__init__()
+        assert tuple(in_channels) == (128, 128) and tuple(out_channels) == (128, 256) and time_embed_dim == 256
+        self.groups = tuple(groups)
+        self.scale = 1.0
+        te = nn.Module()
+        te.linear_1 = _Lin(128, 256, device)
+        te.linear_2 = _Lin(256, 256, device)
+        self.time_embedding = te
+        self.embedding = _Sparse({0: _Conv(3, 64, 3, device), 1: _Affine(64, device), 3: _Conv(64, 64, 3, device),
+                                  4: _Affine(64, device), 6: _Conv(64, 128, 3, device), 7: _Affine(128, device)})
+        self.down_res = _Sparse({0: _Res(128, 128, device), 1: _Res(128, 256, device)})
+        self.down_sample = _Sparse({0: _Down(128, device), 1: _Down(256, device)})
+        mid0 = _Sparse({0: _Conv(256, 256, 3, device), 2: _Affine(256, device), 3: _Conv(256, 256, 3, device),
+                        4: _Affine(256, device)})
+        self.mid_convs = _Sparse({0: mid0, 1: _Conv(256, control_out_channels, 2, device)})
+        self._hint_cache = None
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        for m in self.modules():
+            if isinstance(m, _Conv):
+                m._packed = None
+        self._hint_cache = None
+        return r
+
+    # ---- timestep-independent prefix (cached per hint tensor)
+    @torch.no_grad()
+    def prepare_hint(self, sample):
+        """embedding (3 convs + GN + ReLU, :593-603,740) and ResnetBlock 0's norm1+SiLU+conv1 (before the time term)."""
+        B, _, H, W = sample.shape
+        e = self.embedding
+        x = sample.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()  # NHWC
+        w0 = e[0].weight.float().permute(0, 2, 3, 1).contiguous()  # [64, ky, kx, 3]
+        x = ops.conv_stem(x, w0, e[0].bias.float(), 64)
+        x = ops.groupnorm_nhwc(x, e[1].weight, e[1].bias, 2, 1e-5, act=ACT_RELU)
+        h, w = H // 2, W // 2
+        x = ops.conv2d_nhwc(x, e[3].packed(), e[3].bias, h, w, 64, 64, 3, 3, 1, 1)
+        x = ops.groupnorm_nhwc(x, e[4].weight, e[4].bias, 2, 1e-5, act=ACT_RELU)
+        x = ops.conv2d_nhwc(x, e[6].packed(), e[6].bias, h, w, 64, 128, 3, 3, 1, 1)
+        x0 = ops.groupnorm_nhwc(x, e[7].weight, e[7].bias, 2, 1e-5, act=ACT_RELU)
+        r = self.down_res[0]
+        n = ops.groupnorm_nhwc(x0, r.norm1.weight, r.norm1.bias, self.groups[0], 1e-6, act=ACT_SILU)
+        h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 128, 3, 3, 1, 1)
+        return dict(x0=x0, h1=h1, h=h, w=w, B=B, round_bf16=sample.dtype == torch.bfloat16)
+
+    def _resblock_tail(self, r, x_in, h1, temb_act, G, h, w, cin, cout):
+        """ResnetBlock2D after conv1: h = h1 + time_emb_proj(silu(temb)); h = conv2(silu(GN(h))); out = shortcut(x) + h."""
+        tproj = ops.skinny_linear(temb_act, r.time_emb_proj.weight, r.time_emb_proj.bias, act_in=ACT_SILU)  # [B, cout] f32
+        n = ops.groupnorm_nhwc(h1, r.norm2.weight, r.norm2.bias, G, 1e-6, act=ACT_SILU, pre_add=tproj)
+        if hasattr(r, "conv_shortcut"):
+            sc = ops.conv2d_nhwc(x_in, r.conv_shortcut.packed(), r.conv_shortcut.bias, h, w, cin, cout, 1, 1, 1, 0)
+        else:
+            sc = x_in
+        return ops.conv2d_nhwc(n, r.conv2.packed(), r.conv2.bias, h, w, cout, cout, 3, 3, 1, 1, res=sc)
+
+    @torch.no_grad()
+    def forward_nhwc(self, prep, timestep, add_into=None, add_offset=0, add_batch_stride=None, add_ld=None):
+        """Timestep-dependent part.  Returns NHWC [B, H/16, W/16, out_ch]; with `add_into` (the transformer's joint
+        residual buffer) the final conv's epilogue adds its result straight into the image-token rows instead
+        (hidden_states + control['out'] * 1.0, lightcontrol_flux.py:506-507)."""
+        B, h, w = prep["B"], prep["h"], prep["w"]
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)], device=prep["x0"].device)
+        t = t.reshape(-1).to(device=prep["x0"].device, dtype=torch.float32).expand(B).contiguous()
+        tp = ops.timestep_sinusoid(t, 128, round_bf16=prep["round_bf16"])  # Timesteps(128).to(sample.dtype) (:730-733)
+        te = self.time_embedding
+        e1 = ops.skinny_linear(tp, te.linear_1.weight, te.linear_1.bias, act_out=ACT_SILU)
+        emb = ops.skinny_linear(e1, te.linear_2.weight, te.linear_2.bias)  # [B,256] f32
+        x = self._resblock_tail(self.down_res[0], prep["x0"], prep["h1"], emb, self.groups[0], h, w, 128, 128)
+        d = self.down_sample[0].conv
+        x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 128, 128, 3, 3, 2, 1)
+        h, w = h // 2, w // 2
+        r = self.down_res[1]
+        n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
+        h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
+        x = self._resblock_tail(r, x, h1, emb, self.groups[1], h, w, 128, 256)
+        d = self.down_sample[1].conv
+        x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 256, 256, 3, 3, 2, 1)
+        h, w = h // 2, w // 2
+        m = self.mid_convs[0]
+        y = ops.conv2d_nhwc(x, m[0].packed(), m[0].bias, h, w, 256, 256, 3, 3, 1, 1, act=ACT_RELU)
+        y = ops.groupnorm_nhwc(y, m[2].weight, m[2].bias, 8, 1e-5)
+        y = ops.conv2d_nhwc(y, m[3].packed(), m[3].bias, h, w, 256, 256, 3, 3, 1, 1)
+        x = ops.groupnorm_nhwc(y, m[4].weight, m[4].bias, 8, 1e-5, post_add=x)  # mid_convs[0](x) + x (:744)
+        f = self.mid_convs[1]
+        cout = f.weight.shape[0]
+        if add_into is not None:
+            ops.conv2d_nhwc(x, f.packed(), f.bias, h, w, 256, cout, 2, 2, 2, 0, out=add_into, c_offset=add_offset,
+                            c_batch_stride=add_batch_stride, ldc=add_ld, res=add_into, res_offset=add_offset,
+                            res_batch_stride=add_batch_stride, ldr=add_ld)
+            return None
+        return ops.conv2d_nhwc(x, f.packed(), f.bias, h, w, 256, cout, 2, 2, 2, 0)
+
+    @torch.no_grad()
+    def forward(self, sample, timestep):
+        prep = self.prepare_hint(sample)
+        out = self.forward_nhwc(prep, timestep)
+        return {"out": out.permute(0, 3, 1, 2), "scale": self.scale}  # NCHW view like the reference
+
+
+def make_control_fn(control_nets, guided_hint):
+    """Callable(i, timestep_x1000, X, St, S, D) used by FluxTransformer2DModel.denoise: adds control net i's output into the
+    image rows of the joint residual buffer.  The t-independent prefix of every net is computed once per hint."""
+    nets = list(control_nets)
+    preps = [n.prepare_hint(guided_hint) for n in nets]
+
+    def fn(i, t1000, X, St, S, D):
+        if i >= len(nets):
+            return False
+        nets[i].forward_nhwc(preps[i], t1000, add_into=X, add_offset=St * D, add_batch_stride=S * D, add_ld=D)
+        return True
+
+    return fn
+
+
+class FluxTransformer2DModel(_BaseFlux):
+    """The reference's modified transformer (lightcontrol_flux.py:208-553): extra `guided_hint`, `control_nets`
+    arguments; return_dict=False returns the bare tensor."""
+
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,
+                txt_ids=None, guidance=None, joint_attention_kwargs=None, guided_hint=None, control_nets=None,
+                return_dict: bool = True):
+        if control_nets is None:
+            raise TypeError("object of type 'NoneType' has no len()  (pass control_nets=[]; lightcontrol_flux.py:504)")
+        state = self.prepare_conditioning(encoder_hidden_states, pooled_projections, txt_ids, img_ids, guidance)
+        control = make_control_fn(control_nets, guided_hint.to(self.device)) if len(control_nets) else None
+        out = self.denoise(state, hidden_states, timestep, control=control)
+        if not return_dict:
+            return out
+        from .flux import Transformer2DModelOutput
+        return Transformer2DModelOutput(sample=out)
+
+
+class LightControlSampler:
+    """Row L: N-step Euler sampling with the instruction-edit branch (FLUX.1-dev schedule by default: dynamic shift,
+    guidance embedding), i.e. the inference counterpart of train_lightcontrol.py:732-743."""
+
+    def __init__(self, transformer, control_nets, scheduler=None):
+        from .pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+        self.pipeline = FluxPipeline(transformer, scheduler or FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True),
+                                     control_nets=control_nets)
+
+    def __call__(self, prompt_embeds, pooled_prompt_embeds, guided_hint, num_inference_steps=20, guidance_scale=3.5,
+                 height=1024, width=1024, latents=None, generator=None, use_graph=False):
+        return self.pipeline(prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+                             num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, height=height,
+                             width=width, output_type="latent", latents=latents, generator=generator,
+                             guided_hint=guided_hint, use_graph=use_graph).images

@@ -31,7 +31,7 @@ def pad128(n):
 
 def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=None, c_batch_stride=0, ldc=None,
          act=ACT_NONE, gate=None, gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, out2=None, act2=ACT_NONE,
-         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None):
+         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None, bias2=None, bias2_batch_stride=0):
     """C = epi(A W^T).  A, out, res may be sub-views addressed as (tensor, element offset, row stride, batch stride)."""
     lib = _lib.load()
     _req(A, torch.bfloat16, "A")
@@ -64,6 +64,8 @@ def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=No
     a.res = (res.data_ptr() + res_offset * 2) if res is not None else None
     a.res_batch_stride = res_batch_stride
     a.ldr = (ldc if ldr is None else ldr)
+    a.bias2 = bias2.data_ptr() if bias2 is not None else None
+    a.bias2_batch_stride = bias2_batch_stride
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act = act
     a.out_f32 = 1 if out_f32 else 0
@@ -180,4 +182,74 @@ def to_f32(x):
     _req(x, torch.bfloat16, "x")
     out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     check(lib.x2i_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _stream()), "cast")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- ControlNeXt ops
+from ._lib import ACT_RELU, ConvDesc  # noqa: E402
+
+
+def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=None, act=ACT_NONE, bias2=None, res=None,
+                c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None):
+    """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout]."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    _req(w_packed, torch.bfloat16, "w")
+    B = x.shape[0]
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=torch.bfloat16)
+    a = GemmArgs()
+    a.A = x.data_ptr()
+    a.a_batch_stride = H * W * Cin
+    a.lda = Cin
+    a.W = w_packed.data_ptr()
+    a.ldw = KH * KW * Cin
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C = out.data_ptr() + 2 * c_offset
+    a.c_batch_stride = OH * OW * Cout if c_batch_stride is None else c_batch_stride
+    a.ldc = Cout if ldc is None else ldc
+    a.C2 = None
+    a.gate = None
+    a.res = (res.data_ptr() + 2 * res_offset) if res is not None else None
+    a.res_batch_stride = (OH * OW * Cout if res_batch_stride is None else res_batch_stride)
+    a.ldr = (Cout if ldr is None else ldr)
+    a.bias2 = bias2.data_ptr() if bias2 is not None else None
+    a.bias2_batch_stride = bias2.stride(0) if bias2 is not None else 0
+    a.M, a.N, a.K, a.batch = OH * OW, Cout, KH * KW * Cin, B
+    a.act = act
+    a.out_f32 = 0
+    d = ConvDesc(H, W, Cin, KH, KW, stride, pad)
+    check(lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(d), _stream()), "conv2d_nhwc")
+    return out
+
+
+def conv_stem(x_nhwc, w, bias, Cout):
+    """Conv2d(3->Cout, k3, s2, p1): x bf16 NHWC [B,H,W,3]; w f32 [Cout,3,3,3] (ky,kx,ci)."""
+    lib = _lib.load()
+    _req(x_nhwc, torch.bfloat16, "x")
+    _req(w, torch.float32, "w")
+    B, H, W, _ = x_nhwc.shape
+    out = torch.empty((B, H // 2, W // 2, Cout), device=x_nhwc.device, dtype=torch.bfloat16)
+    check(lib.x2i_conv_stem_bf16(_p(x_nhwc), _p(w), _p(bias), _p(out), B, H, W, Cout, _stream()), "conv_stem")
+    return out
+
+
+_gn_scratch = {}
+
+
+def groupnorm_nhwc(x, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add=None, out=None):
+    """GroupNorm on NHWC bf16 [B, ..., C] with fused pre-add (f32 [B,C]), activation and post-add (bf16 like x)."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    out = torch.empty_like(x) if out is None else out
+    n = lib.x2i_groupnorm_scratch_floats(B, G)
+    key = (x.device, n)
+    if key not in _gn_scratch:
+        _gn_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.x2i_groupnorm_nhwc_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), eps, act, _p(pre_add), _p(post_add),
+                                      _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc")
     return out
