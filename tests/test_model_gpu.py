@@ -146,3 +146,24 @@ def test_projector_rejects_dead_t5_path():
     import x2i_amd.proj as XP
     with pytest.raises(NotImplementedError):
         XP.create_proj3_qwen7b(in_channels=29, use_t5=True, use_scale=False, use_cnn=True)
+
+
+@pytest.mark.parametrize("cls", ["MLP", "MLP2", "MLP_plus"])
+def test_legacy_projector_heads_vs_reference_golden(cls):
+    import x2i_amd.proj as XP
+    t, meta = golden("legacy_" + cls)
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("sd.")}
+    kw = dict(in_dim=64, out_dim=128, hidden_dim=128, out_dim1=32)
+    m = getattr(XP, cls)(**kw)
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    x1, x2 = m(t["x"].to(DEV))
+    assert rel_l2(x2, t["x2"]) < 2e-2 and rel_l2(x1, t["x1"]) < 2e-2
+
+
+def test_legacy_proj_front_stage_vs_reference_golden():
+    import x2i_amd.proj as XP
+    t, meta = golden("legacy_Proj_pre")
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("sd.")}
+    m = XP.ProjFrontStage(in_channels=3, input_dim=64, layer_norm_eps=meta["eps"])
+    m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    assert rel_l2(m(t["x"].to(DEV)), t["pre"]) < 2e-2

@@ -152,3 +152,83 @@ def create_proj_minicpm(in_channels, use_t5=True, use_scale=True, use_cnn=False,
     use_cnn = False if use_scale else use_cnn
     return Proj7Exp(in_channels=in_channels, kernel_size=5, input_dim=3584, output_dim0=768, output_dim1=4096, num_layers=2,
                     num_heads=28, norm_eps=1e-6, head_dim=128, use_t5=use_t5, use_scale=use_scale, use_cnn=use_cnn, **kw)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Legacy projector heads (model_internvl/proj.py) -- imported by no reference script, kept for checkpoint compatibility.
+# ------------------------------------------------------------------------------------------------------------------
+class _LegacyMLP(nn.Module):
+    """Common body of MLP / MLP2 / MLP_plus (model_internvl/proj.py:53-130): LayerNorm -> [Linear,GELU]*n -> Linear
+    (no bias) ; x2 = GELU(.) ; x1 = mean_S(fc(x2))."""
+
+    n_proj = 3
+    fc_chain = False
+
+    def __init__(self, in_dim=4096, out_dim=4096, hidden_dim=4096, out_dim1=768, layer_norm_eps=1e-5, use_residual=True,
+                 device="cuda", dtype=torch.bfloat16):
+        super().__init__()
+        self.eps = layer_norm_eps
+        self.layernorm = _LN(in_dim, device, dtype)
+        dims = [in_dim] + [hidden_dim] * (self.n_proj - 1) + [out_dim]
+        self.projector = _Sparse({2 * i: _Lin(dims[i], dims[i + 1], False, device, dtype) for i in range(self.n_proj)})
+        if self.fc_chain:  # MLP2: Linear,GELU,Linear,GELU,Linear without bias (:91-97)
+            self.fc = _Sparse({0: _Lin(out_dim, out_dim1, False, device, dtype), 2: _Lin(out_dim1, out_dim1, False, device, dtype),
+                               4: _Lin(out_dim1, out_dim1, False, device, dtype)})
+        else:  # MLP / MLP_plus: one biased Linear (:64, :123)
+            self.fc = _Lin(out_dim, out_dim1, True, device, dtype)
+
+    @torch.no_grad()
+    def forward(self, x):
+        B, S, H = x.shape
+        h = ops.ln_affine(x.to(torch.bfloat16).contiguous(), self.layernorm.weight, self.layernorm.bias, self.eps)
+        for i in range(self.n_proj - 1):
+            h = ops.gemm(h, self.projector[2 * i].weight, act=ACT_GELU_ERF, M=B * S)
+        x2 = ops.gemm(h, self.projector[2 * (self.n_proj - 1)].weight, act=ACT_GELU_ERF, M=B * S)  # x2 = GELU(projector(x))
+        if self.fc_chain:
+            t = ops.gemm(x2, self.fc[0].weight, act=ACT_GELU_ERF, M=B * S)
+            t = ops.gemm(t, self.fc[2].weight, act=ACT_GELU_ERF, M=B * S)
+            x1_tok = ops.gemm(t, self.fc[4].weight, M=B * S, out_f32=True)
+        else:
+            x1_tok = ops.gemm(x2, self.fc.weight, self.fc.bias, M=B * S, out_f32=True)
+        x1 = ops.seq_mean(x1_tok.view(B, S, -1))
+        return x1.to(torch.bfloat16), x2.view(B, S, -1)
+
+
+class MLP(_LegacyMLP):
+    """model_internvl/proj.py:53-73"""
+
+
+class MLP2(_LegacyMLP):
+    """model_internvl/proj.py:76-102"""
+    fc_chain = True
+
+
+class MLP_plus(_LegacyMLP):
+    """model_internvl/proj.py:104-130 (six projector linears, LayerNorm default eps)"""
+    n_proj = 6
+
+    def __init__(self, in_dim=4096, out_dim=4096, hidden_dim=4096, out_dim1=768, use_residual=True, device="cuda",
+                 dtype=torch.bfloat16):
+        super().__init__(in_dim, out_dim, hidden_dim, out_dim1, 1e-5, use_residual, device, dtype)
+
+
+class ProjFrontStage(nn.Module):
+    """The kernelised part of legacy Proj / Proj2 (model_internvl/proj.py:163-166): norm0 -> Conv2d(C->1,5x5) -> norm1.
+    The T5Stack that follows in the reference stays on `transformers` and is not part of this class."""
+
+    def __init__(self, in_channels=2, input_dim=896, layer_norm_eps=1e-6, device="cuda", dtype=torch.bfloat16):
+        super().__init__()
+        self.eps = layer_norm_eps
+        self.norm0 = _LN(input_dim, device, dtype)
+        conv = nn.Module()
+        conv.weight = _param(1, in_channels, 5, 5, device=device, dtype=dtype)
+        conv.bias = _param(1, device=device, dtype=dtype)
+        self.conv = conv
+        self.norm1 = _LN(input_dim, device, dtype)
+
+    @torch.no_grad()
+    def forward(self, x):
+        B, C, S, H = x.shape
+        x = ops.ln_affine(x.to(torch.bfloat16).contiguous(), self.norm0.weight, self.norm0.bias, self.eps)
+        x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())
+        return ops.ln_affine(x, self.norm1.weight, self.norm1.bias, self.eps)
