@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx * scale_log2);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (q = li, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run = xhalf_sum(l_run);
   const float inv = 1.f / l_run;
   const int q = q0 + li;
   if (q < S) {

@@ -11,10 +11,10 @@ __device__ __forceinline__ void unpack8(const bf16x8_t& v, float (&f)[8]) {
   for (int i = 0; i < 8; ++i) f[i] = bf16_to_f32((bf16_t)v[i]);
 }
 __device__ __forceinline__ bf16x8_t pack8(const float (&f)[8]) {
-  bf16x8_t v;
+  union { bf16x8_t v; uint32_t u[4]; } r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = (short)f32_to_bf16(f[i]);
-  return v;
+  for (int i = 0; i < 4; ++i) r.u[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return r.v;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -293,7 +293,9 @@ __device__ __forceinline__ void stage_unit(__amdgpu_buffer_rsrc_t rsrc, char* ld
                                              16, voff[j], koff_bytes, 0, 0);
 }
 
-template <int ACT, bool RES, bool OUTF32, bool HASC2>
+// ABL: ablation bits for tools/gemm_ablate.py (wrong results by design): 1 = no ds_reads after the first K-tile,
+// 2 = no barriers / load waits, 4 = no global->LDS DMA after the prologue.  ABL = 0 is the product kernel.
+template <int ACT, bool RES, bool OUTF32, bool HASC2, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A.k0 | W.k0 | A.k1 | W.k1]
   const int tid = threadIdx.x;
@@ -349,51 +351,97 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
   const uint32_t b_base = wn * 64 * 64 + frag;   // + j*1024 per n-tile
 
   const int nk = p.K / BK;
-  // prologue: all four units of tile 0
-  stage_unit(a_rsrc, smem + 0 * UNIT_BYTES, a_voff, 0, wave);
-  stage_unit(w_rsrc, smem + 1 * UNIT_BYTES, w_voff, 0, wave);
-  stage_unit(a_rsrc, smem + 2 * UNIT_BYTES, a_voff, 64, wave);
-  stage_unit(w_rsrc, smem + 3 * UNIT_BYTES, w_voff, 64, wave);
+  // ---- software pipeline (see header comment): unit u = 4*tile + {0:A.k0, 1:W.k0, 2:A.k1, 3:W.k1} lives in LDS slot u % 8
+  // and is DMA-issued LEAD = 5 phases before the phase with the same number; fragments of phase G+1 are read from LDS
+  // while the MFMAs of phase G run (two register sets); barriers only at odd phases, where freshly landed units are
+  // first read.  In flight across a barrier: (LEAD - 3) = 2 units = 4 loads per thread (counted vmcnt, never 0).
+  constexpr int LEAD = 5;
+  const int total_units = 4 * nk;
+  auto issue_unit = [&](int u) {
+    if ((ABL & 4) && u >= LEAD) return;
+    const int t = u >> 2, pu = u & 3;
+    char* dst = smem + (u & 7) * UNIT_BYTES;
+    const uint32_t koff = (uint32_t)(t * BK + (pu >> 1) * 32) * 2;
+    if (pu & 1) stage_unit(w_rsrc, dst, w_voff, koff, wave);
+    else stage_unit(a_rsrc, dst, a_voff, koff, wave);
+  };
+  auto wait_units_in_flight = [&](int units) {  // wave-uniform small integer -> immediate vmcnt
+    if (units >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (units == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+#pragma unroll
+  for (int u = 0; u < LEAD; ++u)
+    if (u < total_units) issue_unit(u);
 
-  bf16x8_t wf[4], af[8];
+  bf16x8_t wf[2][4], af[2][4];
+  // first fragments: units 0 (A.k0) and 1 (W.k0) of tile 0
+  wait_units_in_flight(min(LEAD, total_units) - 2);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wf[0][j] = *(const bf16x8_t*)(smem + 1 * UNIT_BYTES + b_base + j * 1024);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[0][i] = *(const bf16x8_t*)(smem + 0 * UNIT_BYTES + a_base + i * 1024);
+
   for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * TILE2_BYTES;
-    char* nxt = smem + ((kt + 1) & 1) * TILE2_BYTES;
+    const char* cur = smem + (kt & 1) * TILE2_BYTES;
+    const char* nxt = smem + ((kt + 1) & 1) * TILE2_BYTES;
     const bool more = (kt + 1 < nk);
-    const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
+      const int G = 4 * kt + ph;
       const int kh = ph >> 1, mh = ph & 1;
-      if (mh == 0) {
-        // units (A.kh, W.kh) of this tile are about to be read for the first time: everything issued >= 3 phases ago
-        // must have landed (at most the two younger units = 4 loads may still be in flight), for every wave
-        if (kh == 0 || more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+      if (ph & 1) {
+        // odd phase: the units read below ((A.k1,W.k1) of this tile at ph 1, (A.k0,W.k0) of the next at ph 3) must have
+        // landed for every wave; units issued so far = G-1+LEAD, needed = G+2
+        const bool need = (ph == 1) || more;
+        if (need && !((ABL & 2) && kt > 0)) {
+          const int last_issued = min(G - 1 + LEAD, total_units - 1);
+          wait_units_in_flight(last_issued - (G + 2));
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
       }
-      if (more) {
-        if (ph == 0) stage_unit(a_rsrc, nxt + 0 * UNIT_BYTES, a_voff, koff, wave);
-        if (ph == 1) stage_unit(w_rsrc, nxt + 1 * UNIT_BYTES, w_voff, koff, wave);
-        if (ph == 2) stage_unit(a_rsrc, nxt + 2 * UNIT_BYTES, a_voff, koff + 64, wave);
-        if (ph == 3) stage_unit(w_rsrc, nxt + 3 * UNIT_BYTES, w_voff, koff + 64, wave);
-      }
-      const char* Au = cur + (2 * kh) * UNIT_BYTES + a_base;
-      const char* Wu = cur + (2 * kh + 1) * UNIT_BYTES + b_base;
-      if (mh == 0) {
-        // both m-halves' A fragments are read now (same units): phase mh=1 then starts straight on the MFMA pipe
+      if (G + LEAD < total_units) issue_unit(G + LEAD);
+      // ---- LDS -> registers for phase G+1
+      if (!((ABL & 1) && kt > 0)) {
+        if (ph == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(Wu + j * 1024);
+          for (int i = 0; i < 4; ++i) af[1][i] = *(const bf16x8_t*)(cur + 0 * UNIT_BYTES + a_base + (4 + i) * 1024);
+        } else if (ph == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(Au + i * 1024);
+          for (int j = 0; j < 4; ++j) wf[1][j] = *(const bf16x8_t*)(cur + 3 * UNIT_BYTES + b_base + j * 1024);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[0][i] = *(const bf16x8_t*)(cur + 2 * UNIT_BYTES + a_base + i * 1024);
+        } else if (ph == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[1][i] = *(const bf16x8_t*)(cur + 2 * UNIT_BYTES + a_base + (4 + i) * 1024);
+        } else if (more) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wf[0][j] = *(const bf16x8_t*)(nxt + 1 * UNIT_BYTES + b_base + j * 1024);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[0][i] = *(const bf16x8_t*)(nxt + 0 * UNIT_BYTES + a_base + i * 1024);
+        }
       }
-      __builtin_amdgcn_s_setprio(1);
+      // ---- 16 MFMAs of phase G on the register set loaded during phase G-1
+      constexpr int VAR = ABL >> 4;  // scheduling experiments (ABL >= 16): 1 = setprio, 2 = sched_group interleave, 3 = both
+      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[mh * 4 + i], acc[mh * 4 + i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+          acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][j], af[mh][i], acc[mh * 4 + i][j], 0, 0, 0);
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+      if (VAR & 2) {
+        // interleave: 2 MFMA, 1 DS read, ... ; the two DMA pieces after the 4th and 10th MFMA
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          if (k == 1 || k == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+        }
+      }
     }
   }
   epilogue_store<ACT, RES, OUTF32, HASC2, 8, 4>(p, acc, z, m0 + wm * 128 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
@@ -479,6 +527,17 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
   }
 #undef X2I_PICK
   // tile choice: the 256^2 pipelined kernel needs enough tiles to fill 256 CUs (1 workgroup per CU)
+  if (const char* ab = getenv("X2I_GEMM_ABLATE")) {  // measurement-only kernels (tools/gemm_ablate.py)
+    const int abl = atoi(ab);
+    if (abl == 1) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 1>;
+    if (abl == 2) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 2>;
+    if (abl == 4) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 4>;
+    if (abl == 3) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 3>;
+    if (abl == 7) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 7>;
+    if (abl == 16) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 16>;
+    if (abl == 32) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 32>;
+    if (abl == 48) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 48>;
+  }
   const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
   const int force = force_env ? atoi(force_env) : 0;
   const long long tiles256 = (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) * a->batch;

@@ -21,15 +21,26 @@ int x2i_set_error(int code, const char* fmt, ...);
 int x2i_check_launch(const char* what);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// float -> bf16, round-to-nearest-even (== torch .to(bfloat16)); hipcc lowers these casts to v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  // round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
+  const f32x2_hw v = {lo, hi};
+  const bf16x2_hw h = __builtin_convertvector(v, bf16x2_hw);
+  return __builtin_bit_cast(uint32_t, h);
+}
+// value held by lane ^ 32, via v_permlane32_swap (no LDS round trip); returns max / sum of own and partner
+__device__ __forceinline__ float xhalf_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
