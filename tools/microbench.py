@@ -53,8 +53,11 @@ def main():
     Q, K_ = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128)
     VT = rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device=DEV, dtype=torch.bfloat16)
-    t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
-    print(f"attention B={B} H={H} S={S}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
+    for var, nm in (("0", "nw4 thr8"), ("1", "nw8 thr8"), ("2", "nw4 thr0"), ("3", "nw8 thr0"), ("0", "nw4 thr8")):
+        os.environ["X2I_ATTN_VARIANT"] = var
+        t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
+        print(f"attention[{nm}] B={B} H={H} S={S}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
+    os.environ.pop("X2I_ATTN_VARIANT")
     # qkv split
     qkv = rnd(B * S, 3 * D)
     nw = rnd(128)

@@ -17,6 +17,7 @@
 //   * O^T accumulates in 4 x f32x16; epilogue normalises by 1/l and writes token-major bf16 (8-byte stores)
 #include "x2i_common.h"
 #include "x2i_kernels.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -39,7 +40,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NW>
+template <int NW, int THR>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S,
                                                            int Spad, int ldo, long long o_bs, float scale_log2) {
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
     mx = xhalf_max(mx);
-    const float m_new = fmaxf(m_run, mx * scale_log2);
+    // defer-max (T13): keep the old running max while no row of this wave grew by more than THR (exp2 domain), so the
+    // O rescale pass is skipped on most tiles; P is then bounded by 2^THR instead of 1 (fp32 accumulate, bf16 P).
+    float m_new = fmaxf(m_run, mx * scale_log2);
+    if (THR > 0 && __all(m_new - m_run <= (float)THR)) m_new = m_run;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
@@ -215,13 +219,23 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   if (!Q || !K || !VT || !O) return x2i_set_error(X2I_ERR_ARG, "attention: null pointer");
   if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention: need Spad %% 128 == 0 and Spad >= S (S=%d Spad=%d)", S, Spad);
   if (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)) return x2i_set_error(X2I_ERR_ALIGN, "attention: output rows must be 8-byte aligned");
-  constexpr int NW = 4;
   const size_t shm = 2 * (KTILE + VTILE);
-  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));
   const float scale_log2 = scale * 1.4426950408889634f;
-  dim3 grid((S + 32 * NW - 1) / (32 * NW), H, B);
-  hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
-                     (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);
+  const char* ev = getenv("X2I_ATTN_VARIANT");  // A/B benchmarking: "nw8", "thr0", "nw8thr0"
+  const int var = ev ? atoi(ev) : 0;
+#define X2I_ATTN_LAUNCH(NW_, THR_)                                                                                          \
+  {                                                                                                                         \
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, THR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)shm);                                                                           \
+    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));                          \
+    dim3 grid((S + 32 * NW_ - 1) / (32 * NW_), H, B);                                                                       \
+    hipLaunchKernelGGL((attn_fwd_kernel<NW_, THR_>), grid, dim3(NW_ * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);                                   \
+  }
+  if (var == 1) X2I_ATTN_LAUNCH(8, 8)
+  else if (var == 2) X2I_ATTN_LAUNCH(4, 0)
+  else if (var == 3) X2I_ATTN_LAUNCH(8, 0)
+  else X2I_ATTN_LAUNCH(4, 8)
+#undef X2I_ATTN_LAUNCH
   return x2i_check_launch("attention");
 }

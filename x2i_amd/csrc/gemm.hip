@@ -267,6 +267,81 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   epilogue_store<ACT, RES, OUTF32, HASC2, 4, 4>(p, acc, z, m0 + wm * 64 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
 }
 
+// LDS-staged epilogue of the 256x256 kernel: every wave parks its finished 128x64 bf16 sub-tile in a private LDS region
+// (row stride 144 B: 16-byte aligned, spreads the 16 rows of a ds_write_b64 over the banks) and writes it out as whole
+// 128-byte row segments with 16-byte stores -- a wave store instruction covers 8 full cache lines instead of sixteen
+// 32-byte fragments (the direct accumulator layout), which is what the HBM-bound epilogue of the large-N GEMMs needs.
+constexpr int EPI_ROW_BYTES = 144;
+constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // 18 KiB per wave, 144 KiB per workgroup
+
+template <int ACT, bool RES, bool HASC2>
+__device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc)[8][4], int z, int m_wave, int n_wave, int lane,
+                                                   char* wave_lds) {
+  const int mlane = lane & 15, ng = lane >> 4;
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+  bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
+  bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
+  constexpr int NPASS = HASC2 ? 2 : 1;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n_wave + j * 16 + ng * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (n + 3 < p.N) {
+        if (p.bias) {
+          const uint2 bb = *(const uint2*)(p.bias + n);
+          bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+          bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
+        }
+        if (b2) {
+          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+          bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
+        }
+      }
+      static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int mrel = i * 16 + mlane;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
+        if constexpr (RES) {
+          const int m = m_wave + mrel;
+          if (m < p.M && n + 3 < p.N) {
+            const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
+            v[0] = __uint_as_float(r2.x << 16) + gv[0] * v[0];
+            v[1] = __uint_as_float(r2.x & 0xffff0000u) + gv[1] * v[1];
+            v[2] = __uint_as_float(r2.y << 16) + gv[2] * v[2];
+            v[3] = __uint_as_float(r2.y & 0xffff0000u) + gv[3] * v[3];
+          }
+        }
+        if (pass == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
+        }
+        *(uint2*)(wave_lds + mrel * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      });
+    });
+    // the region is private to this wave: LDS operations of one wave complete in order, only the data hazard matters
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16_t* dst = (pass == 0) ? Cz : C2z;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + (lane >> 3), c = lane & 7;
+      const bf16x8_t d = *(const bf16x8_t*)(wave_lds + row * EPI_ROW_BYTES + c * 16);
+      const int m = m_wave + row, n = n_wave + c * 8;
+      if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
+    }
+    if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 256x256x64 pipelined kernel (8 waves, 1 workgroup per CU, 128 KiB LDS) for the large DiT GEMMs.
 //
@@ -283,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int UNIT_BYTES = 256 * 32 * 2;        // 16 KiB
 constexpr int TILE2_BYTES = 4 * UNIT_BYTES;     // 64 KiB per K-tile
-constexpr int SMEM2_BYTES = 2 * TILE2_BYTES;    // 128 KiB
+constexpr int SMEM2_BYTES = 8 * 18432;          // 144 KiB: 128 KiB operand ring, reused as 8 x 18 KiB epilogue staging
 
 __device__ __forceinline__ void stage_unit(__amdgpu_buffer_rsrc_t rsrc, char* lds_unit, const uint32_t (&voff)[2],
                                            uint32_t koff_bytes, int wave) {
@@ -444,6 +519,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
       }
     }
   }
+  if (ABL & 8) {  // ablation: no epilogue (keep the accumulators alive with one predicated store)
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 12345.678f) ((float*)p.C)[tid] = sacc;
+    return;
+  }
+  if constexpr (!OUTF32) {
+    // whole-line stores through LDS need 16-byte aligned rows and N % 8 == 0 (wave-uniform test)
+    if (((p.N | p.ldc) & 7) == 0 && (!RES || (p.ldr & 3) == 0) && ((((uintptr_t)p.C) | ((uintptr_t)p.C2)) & 15) == 0 && (p.c_bs & 7) == 0) {
+      __syncthreads();  // every wave is done reading the operand ring before it is reused as staging space
+      epilogue_store_lds<ACT, RES, HASC2>(p, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
+      return;
+    }
+  }
   epilogue_store<ACT, RES, OUTF32, HASC2, 8, 4>(p, acc, z, m0 + wm * 128 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
 }
 
@@ -534,6 +626,7 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
     if (abl == 4) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 4>;
     if (abl == 3) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 3>;
     if (abl == 7) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 7>;
+    if (abl == 8) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 8>;
     if (abl == 16) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 16>;
     if (abl == 32) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 32>;
     if (abl == 48) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 48>;

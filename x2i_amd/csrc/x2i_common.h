@@ -44,11 +44,12 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
+  // exp(-2u) = exp2(-2 log2(e) u); v_exp_f32 + v_rcp_f32 (1 ulp) instead of a full-precision division
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x / (1.0f + __expf(-2.0f * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // activation codes shared by every kernel and by the C ABI (include/x2i.h)
 enum { X2I_ACT_NONE = 0, X2I_ACT_GELU_TANH = 1, X2I_ACT_GELU_ERF = 2, X2I_ACT_SILU = 3, X2I_ACT_RELU = 4 };
