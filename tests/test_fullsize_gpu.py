@@ -1,0 +1,134 @@
+"""Parity at BASELINE.json's FULL sizes (FLUX width 3072 / 24 heads, 1024x1024 -> 4096 image + 512 text tokens, real
+projector shapes) -- direct oracle comparison where the CPU oracle finishes in about a minute, size-independent
+properties (batch independence, determinism under graph replay, convexity of attention, linearity of the
+layer-fusion stage, pack/unpack identity) for the whole 57-block model."""
+import math
+
+import pytest
+import torch
+
+from oracle import flux as OF
+from oracle import projector as OP
+from oracle import sampler as OS
+from tests.util import rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+def test_one_double_one_single_block_at_full_sequence_vs_oracle():
+    """D=3072, S = 512 + 4096: exercises the 256x256 pipelined GEMM, the LDS-staged epilogue and attention at S=4608."""
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=1, num_single_layers=1)
+    sd = OF.random_flux_state_dict(cfg, seed=21, std=0.02)
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
+    hidden, enc, pooled = seeded((1, 4096, 64), 1), seeded((1, 512, 4096), 2), seeded((1, 768), 3)
+    ts = torch.tensor([0.5])
+    img_ids, txt_ids = OS.prepare_latent_image_ids(64, 64), torch.zeros(512, 3)
+    out = m(hidden_states=hidden.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV),
+            timestep=ts.to(DEV), img_ids=img_ids.to(DEV), txt_ids=txt_ids.to(DEV), return_dict=False)[0]
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = OF.flux_forward({k: rb(v) for k, v in sd.items()}, cfg, rb(hidden), rb(enc), rb(pooled), ts, img_ids, txt_ids)
+    assert rel_l2(out, ref) < 2e-2
+
+
+@pytest.fixture(scope="module")
+def full_model():
+    from x2i_amd.flux import FluxTransformer2DModel
+    return FluxTransformer2DModel(device=DEV).init_random_(seed=5, std=0.02)
+
+
+def _inputs(B, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return dict(hidden=torch.randn((B, 4096, 64), device=DEV, generator=g).bfloat16(),
+                enc=torch.randn((B, 512, 4096), device=DEV, generator=g).bfloat16(),
+                pooled=torch.randn((B, 768), device=DEV, generator=g).bfloat16(),
+                t=torch.tensor([0.75, 0.25, 0.5, 1.0][:B], device=DEV).bfloat16(),
+                img_ids=OS.prepare_latent_image_ids(64, 64).to(DEV), txt_ids=torch.zeros(512, 3, device=DEV))
+
+
+def _fwd(m, x, sl=slice(None)):
+    return m(hidden_states=x["hidden"][sl], encoder_hidden_states=x["enc"][sl], pooled_projections=x["pooled"][sl],
+             timestep=x["t"][sl], img_ids=x["img_ids"], txt_ids=x["txt_ids"], return_dict=False)[0]
+
+
+def test_full_model_batch_independence_and_determinism(full_model):
+    """19 + 38 blocks, 11.9 B parameters, 1024^2: no cross-sample operation exists on the path, so a
+    sample's result must not depend on what else is in the batch -- bit for bit -- and reruns must be identical."""
+    x = _inputs(3, 11)
+    full = _fwd(full_model, x)
+    assert full.shape == (3, 4096, 64) and torch.isfinite(full.float()).all()
+    assert float(full.float().std()) > 1e-3
+    for b in range(3):
+        assert torch.equal(_fwd(full_model, x, slice(b, b + 1))[0], full[b]), b
+    assert torch.equal(_fwd(full_model, x), full)
+
+
+def test_full_pipeline_graph_replay_equals_eager(full_model):
+    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+    pipe = FluxPipeline(full_model, FlowMatchEulerDiscreteScheduler())
+    x = _inputs(2, 12)
+    kw = dict(prompt_embeds=x["enc"], pooled_prompt_embeds=x["pooled"], num_inference_steps=4, guidance_scale=3.5, height=1024,
+              width=1024, output_type="latent", latents=x["hidden"])
+    a = pipe(**kw).images
+    b = pipe(**kw, use_graph=True).images
+    c = pipe(**kw, use_graph=True).images
+    assert a.shape == (2, 4096, 64) and torch.equal(a, b) and torch.equal(b, c)
+    u = FluxPipeline._unpack_latents(a, 1024, 1024, 16)
+    assert u.shape == (2, 16, 128, 128)
+    assert torch.equal(FluxPipeline._pack_latents(u, 2, 16, 128, 128), a)  # pack o unpack = id at full size
+
+
+def test_attention_is_a_convex_combination_at_full_size():
+    """softmax rows sum to one: with V = per-head constants the output equals the constant; with V in [0,1] it stays there."""
+    from x2i_amd import ops
+    B, H, S = 1, 24, 4608
+    Spad = ops.pad128(S)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Q = torch.randn((B, H, Spad, 128), device=DEV, generator=g).bfloat16()
+    K = torch.randn((B, H, Spad, 128), device=DEV, generator=g).bfloat16()
+    const = (torch.arange(H, device=DEV).float() / 8 - 1).bfloat16()
+    VT = const.view(1, H, 1, 1).expand(B, H, 128, Spad).contiguous()
+    out = torch.empty((B, S, H * 128), device=DEV, dtype=torch.bfloat16)
+    ops.attention(Q, K, VT, out, B, H, S, Spad, H * 128, S * H * 128, 1 / math.sqrt(128))
+    want = const.view(1, 1, H, 1).expand(B, S, H, 128).reshape(B, S, H * 128)
+    assert (out.float() - want.float()).abs().max() < 2e-2
+    VT = torch.rand((B, H, 128, Spad), device=DEV, generator=g).bfloat16()
+    ops.attention(Q, K, VT, out, B, H, S, Spad, H * 128, S * H * 128, 1 / math.sqrt(128))
+    assert out.float().min() >= -1e-3 and out.float().max() <= 1 + 1e-2
+
+
+@pytest.mark.parametrize("kind", ["qwen3b", "qwen7b", "internvl1b"])
+def test_projector_full_size_vs_oracle(kind):
+    """Real shapes: [B, C, 512, H] (78-106 MB per sample), S = 512 padded text tokens."""
+    from x2i_amd.infer.harness import PROJECTORS
+    make, C, kw = PROJECTORS[kind]
+    sd = OP.random_proj_state_dict(kind, seed=9)
+    proj = make(in_channels=C, device=DEV, **kw)
+    proj.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
+    H = OP.FACTORIES[kind]["input_dim"]
+    x = seeded((2, C, 512, H), 4, 3.0).bfloat16()
+    x1, x2 = proj(x.to(DEV))
+    r1, r2 = OP.proj7exp({k: rb(v) for k, v in sd.items()}, x.float())
+    assert x1.shape == (2, 768) and x2.shape == (2, 512, 4096)
+    assert rel_l2(x2, r2) < 1e-2 and rel_l2(x1, r1) < 1e-2
+
+
+def test_layer_fusion_conv_is_linear_at_full_size():
+    from x2i_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn((1, 29, 512, 3584), device=DEV, generator=g).bfloat16()
+    y = torch.randn((1, 29, 512, 3584), device=DEV, generator=g).bfloat16()
+    w = torch.randn((29, 25), device=DEV, generator=g) / 27
+    zero = torch.zeros(1, device=DEV)
+    s = (x.float() * 2).bfloat16()  # exact in bf16
+    cx, cs = ops.proj_conv5x5(x, w, zero), ops.proj_conv5x5(s, w, zero)
+    assert rel_l2(cs, 2 * cx.float()) < 4e-3  # f(2x) = 2 f(x) up to the bf16 rounding of the outputs
+    cxy = ops.proj_conv5x5((x.float() + y.float()).bfloat16(), w, zero)
+    assert rel_l2(cxy, cx.float() + ops.proj_conv5x5(y, w, zero).float()) < 1e-2

@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restri
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const f32x4_t x0 = *(const f32x4_t*)(xs + b * K + k), x1 = *(const f32x4_t*)(xs + b * K + k + 4);
-        acc[b] += wf[0] * x0[0] + wf[1] * x0[1] + wf[2] * x0[2] + wf[3] * x0[3] + wf[4] * x1[0] + wf[5] * x1[1] +
-                  wf[6] * x1[2] + wf[7] * x1[3];
+        // explicit fma chain: the arithmetic of one sample must not depend on how many samples share the launch
+        float a = acc[b];
+        a = fmaf(wf[0], x0[0], a); a = fmaf(wf[1], x0[1], a); a = fmaf(wf[2], x0[2], a); a = fmaf(wf[3], x0[3], a);
+        a = fmaf(wf[4], x1[0], a); a = fmaf(wf[5], x1[1], a); a = fmaf(wf[6], x1[2], a); a = fmaf(wf[7], x1[3], a);
+        acc[b] = a;
       }
     }
 #pragma unroll
