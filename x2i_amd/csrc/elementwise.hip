@@ -190,36 +190,53 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restri
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n_base = (blockIdx.x * 4 + wave) * rpw;  // 4 waves x rpw output rows each
+  // R = 4 weight rows are streamed together: 4 x (K/512) independent 16-byte loads in flight per lane (a single row
+  // would leave the wave latency-bound on HBM)
+  constexpr int R = 4;
 #pragma unroll 1
-  for (int rr = 0; rr < rpw; ++rr) {
-    const int n = n_base + rr;
-    if (n >= N) break;
-    const bf16_t* w = W + (long long)n * K;
-    float acc[NB];
+  for (int rr = 0; rr < rpw; rr += R) {
+    const int n0 = n_base + rr;
+    if (n0 >= N) break;
+    float acc[R][NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
     for (int k = lane * 8; k < K; k += 512) {
-      float wf[8];
-      unpack8(*(const bf16x8_t*)(w + k), wf);
+      bf16x8_t wv[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int n = min(n0 + r, N - 1);  // clamp: rows past N are computed and discarded
+        wv[r] = *(const bf16x8_t*)(W + (long long)n * K + k);
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const f32x4_t x0 = *(const f32x4_t*)(xs + b * K + k), x1 = *(const f32x4_t*)(xs + b * K + k + 4);
-        // explicit fma chain: the arithmetic of one sample must not depend on how many samples share the launch
-        float a = acc[b];
-        a = fmaf(wf[0], x0[0], a); a = fmaf(wf[1], x0[1], a); a = fmaf(wf[2], x0[2], a); a = fmaf(wf[3], x0[3], a);
-        a = fmaf(wf[4], x1[0], a); a = fmaf(wf[5], x1[1], a); a = fmaf(wf[6], x1[2], a); a = fmaf(wf[7], x1[3], a);
-        acc[b] = a;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float wf[8];
+          unpack8(wv[r], wf);
+          // explicit fma chain: the arithmetic of one sample must not depend on how many samples share the launch
+          float a = acc[r][b];
+          a = fmaf(wf[0], x0[0], a); a = fmaf(wf[1], x0[1], a); a = fmaf(wf[2], x0[2], a); a = fmaf(wf[3], x0[3], a);
+          a = fmaf(wf[4], x1[0], a); a = fmaf(wf[5], x1[1], a); a = fmaf(wf[6], x1[2], a); a = fmaf(wf[7], x1[3], a);
+          acc[r][b] = a;
+        }
       }
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = wave_sum(acc[b]);
-    if (lane == 0) {
-      const float bv = bias ? bf16_to_f32(bias[n]) : 0.f;
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        float v = apply_act(acc[b] + bv, act_out);
-        float* yp = Y + (long long)b * ldy + n;
-        *yp = accumulate ? (*yp + v) : v;
+      for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum(acc[r][b]);
+      const int n = n0 + r;
+      if (lane == 0 && n < N && rr + r < rpw) {
+        const float bv = bias ? bf16_to_f32(bias[n]) : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float v = apply_act(acc[r][b] + bv, act_out);
+          float* yp = Y + (long long)b * ldy + n;
+          *yp = accumulate ? (*yp + v) : v;
+        }
       }
     }
   }
@@ -330,7 +347,7 @@ int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const 
     const void* xp = (const char*)X + (long long)b0 * K * esz;
     float* yp = Y + (long long)b0 * ldy;
     // many rows per block when N is huge (the 1M-row AdaLN modulation table) so the activations are staged once
-    const int rpw = N >= 65536 ? 16 : 2;
+    const int rpw = N >= 65536 ? 16 : 4;
     const dim3 grid((N + 4 * rpw - 1) / (4 * rpw)), block(256);
     const size_t shm = (size_t)nb * K * 4;
     if (shm > 160 * 1024) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: B*K too large for LDS");
