@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU")
     ap.add_argument("--denoise-steps", type=int, default=4)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config (1-based): 2 = Qwen-3B/shuttle-3 (default, the bench line), 3 = MiniCPM projector, "
+                         "4 = InternVL-4B projector, 5 = LightControl edit branch (FLUX.1-dev schedule, 20 steps, 19 ControlNeXt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -157,11 +160,37 @@ def main():
     from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
     from x2i_amd.proj import create_proj3_qwen3b
 
+    from x2i_amd.infer.harness import PROJECTORS, HIDDEN
     B, N = args.batch, args.denoise_steps
-    St, C, Hm = 512, 37, 2048
-    model = FluxTransformer2DModel(device=dev).init_random_(seed=1234 + rank)
-    proj = create_proj3_qwen3b(in_channels=C, use_t5=False, use_scale=False, use_cnn=True, device=dev).init_random_(seed=7)
-    pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
+    St = 512
+    kind = {2: "qwen3b", 3: "minicpm", 4: "internvl4b", 5: "qwen7b"}[args.config]
+    make, C, pkw = PROJECTORS[kind]
+    Hm = HIDDEN[kind]
+    proj = make(in_channels=C, device=dev, **pkw).init_random_(seed=7)
+    hint = None
+    if args.config == 5:
+        from x2i_amd.lightcontrol import ControlNeXtModel, FluxTransformer2DModel as LCFlux
+        if N == 4:
+            N = 20
+        model = LCFlux(guidance_embeds=True, device=dev).init_random_(seed=1234 + rank)
+        nets = []
+        for i in range(19):
+            net = ControlNeXtModel(device=dev)
+            gw = torch.Generator(device="cpu").manual_seed(500 + i)
+            for name, prm in net.named_parameters():
+                if prm.dim() > 1:  # conv / linear weights: N(0, 1/fan_in)
+                    v = torch.randn(prm.shape, generator=gw) / prm[0].numel() ** 0.5
+                elif name.endswith("weight"):  # GroupNorm scale
+                    v = 1.0 + 0.1 * torch.randn(prm.shape, generator=gw)
+                else:
+                    v = 0.02 * torch.randn(prm.shape, generator=gw)
+                prm.data.copy_(v)
+            nets.append(net)
+        pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True), control_nets=nets)
+        hint = (torch.rand((B, 3, args.size, args.size), device=dev) * 2 - 1).bfloat16()
+    else:
+        model = FluxTransformer2DModel(device=dev).init_random_(seed=1234 + rank)
+        pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     mllm_hidden = (torch.randn((B, C, St, Hm), device=dev, generator=g) * 3.0).bfloat16()
     noise = torch.randn((B, (args.size // 16) ** 2, 64), device=dev, generator=g).bfloat16()
@@ -170,7 +199,7 @@ def main():
     def one_pass():
         pooled, embeds = proj(mllm_hidden)
         lat = pipe(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=N, guidance_scale=3.5,
-                   height=args.size, width=args.size, output_type="latent", latents=noise,
+                   height=args.size, width=args.size, output_type="latent", latents=noise, guided_hint=hint,
                    use_graph=not args.no_graph).images
         if world > 1:
             dist.all_gather(gathered, lat)  # one RCCL all-gather of the final packed latents
@@ -206,15 +235,21 @@ def main():
             "value": images_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_pass, "ms_per_denoise_step": ms_pass / N, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random MLLM hidden states, seeded noise)",
-            "config": {"workload": "BASELINE configs[1]: QwenVL2.5-3B conditioning (C=37,H=2048,S_txt=512) -> projector -> "
-                                   "shuttle-3/FLUX-schnell DiT %dx%d, %d steps" % (args.size, args.size, N),
+            "config": {"workload": "BASELINE configs[%d]: %s conditioning (C=%d,H=%d,S_txt=512) -> projector -> %s DiT %dx%d, %d steps"
+                                   % (args.config - 1, kind, C, Hm,
+                                      "FLUX.1-dev + 19 ControlNeXt (LightControl)" if args.config == 5 else "shuttle-3/FLUX-schnell",
+                                      args.size, args.size, N),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "batch-sharded x%d" % world,
                        "graph": not args.no_graph},
             "model_tflops_per_gpu": fl * N / (ms_pass * 1e-3) / 1e12,
             "model_frac_of_bf16_peak": fl * N / (ms_pass * 1e-3) / PEAK_BF16,
         }
+        if args.config == 5:
+            line["metric"] = "images/sec, LightControl FLUX.1-dev 1024x1024 %d-step (projector + denoise loop), whole job" % N
+            line["model_tflops_per_gpu"] = (fl + 8.30e12 * B) * N / (ms_pass * 1e-3) / 1e12  # + 19 x 436.8 GFLOP per image-step
+            line["model_frac_of_bf16_peak"] = line["model_tflops_per_gpu"] * 1e12 / PEAK_BF16
         line["roofline"] = gemm_roofline(B)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
