@@ -251,3 +251,25 @@ def test_errors_are_reported_not_fatal(ops):
                       torch.zeros(8, device=DEV, dtype=torch.bfloat16), 1, 1, 100, 100, 128, 0, 1.0)  # Spad % 128 != 0
     with pytest.raises(X2IError):
         ops.gemm(torch.zeros((4, 8)), torch.zeros((4, 8)))  # CPU tensors: no fallback
+
+
+def test_gemm_tile_quantisation_split_is_bit_identical(ops, monkeypatch):
+    """M=4x1152 rows, N=3072 -> 4*5*12 = 240 + ... the launcher peels the trailing rows of each batch item into a second
+    (128x128-tile) launch; both kernels accumulate in the same order, so the result must equal the unsplit launch."""
+    B, S, N, K = 4, 4608, 3072, 256
+    A = torch.randn((B, S, K), device=DEV).bfloat16()
+    W, b = (torch.randn((N, K), device=DEV) * 0.05).bfloat16(), torch.randn(N, device=DEV).bfloat16()
+    X = torch.randn((B, S, N), device=DEV).bfloat16()
+    gate = torch.randn((B, N), device=DEV)
+
+    def run():
+        out = X.clone()
+        ops.gemm(A, W, b, out=out, M=S, batch=B, a_batch_stride=S * K, lda=K, c_batch_stride=S * N, ldc=N, res=out,
+                 res_batch_stride=S * N, ldr=N, gate=gate, gate_batch_stride=N)
+        return out
+    split = run()                      # 864 tiles -> 768 in the 256-kernel + trailing 512 rows per batch item in the 128-kernel
+    monkeypatch.setenv("X2I_GEMM_NOSPLIT", "1")
+    whole = run()
+    assert torch.equal(split, whole)
+    ref = X[1].float() + gate[1] * F.linear(A[1].float(), W.float(), b.float())
+    assert rel_l2(split[1], ref.cpu()) < 1e-2

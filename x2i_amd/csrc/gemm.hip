@@ -111,10 +111,10 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
           if (full) {
             if constexpr (RES) {
               const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
-              v[0] = __uint_as_float(r2.x << 16) + gv[0] * v[0];
-              v[1] = __uint_as_float(r2.x & 0xffff0000u) + gv[1] * v[1];
-              v[2] = __uint_as_float(r2.y << 16) + gv[2] * v[2];
-              v[3] = __uint_as_float(r2.y & 0xffff0000u) + gv[3] * v[3];
+              v[0] = fmaf(gv[0], v[0], __uint_as_float(r2.x << 16));
+              v[1] = fmaf(gv[1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+              v[2] = fmaf(gv[2], v[2], __uint_as_float(r2.y << 16));
+              v[3] = fmaf(gv[3], v[3], __uint_as_float(r2.y & 0xffff0000u));
             }
             if constexpr (OUTF32) {
               *(f32x4_t*)((float*)p.C + coff) = (f32x4_t){v[0], v[1], v[2], v[3]};
@@ -130,7 +130,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
             for (int r = 0; r < 4; ++r) {
               if (n + r < p.N) {
                 float x = v[r];
-                if constexpr (RES) x = bf16_to_f32(rz[(long long)m * p.ldr + n + r]) + gv[r] * x;
+                if constexpr (RES) x = fmaf(gv[r], x, bf16_to_f32(rz[(long long)m * p.ldr + n + r]));
                 if constexpr (OUTF32) ((float*)p.C)[coff + r] = x;
                 else ((bf16_t*)p.C)[coff + r] = f32_to_bf16(x);
                 if constexpr (HASC2) p.C2[coff + r] = f32_to_bf16(apply_act(x, p.act2));
@@ -315,10 +315,10 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
           const int m = m_wave + mrel;
           if (m < p.M && n + 3 < p.N) {
             const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
-            v[0] = __uint_as_float(r2.x << 16) + gv[0] * v[0];
-            v[1] = __uint_as_float(r2.x & 0xffff0000u) + gv[1] * v[1];
-            v[2] = __uint_as_float(r2.y << 16) + gv[2] * v[2];
-            v[3] = __uint_as_float(r2.y & 0xffff0000u) + gv[3] * v[3];
+            v[0] = fmaf(gv[0], v[0], __uint_as_float(r2.x << 16));
+            v[1] = fmaf(gv[1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+            v[2] = fmaf(gv[2], v[2], __uint_as_float(r2.y << 16));
+            v[3] = fmaf(gv[3], v[3], __uint_as_float(r2.y & 0xffff0000u));
           }
         }
         if (pass == 1) {
@@ -554,7 +554,7 @@ __global__ void gemm_naive_kernel(GemmP p) {
   v = apply_act(v, p.act);
   if (p.res) {
     const float g = p.gate ? p.gate[(long long)z * p.gate_bs + n] : 1.f;
-    v = bf16_to_f32(p.res[(long long)z * p.r_bs + (long long)m * p.ldr + n]) + g * v;
+    v = fmaf(g, v, bf16_to_f32(p.res[(long long)z * p.r_bs + (long long)m * p.ldr + n]));  // one rounding, as in the MFMA kernels
   }
   const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
   if (p.out_f32) ((float*)p.C)[coff] = v;
@@ -638,11 +638,37 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
   if (force == 128) use256 = false;
   if (force == 256) use256 = true;
   if (fast && kern && use256) {
-    p.tilesM = (a->M + BM2 - 1) / BM2; p.tilesN = (a->N + BN2 - 1) / BN2;
     hipError_t e = hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    dim3 grid(p.tilesM * p.tilesN, a->batch);
-    hipLaunchKernelGGL(kern2, grid, dim3(512), SMEM2_BYTES, stream, p);
+    // Tile-quantisation fix: with one 256x256 workgroup per CU the launch runs in rounds of 256 tiles; a last round that
+    // is less than ~60% full wastes the machine (e.g. M=4x4608, N=3072: 864 tiles = 3.375 rounds).  Peel the trailing
+    // rows of every batch item off into a second launch of the 128x128 kernel (2 workgroups per CU, 4x smaller tiles)
+    // that fills in behind the last full round.
+    const int tm_all = (a->M + BM2 - 1) / BM2, tn = (a->N + BN2 - 1) / BN2;
+    const long long per_row = (long long)tn * a->batch;
+    const long long full_rounds = tiles256 / 256, rem = tiles256 % 256;
+    int tm_main = tm_all;
+    if (force == 0 && full_rounds >= 1 && rem > 0 && rem <= 160 && !getenv("X2I_GEMM_NOSPLIT")) {
+      const long long tm_fit = (full_rounds * 256) / per_row;
+      if (tm_fit >= 1 && tm_fit < tm_all) tm_main = (int)tm_fit;
+    }
+    GemmP pm = p;
+    pm.M = (tm_main < tm_all) ? tm_main * BM2 : a->M;
+    pm.tilesM = tm_main; pm.tilesN = tn;
+    hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(512), SMEM2_BYTES, stream, pm);
+    if (tm_main < tm_all) {
+      e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+      if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      GemmP pt = p;
+      const long long r0 = (long long)tm_main * BM2;
+      pt.A = p.A + r0 * p.lda;
+      pt.C = p.out_f32 ? (void*)((float*)p.C + r0 * p.ldc) : (void*)((bf16_t*)p.C + r0 * p.ldc);
+      if (p.C2) pt.C2 = p.C2 + r0 * p.ldc;
+      if (p.res) pt.res = p.res + r0 * p.ldr;
+      pt.M = a->M - (int)r0;
+      pt.tilesM = (pt.M + BM - 1) / BM; pt.tilesN = (a->N + BN - 1) / BN;
+      hipLaunchKernelGGL(kern, dim3(pt.tilesM * pt.tilesN, a->batch), dim3(256), 4 * TILE_BYTES, stream, pt);
+    }
   } else if (fast && kern) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
