@@ -40,7 +40,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NW, int THR>
+// ABL (measurement only, wrong results; tools/microbench.py): 1 = no softmax VALU, 2 = no barrier/wait after the first
+// tile, 4 = no DMA after the first tile.  ABL = 0 is the product kernel.
+template <int NW, int THR, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S,
                                                            int Spad, int ldo, long long o_bs, float scale_log2) {
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) stage(buf ^ 1, (t + 1) * KVB);
+    if (t + 1 < ntiles && !((ABL & 4) && t > 0)) stage(buf ^ 1, (t + 1) * KVB);
     const char* kb = smem + buf * (KTILE + VTILE);
     const char* vb = kb + KTILE;
 
@@ -138,8 +140,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
           if (key >= S) sacc[u][r] = NEG_BIG;
         }
     }
+    if (ABL & 1) {  // ablation: skip the softmax VALU work (keep the data dependence QK -> P -> PV)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) sacc[u][r] = sacc[u][r] * 0.001f;
+    }
     // ---- online softmax (scores scaled into the exp2 domain)
     float mx = NEG_BIG;
+    if (!(ABL & 1)) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -167,6 +176,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
     m_run = m_new;
+    }
 
     // ---- P^T fragments (B operand): sub-tile u, k-step kt uses regs 8kt..8kt+7  (keys u*32+16kt+8hi+0..7)
     bf16x8_t pf[2][2];
@@ -190,8 +200,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u][kt], oacc[db], 0, 0, 0);
         }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA (issued by this wave) has landed
-    __syncthreads();
+    if (!((ABL & 2) && t > 0)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA (issued by this wave) has landed
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (q = li, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
@@ -232,7 +244,22 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     hipLaunchKernelGGL((attn_fwd_kernel<NW_, THR_>), grid, dim3(NW_ * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, \
                        (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);                                   \
   }
-  if (var == 1) X2I_ATTN_LAUNCH(8, 8)
+  const char* ab = getenv("X2I_ATTN_ABLATE");
+  const int abl = ab ? atoi(ab) : 0;
+#define X2I_ATTN_LAUNCH_ABL(A_)                                                                                              \
+  {                                                                                                                          \
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4, 8, A_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                       (int)shm);                                                                            \
+    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));                           \
+    dim3 grid((S + 127) / 128, H, B);                                                                                        \
+    hipLaunchKernelGGL((attn_fwd_kernel<4, 8, A_>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);                                    \
+  }
+  if (abl == 1) X2I_ATTN_LAUNCH_ABL(1)
+  else if (abl == 2) X2I_ATTN_LAUNCH_ABL(2)
+  else if (abl == 4) X2I_ATTN_LAUNCH_ABL(4)
+  else if (abl == 7) X2I_ATTN_LAUNCH_ABL(7)
+  else if (var == 1) X2I_ATTN_LAUNCH(8, 8)
   else if (var == 2) X2I_ATTN_LAUNCH(4, 0)
   else if (var == 3) X2I_ATTN_LAUNCH(8, 0)
   else X2I_ATTN_LAUNCH(4, 8)
