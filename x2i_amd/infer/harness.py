@@ -84,26 +84,28 @@ def strip_module_prefix(state_dict):
 
 
 def load_projector(kind, path=None, device="cuda", seed=0):
+    """Factory per MLLM size; with a checkpoint path the constructor arguments come from the file itself (flat .bin with
+    optional "module." prefix, or the ComfyUI {"config","state_dict"} packaging) and are checked against `kind`."""
     make, C, kw = PROJECTORS[kind]
-    proj = make(in_channels=C, device=device, **kw)
     if path is None:
-        proj.init_random_(seed)
-    else:
-        sd = torch.load(path, map_location="cpu")
-        if "state_dict" in sd and "config" in sd:  # ComfyUI packaging (x2i_comfyui/model.py:33-39)
-            sd = sd["state_dict"]
-        proj.load_state_dict({k: v.to(torch.bfloat16) for k, v in strip_module_prefix(sd).items()}, strict=True)
-    return proj.eval()
+        return make(in_channels=C, device=device, **kw).init_random_(seed).eval()
+    from ..checkpoints import load_projector_checkpoint
+    proj = load_projector_checkpoint(path, device)
+    got_c = proj.cha_scale.shape[1] if proj.use_scale else proj.conv.weight.shape[1]
+    if got_c != C or proj.mlp.layernorm.weight.shape[0] != HIDDEN[kind]:
+        raise ValueError("projector checkpoint %s (C=%d, H=%d) does not match --%s (C=%d, H=%d)"
+                         % (path, got_c, proj.mlp.layernorm.weight.shape[0], kind, C, HIDDEN[kind]))
+    return proj
 
 
 def load_pipeline(flux_path, device="cuda", synthetic=False, seed=0):
-    """FluxPipeline without text encoders / VAE, as infer/inference_qwenvl.py:72-73 builds it."""
+    """FluxPipeline without text encoders / VAE, as infer/inference_qwenvl.py:72-73 builds it; the scheduler constants are
+    read from the checkpoint's scheduler_config.json, never hard-coded."""
     if synthetic:
         tr = FluxTransformer2DModel(device=device).init_random_(seed)
         return FluxPipeline(tr, FlowMatchEulerDiscreteScheduler())
-    tr = FluxTransformer2DModel.from_pretrained(flux_path, subfolder="transformer", device=device)
-    with open(os.path.join(flux_path, "scheduler", "scheduler_config.json")) as fh:
-        sched = FlowMatchEulerDiscreteScheduler.from_config(json.load(fh))  # never hard-coded: SURVEY.md Appendix E
+    from ..checkpoints import load_pipeline_dir
+    tr, sched = load_pipeline_dir(flux_path, device)
     return FluxPipeline(tr, sched)
 
 
