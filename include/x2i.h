@@ -63,6 +63,7 @@ typedef struct x2i_gemm_args {
   const float* gate; int64_t gate_batch_stride;
   const void* res; int64_t res_batch_stride; int32_t ldr;
   const float* bias2; int64_t bias2_batch_stride; /* optional f32 [batch][N] added before act (time-embedding bias) */
+  int64_t w_batch_stride;                            /* 0 = one W for every batch item (nn.Linear); else W[z] = W + z*stride (q k^T) */
   int32_t M, N, K, batch;
   int32_t act; int32_t out_f32;
 } x2i_gemm_args;
@@ -77,6 +78,7 @@ int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
  * descriptor's out-of-range rule.  The 3-channel stem conv has its own entry point below. */
 typedef struct x2i_conv_desc {
   int32_t H, W, Cin, KH, KW, stride, pad;
+  int32_t up; /* 1: F.interpolate(scale_factor=2, mode="nearest") fused in front of the conv (diffusers Upsample2D) */
 } x2i_conv_desc;
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
 
@@ -150,6 +152,10 @@ int x2i_proj_layer_mean_bf16(const void* x, const float* scale, void* y, int32_t
                              x2i_stream_t stream);
 /* torch.mean(x1, 1): x f32 [B,S,N] -> y f32 [B,N] (utils/proj.py:32) */
 int x2i_seq_mean_f32(const float* x, float* y, int32_t B, int32_t S, int32_t N, x2i_stream_t stream);
+
+/* In-place row softmax, bf16 [rows][cols]: x <- softmax(scale * x) with fp32 statistics (the single-head mid-block attention
+ * of the VAE decoder, diffusers Attention/AttnProcessor2_0 on [B, HW, 512]). cols % 8 == 0. */
+int x2i_softmax_rows_bf16(void* x, int64_t rows, int32_t cols, float scale, x2i_stream_t stream);
 
 /* dtype casts used at the boundary */
 int x2i_cast_f32_to_bf16(const float* x, void* y, int64_t n, x2i_stream_t stream);

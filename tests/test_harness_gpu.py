@@ -18,3 +18,13 @@ def test_qwenvl_harness_synthetic(tmp_path):
     lat = torch.load(files[0])
     assert lat.shape == (2, 256, 64) and lat.dtype == torch.bfloat16 and torch.isfinite(lat.float()).all()
     assert lat.float().std() > 0.1
+
+
+def test_qwenvl_harness_synthetic_with_vae_decode(tmp_path):
+    from x2i_amd.infer import inference_qwenvl
+    inference_qwenvl.main(["--synthetic", "--decode", "--qwen_size", "7b", "--task", "video2image", "--height", "256", "--width", "256",
+                           "--outputs", str(tmp_path), "--num_steps", "2"])
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "video2image", "*.jpg")))
+    assert len(files) == 2
+    from PIL import Image
+    assert Image.open(files[0]).size == (256, 256)

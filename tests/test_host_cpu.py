@@ -114,3 +114,22 @@ def test_scheduler_step_fp32_path_on_cpu():
     x, e = torch.randn(2, 8, 4), torch.randn(2, 8, 4)
     y = s.step(e, s.timesteps[0], x)[0]
     assert torch.allclose(y, x - 0.25 * e)
+
+
+def test_vae_decoder_parameter_tree_and_oracle_known_answers():
+    """N1 (parity unpinned: diffusers absent).  Key/shape table == oracle table; FLUX decoder has 49.5 M parameters; a zero
+    conv_out weight turns the decoder into its bias image; nearest upsampling makes a constant latent decode to a constant."""
+    import math
+    from oracle import vae as OV
+    from x2i_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(device="meta")
+    want = OV.vae_decoder_param_shapes()
+    assert {k: tuple(v.shape) for k, v in vae.state_dict().items()} == {k: tuple(v) for k, v in want.items()}
+    assert abs(sum(math.prod(s) for s in want.values()) / 1e6 - 49.545) < 0.01
+    assert 2 ** len(vae.config.block_out_channels) == 16  # vae_scale_factor the reference derives (infer/inference_qwenvl.py:209)
+    cfg = dict(OV.FLUX_VAE_CFG, block_out_channels=(32, 32, 64, 64), norm_num_groups=8)
+    sd = OV.random_vae_decoder_state_dict(cfg, seed=0)
+    sd["decoder.conv_out.weight"].zero_()
+    y = OV.vae_decode(sd, torch.randn(1, 16, 4, 4), cfg)
+    assert y.shape == (1, 3, 32, 32)
+    assert torch.allclose(y, sd["decoder.conv_out.bias"].view(1, 3, 1, 1).expand_as(y))

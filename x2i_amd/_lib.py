@@ -26,6 +26,7 @@ class GemmArgs(C.Structure):
         ("gate", C.c_void_p), ("gate_batch_stride", C.c_int64),
         ("res", C.c_void_p), ("res_batch_stride", C.c_int64), ("ldr", C.c_int32),
         ("bias2", C.c_void_p), ("bias2_batch_stride", C.c_int64),
+        ("w_batch_stride", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("act", C.c_int32), ("out_f32", C.c_int32),
     ]
@@ -33,7 +34,7 @@ class GemmArgs(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
-                ("stride", C.c_int32), ("pad", C.c_int32)]
+                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32)]
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -54,6 +55,7 @@ SIGNATURES = {
     "x2i_proj_conv5x5_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_proj_layer_mean_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _vp],
     "x2i_seq_mean_f32": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "x2i_softmax_rows_bf16": [_vp, _i64, _i32, _f32, _vp],
     "x2i_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "x2i_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
 }

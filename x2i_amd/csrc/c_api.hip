@@ -96,6 +96,10 @@ int x2i_seq_mean_f32(const float* x, float* y, int32_t B, int32_t S, int32_t N, 
   return x2i_launch_seq_mean(x, y, B, S, N, (hipStream_t)stream);
 }
 
+int x2i_softmax_rows_bf16(void* x, int64_t rows, int32_t cols, float scale, x2i_stream_t stream) {
+  return x2i_launch_softmax_rows(x, rows, cols, scale, (hipStream_t)stream);
+}
+
 int x2i_cast_f32_to_bf16(const float* x, void* y, int64_t n, x2i_stream_t stream) {
   return x2i_launch_cast_f32_bf16(x, y, n, (hipStream_t)stream);
 }

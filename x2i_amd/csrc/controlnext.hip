@@ -58,14 +58,15 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const bf16_t* __restrict
   *(bf16x8_t*)(yp + 8) = hi.v;
 }
 
-// grid (GN_SLABS, B); each thread owns one 8-channel chunk position (tid % (C/8)) and strides over pixels, so its partial
-// sums belong to a single group; block reduces per group through LDS.  partial layout: [B][GN_SLABS][G][2]
+// grid (GN_SLABS, B); each thread owns one 8-channel chunk position (tid % (C/8)) and strides over pixels.  A chunk lies in
+// one group (channels per group a multiple of 8) or spans exactly two (channels per group == 4, the VAE's GroupNorm(32, 128)):
+// two partial-sum pairs per thread cover both cases.  partial layout: [B][GN_SLABS][G][2]
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, const float* __restrict__ pre_add,
                                                          float* __restrict__ partial, long long HW, int C, int G) {
-  __shared__ float red[256][2];
+  __shared__ float red[256][4];
   const int b = blockIdx.y, slab = blockIdx.x;
   const int cpp = C / 8;                   // chunks per pixel
-  const int ppi = 256 / cpp;               // pixels per block iteration (C/8 divides 256 for C in {64,128,256})
+  const int ppi = 256 / cpp;               // pixels per block iteration
   const int chunk = threadIdx.x % cpp, psub = threadIdx.x / cpp;
   const long long per = (HW + GN_SLABS - 1) / GN_SLABS;
   const long long p0 = (long long)slab * per, p1 = min(HW, p0 + per);
@@ -74,28 +75,37 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) add[j] = pre_add[(long long)b * C + chunk * 8 + j];
   }
-  float s = 0.f, ss = 0.f;
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // first / second half of the chunk
   const bf16_t* xb = x + (long long)b * HW * C;
   for (long long pbase = p0 + psub; pbase < p1; pbase += ppi) {
     const bf16x8_t v = *(const bf16x8_t*)(xb + pbase * C + chunk * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const float f = bf16_to_f32((bf16_t)v[j]) + add[j];
-      s += f;
-      ss += f * f;
+      s0 += f;
+      q0 += f * f;
+      const float g = bf16_to_f32((bf16_t)v[j + 4]) + add[j + 4];
+      s1 += g;
+      q1 += g * g;
     }
   }
-  red[threadIdx.x][0] = s;
-  red[threadIdx.x][1] = ss;
+  red[threadIdx.x][0] = s0;
+  red[threadIdx.x][1] = q0;
+  red[threadIdx.x][2] = s1;
+  red[threadIdx.x][3] = q1;
   __syncthreads();
-  // thread g < G sums the threads whose chunk lies in group g
   if (threadIdx.x < G) {
-    const int cpg = cpp / G;  // chunks per group
+    const int cpg = C / G;  // channels per group: 4 or a multiple of 8
     float a = 0.f, bq = 0.f;
     for (int t = 0; t < 256; ++t) {
-      if ((t % cpp) / cpg == (int)threadIdx.x) {
+      const int c0 = (t % cpp) * 8;
+      if (c0 / cpg == (int)threadIdx.x) {
         a += red[t][0];
         bq += red[t][1];
+      }
+      if ((c0 + 4) / cpg == (int)threadIdx.x) {
+        a += red[t][2];
+        bq += red[t][3];
       }
     }
     float* o = partial + (((long long)b * GN_SLABS + slab) * G + threadIdx.x) * 2;
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     rstd_s[threadIdx.x] = rsqrtf(var + eps);
   }
   __syncthreads();
-  const int cpp = C / 8;
+  const int cpp = C / 8, cpg = C / G;
   const long long total = HW * cpp;
   const bf16_t* xb = x + (long long)b * HW * C;
   bf16_t* yb = y + (long long)b * HW * C;
@@ -132,23 +142,80 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int chunk = (int)(i % cpp);
     const int c0 = chunk * 8;
-    const int g = c0 / (C / G);
-    const float m = mean_s[g], r = rstd_s[g];
+    const int g0 = c0 / cpg, g1 = (c0 + 4) / cpg;
+    const float m0 = mean_s[g0], r0 = rstd_s[g0], m1 = mean_s[g1], r1 = rstd_s[g1];
     const bf16x8_t v = *(const bf16x8_t*)(xb + i * 8);
     const bf16x8_t wv = *(const bf16x8_t*)(w + c0), bv = *(const bf16x8_t*)(bias + c0);
     bf16x8_t pa = {0, 0, 0, 0, 0, 0, 0, 0};
     if (ab) pa = *(const bf16x8_t*)(ab + i * 8);
-    bf16x8_t o;
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = bf16_to_f32((bf16_t)v[j]);
       if (pre_add) f += pre_add[(long long)b * C + c0 + j];
-      f = (f - m) * r * bf16_to_f32((bf16_t)wv[j]) + bf16_to_f32((bf16_t)bv[j]);
+      f = (f - (j < 4 ? m0 : m1)) * (j < 4 ? r0 : r1) * bf16_to_f32((bf16_t)wv[j]) + bf16_to_f32((bf16_t)bv[j]);
       f = apply_act(f, act);
       if (ab) f += bf16_to_f32((bf16_t)pa[j]);
-      o[j] = (short)f32_to_bf16(f);
+      o[j] = f;
     }
-    *(bf16x8_t*)(yb + i * 8) = o;
+    union { bf16x8_t v8; uint32_t u[4]; } r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.u[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+    *(bf16x8_t*)(yb + i * 8) = r.v8;
+  }
+}
+
+// In-place row softmax over bf16 rows (<= 16384 columns live in registers: 256 threads x 8 chunks x 8 values).
+constexpr int SM_MAXC = 8;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, int cols, float scale_log2) {
+  __shared__ float red[4];
+  bf16_t* row = x + (long long)blockIdx.x * cols;
+  const int nchunk = cols >> 3;
+  float v[SM_MAXC][8];
+  float mx = -1.0e30f;
+#pragma unroll
+  for (int c = 0; c < SM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const bf16x8_t t = *(const bf16x8_t*)(row + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = bf16_to_f32((bf16_t)t[j]) * scale_log2;
+        mx = fmaxf(mx, v[c][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < SM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = __builtin_amdgcn_exp2f(v[c][j] - mx);
+        sum += v[c][j];
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int c = 0; c < SM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      union { bf16x8_t v8; uint32_t u[4]; } r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r.u[j] = pack_bf16x2(v[c][2 * j] * inv, v[c][2 * j + 1] * inv);
+      *(bf16x8_t*)(row + ch * 8) = r.v8;
+    }
   }
 }
 
@@ -169,8 +236,8 @@ long long x2i_groupnorm_scratch(int B, int G) { return (long long)B * GN_SLABS *
 int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
                          const float* pre_add, const void* post_add, float* partial, hipStream_t stream) {
   if (!x || !y || !w || !b || !partial) return x2i_set_error(X2I_ERR_ARG, "groupnorm: null pointer");
-  if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || G <= 0 || G > 32 || (C / 8) % G)
-    return x2i_set_error(X2I_ERR_SHAPE, "groupnorm: unsupported C=%d G=%d (need C/8 | 256 and G | C/8)", C, G);
+  if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || G <= 0 || G > 32 || C % G || !((C / G) % 8 == 0 || (C / G) == 4))
+    return x2i_set_error(X2I_ERR_SHAPE, "groupnorm: unsupported C=%d G=%d (need C/8 | 256 and C/G == 4 or a multiple of 8)", C, G);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SLABS, B), dim3(256), 0, stream, (const bf16_t*)x, pre_add, partial, HW, C, G);
   int rc = x2i_check_launch("groupnorm_partial");
   if (rc) return rc;
@@ -180,4 +247,12 @@ int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,
                      (const bf16_t*)w, (const bf16_t*)b, eps, act, pre_add, (const bf16_t*)post_add, partial);
   return x2i_check_launch("groupnorm_apply");
+}
+
+int x2i_launch_softmax_rows(void* x, long long rows, int cols, float scale, hipStream_t stream) {
+  if (!x || rows <= 0 || cols <= 0) return x2i_set_error(X2I_ERR_ARG, "softmax_rows: bad argument");
+  if (cols % 8 || cols > 256 * 8 * SM_MAXC) return x2i_set_error(X2I_ERR_SHAPE, "softmax_rows: cols=%d must be a multiple of 8 and <= %d", cols, 256 * 8 * SM_MAXC);
+  if (rows > 0x7fffffffLL) return x2i_set_error(X2I_ERR_SHAPE, "softmax_rows: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (bf16_t*)x, cols, scale * 1.4426950408889634f);
+  return x2i_check_launch("softmax_rows");
 }

@@ -28,7 +28,7 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 struct GemmP {
   const bf16_t* A; long long a_bs; int lda;
-  const bf16_t* W; int ldw;
+  const bf16_t* W; int ldw; long long w_bs;
   const bf16_t* bias;
   void* C; long long c_bs; int ldc;
   bf16_t* C2; int act2;
@@ -39,7 +39,7 @@ struct GemmP {
   int act, out_f32;
   int tilesM, tilesN;
   // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
-  int cH, cW, cCin, cOW, cKW, cStride, cPad;
+  int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
 };
 
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
                                 : (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)z * p.w_bs), 0, w_bytes, 0x00020000);
 
   // per-thread source offsets of its 4 chunks per operand tile (row r, physical chunk c holds logical chunk c^swz)
   uint32_t a_voff[4], w_voff[4];
@@ -207,9 +207,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     const int ky = tap / p.cKW, kx = tap - ky * p.cKW;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      // coordinates on the (optionally x2 nearest-upsampled) input grid; source pixel = coordinate >> cUp
       const int iy = c_oy[j] * p.cStride + ky - p.cPad, ix = c_ox[j] * p.cStride + kx - p.cPad;
-      const bool ok = (iy >= 0) && (iy < p.cH) && (ix >= 0) && (ix < p.cW);
-      a_voff[j] = ok ? (uint32_t)((((long long)iy * p.cW + ix) * p.cCin + c0 + c_cl[j]) * 2) : 0x80000000u;
+      const bool ok = (iy >= 0) && (iy < (p.cH << p.cUp)) && (ix >= 0) && (ix < (p.cW << p.cUp));
+      a_voff[j] = ok ? (uint32_t)((((long long)(iy >> p.cUp) * p.cW + (ix >> p.cUp)) * p.cCin + c0 + c_cl[j]) * 2) : 0x80000000u;
     }
   };
   if (CONV) conv_offsets(0);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
   const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)z * p.w_bs), 0, w_bytes, 0x00020000);
 
   uint32_t a_voff[2], w_voff[2];
 #pragma unroll
@@ -547,7 +548,7 @@ __global__ void gemm_naive_kernel(GemmP p) {
   const int z = blockIdx.z;
   if (n >= p.N || m >= p.M) return;
   const bf16_t* a = p.A + (long long)z * p.a_bs + (long long)m * p.lda;
-  const bf16_t* w = p.W + (long long)n * p.ldw;
+  const bf16_t* w = p.W + (long long)z * p.w_bs + (long long)n * p.ldw;
   float acc = 0.f;
   for (int k = 0; k < p.K; ++k) acc = fmaf(bf16_to_f32(a[k]), bf16_to_f32(w[k]), acc);
   float v = acc + (p.bias ? bf16_to_f32(p.bias[n]) : 0.f) + (p.bias2 ? p.bias2[(long long)z * p.bias2_bs + n] : 0.f);
@@ -573,7 +574,7 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
   if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
   GemmP p;
   p.A = (const bf16_t*)a->A; p.a_bs = a->a_batch_stride; p.lda = a->lda;
-  p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
+  p.W = (const bf16_t*)a->W; p.ldw = a->ldw; p.w_bs = a->w_batch_stride;
   p.bias = (const bf16_t*)a->bias;
   p.C = a->C; p.c_bs = a->c_batch_stride; p.ldc = a->ldc;
   p.C2 = (bf16_t*)a->C2; p.act2 = a->act2;
@@ -581,15 +582,16 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
   if (conv) {
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
-    const int OH = (cd->H + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = (cd->W + 2 * cd->pad - cd->KW) / cd->stride + 1;
+    const int up = cd->up ? 1 : 0;
+    const int OH = ((cd->H << up) + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = ((cd->W << up) + 2 * cd->pad - cd->KW) / cd->stride + 1;
     if (a->M != OH * OW || a->K != cd->KH * cd->KW * cd->Cin)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: M=%d K=%d do not match OH*OW=%d, KH*KW*Cin=%d", a->M, a->K, OH * OW, cd->KH * cd->KW * cd->Cin);
     if ((long long)cd->H * cd->W * cd->Cin * 2 >= 0x7f000000LL) return x2i_set_error(X2I_ERR_SHAPE, "conv: image too large");
-    p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad;
+    p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad; p.cUp = up;
   }
   p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
   const bool fast = (a->K % BK == 0) && (conv || a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) &&

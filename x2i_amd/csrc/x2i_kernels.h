@@ -28,5 +28,6 @@ int x2i_launch_proj_conv5x5(const void* x, const float* w, const float* bias, vo
                             hipStream_t stream);
 int x2i_launch_layer_mean(const void* x, const float* scale, void* y, int B, int C, long long plane, hipStream_t stream);
 int x2i_launch_seq_mean(const float* x, float* y, int B, int S, int N, hipStream_t stream);
+int x2i_launch_softmax_rows(void* x, long long rows, int cols, float scale, hipStream_t stream);
 int x2i_launch_cast_f32_bf16(const float* x, void* y, long long n, hipStream_t stream);
 int x2i_launch_cast_bf16_f32(const void* x, float* y, long long n, hipStream_t stream);

@@ -63,6 +63,7 @@ def build_parser(family):
     p.add_argument("--batch", type=int, default=1, help="prompts per pipeline call (the reference always uses 1)")
     p.add_argument("--synthetic", action="store_true", help="no checkpoints: random weights, synthetic MLLM hidden states")
     p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--decode", action="store_true", help="with --synthetic: also run the (random-weight) VAE decoder and save images")
     return p
 
 
@@ -109,13 +110,12 @@ def load_pipeline(flux_path, device="cuda", synthetic=False, seed=0):
     return FluxPipeline(tr, sched)
 
 
-def load_vae(flux_path, device, dtype=torch.bfloat16):
-    try:
-        from diffusers import AutoencoderKL  # stock PyTorch-ROCm; "next" row N1
-    except ImportError as e:  # pragma: no cover
-        raise RuntimeError("decoding to images needs diffusers' AutoencoderKL (not on the HIP path); "
-                           "run with --synthetic to stop at latents") from e
-    return AutoencoderKL.from_pretrained(flux_path, subfolder="vae", torch_dtype=dtype).to(device)
+def load_vae(flux_path, device, synthetic=False):
+    """VAE decoder on the HIP path (x2i_amd.vae): `vae/` of the diffusers pipeline directory."""
+    from ..vae import AutoencoderKL
+    if synthetic:
+        return AutoencoderKL(device=device).init_random_(3)
+    return AutoencoderKL.from_pretrained(flux_path, subfolder="vae", device=device)
 
 
 class SyntheticConditioner:
@@ -138,7 +138,8 @@ class Harness:
         self.rank, self.world = xdist.init_from_env(device=self.device if self.device.type == "cuda" else None)
         self.proj = load_projector(kind, None if args.synthetic else args.proj_path, device)
         self.pipeline = load_pipeline(args.flux_path, device, args.synthetic)
-        self.vae = None if args.synthetic else load_vae(args.flux_path, device)
+        self.vae = load_vae(args.flux_path, device, synthetic=True) if (args.synthetic and args.decode) else (
+            None if args.synthetic else load_vae(args.flux_path, device))
         self.conditioner = conditioner
         self.outputs = args.outputs or "./outputs_%s" % kind
 

@@ -31,13 +31,13 @@ def pad128(n):
 
 def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=None, c_batch_stride=0, ldc=None,
          act=ACT_NONE, gate=None, gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, out2=None, act2=ACT_NONE,
-         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None, bias2=None, bias2_batch_stride=0):
+         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None, bias2=None, bias2_batch_stride=0, w_batch_stride=0):
     """C = epi(A W^T).  A, out, res may be sub-views addressed as (tensor, element offset, row stride, batch stride)."""
     lib = _lib.load()
     _req(A, torch.bfloat16, "A")
     _req(W, torch.bfloat16, "W")
-    N = W.shape[0] if N is None else N
-    K = W.shape[1] if K is None else K
+    N = W.shape[-2] if N is None else N
+    K = W.shape[-1] if K is None else K
     if M is None:
         M = A.numel() // A.shape[-1]
     lda = A.shape[-1] if lda is None else lda
@@ -52,7 +52,7 @@ def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=No
     a.a_batch_stride = a_batch_stride
     a.lda = lda
     a.W = W.data_ptr()
-    a.ldw = W.stride(0)
+    a.ldw = W.stride(-2)  # row stride of the [.., N, K] weight (a leading batch dimension is addressed by w_batch_stride)
     a.bias = bias.data_ptr() if bias is not None else None
     a.C = out.data_ptr() + c_offset * esz_c
     a.c_batch_stride = c_batch_stride
@@ -66,6 +66,7 @@ def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=No
     a.ldr = (ldc if ldr is None else ldr)
     a.bias2 = bias2.data_ptr() if bias2 is not None else None
     a.bias2_batch_stride = bias2_batch_stride
+    a.w_batch_stride = w_batch_stride
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act = act
     a.out_f32 = 1 if out_f32 else 0
@@ -190,14 +191,15 @@ from ._lib import ACT_RELU, ConvDesc  # noqa: E402
 
 
 def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=None, act=ACT_NONE, bias2=None, res=None,
-                c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None):
+                c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None, up=False):
     """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout]."""
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")
     _req(w_packed, torch.bfloat16, "w")
     B = x.shape[0]
-    OH = (H + 2 * pad - KH) // stride + 1
-    OW = (W + 2 * pad - KW) // stride + 1
+    u = 2 if up else 1  # nearest-neighbour x2 upsampling fused in front of the conv
+    OH = (H * u + 2 * pad - KH) // stride + 1
+    OW = (W * u + 2 * pad - KW) // stride + 1
     if out is None:
         out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=torch.bfloat16)
     a = GemmArgs()
@@ -220,7 +222,8 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     a.M, a.N, a.K, a.batch = OH * OW, Cout, KH * KW * Cin, B
     a.act = act
     a.out_f32 = 0
-    d = ConvDesc(H, W, Cin, KH, KW, stride, pad)
+    a.w_batch_stride = 0
+    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, 1 if up else 0)
     check(lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(d), _stream()), "conv2d_nhwc")
     return out
 
@@ -253,3 +256,12 @@ def groupnorm_nhwc(x, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add
     check(lib.x2i_groupnorm_nhwc_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), eps, act, _p(pre_add), _p(post_add),
                                       _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc")
     return out
+
+
+def softmax_rows_(x, scale=1.0):
+    """In-place softmax(scale * x) over the last dimension of a contiguous bf16 tensor."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    cols = x.shape[-1]
+    check(lib.x2i_softmax_rows_bf16(_p(x), x.numel() // cols, cols, scale, _stream()), "softmax_rows")
+    return x

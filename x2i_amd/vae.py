@@ -1,0 +1,257 @@
+"""FLUX VAE decoder on the HIP path -- the step right after the sampling path:
+`image = vae.decode(latents / scaling_factor + shift_factor, return_dict=False)[0]` (infer/inference_qwenvl.py:213-214).
+
+Interface of diffusers' AutoencoderKL as the reference uses it: `.config.block_out_channels / scaling_factor /
+shift_factor`, `.decode(z, return_dict=False)[0]`, diffusers state-dict keys (`decoder.*`; encoder / quant keys of a
+full checkpoint are ignored).  Activations are NHWC bf16; every conv is the implicit-GEMM MFMA kernel (the x2
+nearest-neighbour upsampling of Upsample2D is fused into the gather), GroupNorm(32)+SiLU and residual adds are fused
+around them, the single-head 512-wide mid-block attention runs as two GEMMs around a row-softmax kernel
+(S = q k^T is materialised: 512 MiB per 1024^2 image, once per image).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_SILU
+
+
+def _p(*shape, device):
+    return nn.Parameter(torch.empty(shape, device=device, dtype=torch.bfloat16), requires_grad=False)
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, device):
+        super().__init__()
+        self.weight = _p(cout, cin, k, k, device=device)
+        self.bias = _p(cout, device=device)
+        self._packed = None
+
+    def packed(self, cin_pad=None, cout_pad=None):
+        """[Cout, ky, kx, Cin] bf16; optionally zero-padded along Cin (16 -> 64) or Cout."""
+        if self._packed is None or self._packed[0].device != self.weight.device:
+            w = self.weight.permute(0, 2, 3, 1)
+            b = self.bias
+            if cin_pad and cin_pad > w.shape[3]:
+                w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[3]))
+            if cout_pad and cout_pad > w.shape[0]:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
+                b = torch.nn.functional.pad(b, (0, cout_pad - b.shape[0]))
+            self._packed = (w.reshape(w.shape[0], -1).contiguous(), b.contiguous())
+        return self._packed
+
+
+class _Vec(nn.Module):
+    def __init__(self, c, device):
+        super().__init__()
+        self.weight = _p(c, device=device)
+        self.bias = _p(c, device=device)
+
+
+class _Lin(nn.Module):
+    def __init__(self, i, o, device):
+        super().__init__()
+        self.weight = _p(o, i, device=device)
+        self.bias = _p(o, device=device)
+
+
+class _Seq(nn.Module):
+    def __init__(self, items):
+        super().__init__()
+        for k, v in items.items():
+            self.add_module(str(k), v)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout, device):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.norm1 = _Vec(cin, device)
+        self.conv1 = _Conv(cin, cout, 3, device)
+        self.norm2 = _Vec(cout, device)
+        self.conv2 = _Conv(cout, cout, 3, device)
+        if cin != cout:
+            self.conv_shortcut = _Conv(cin, cout, 1, device)
+
+    def run(self, x, H, W, G):
+        n = ops.groupnorm_nhwc(x, self.norm1.weight, self.norm1.bias, G, 1e-6, act=ACT_SILU)
+        w, b = self.conv1.packed()
+        h = ops.conv2d_nhwc(n, w, b, H, W, self.cin, self.cout, 3, 3, 1, 1)
+        n = ops.groupnorm_nhwc(h, self.norm2.weight, self.norm2.bias, G, 1e-6, act=ACT_SILU)
+        if hasattr(self, "conv_shortcut"):
+            w, b = self.conv_shortcut.packed()
+            x = ops.conv2d_nhwc(x, w, b, H, W, self.cin, self.cout, 1, 1, 1, 0)
+        w, b = self.conv2.packed()
+        return ops.conv2d_nhwc(n, w, b, H, W, self.cout, self.cout, 3, 3, 1, 1, res=x)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c, device):
+        super().__init__()
+        self.c = c
+        self.group_norm = _Vec(c, device)
+        self.to_q, self.to_k, self.to_v = _Lin(c, c, device), _Lin(c, c, device), _Lin(c, c, device)
+        self.to_out = _Seq({0: _Lin(c, c, device)})
+
+    def run(self, x, H, W, G):
+        B, C, T = x.shape[0], self.c, H * W
+        h = ops.groupnorm_nhwc(x, self.group_norm.weight, self.group_norm.bias, G, 1e-6)  # [B,H,W,C] == [B,T,C]
+        q = ops.gemm(h, self.to_q.weight, self.to_q.bias, M=B * T)
+        k = ops.gemm(h, self.to_k.weight, self.to_k.bias, M=B * T)
+        # V^T[c][t] = sum_j Wv[c][j] h[t][j]  (one GEMM per image with h as the "weight"); the bias of to_v is added after
+        # P V instead: softmax rows sum to one, so P (V + 1 b^T) = P V + b^T
+        vt = torch.empty((B, C, T), device=x.device, dtype=torch.bfloat16)
+        ops.gemm(self.to_v.weight, h, None, out=vt, M=C, N=T, K=C, batch=B, a_batch_stride=0, lda=C, c_batch_stride=C * T, ldc=T,
+                 w_batch_stride=T * C)
+        s = torch.empty((B, T, T), device=x.device, dtype=torch.bfloat16)
+        ops.gemm(q, k, None, out=s, M=T, N=T, K=C, batch=B, a_batch_stride=T * C, lda=C, c_batch_stride=T * T, ldc=T,
+                 w_batch_stride=T * C)
+        ops.softmax_rows_(s, 1.0 / math.sqrt(C))
+        o = torch.empty((B, T, C), device=x.device, dtype=torch.bfloat16)
+        ops.gemm(s, vt, self.to_v.bias, out=o, M=T, N=C, K=T, batch=B, a_batch_stride=T * T, lda=T, c_batch_stride=T * C, ldc=C,
+                 w_batch_stride=C * T)
+        out = torch.empty_like(x)
+        ops.gemm(o, self.to_out[0].weight, self.to_out[0].bias, out=out, M=B * T, res=x, ldr=C)  # + residual
+        return out
+
+
+class _Up(nn.Module):
+    def __init__(self, c, device):
+        super().__init__()
+        self.conv = _Conv(c, c, 3, device)
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, cin, cout, n, upsample, device):
+        super().__init__()
+        self.resnets = _Seq({j: _Res(cin if j == 0 else cout, cout, device) for j in range(n)})
+        if upsample:
+            self.upsamplers = _Seq({0: _Up(cout, device)})
+
+
+class _Mid(nn.Module):
+    def __init__(self, c, device):
+        super().__init__()
+        self.resnets = _Seq({0: _Res(c, c, device), 1: _Res(c, c, device)})
+        self.attentions = _Seq({0: _Attn(c, device)})
+
+
+class _Decoder(nn.Module):
+    def __init__(self, cfg, device):
+        super().__init__()
+        rev = list(reversed(cfg.block_out_channels))
+        self.conv_in = _Conv(cfg.latent_channels, rev[0], 3, device)
+        self.mid_block = _Mid(rev[0], device)
+        blocks, prev = {}, rev[0]
+        for i, co in enumerate(rev):
+            blocks[i] = _UpBlock(prev, co, cfg.layers_per_block + 1, i != len(rev) - 1, device)
+            prev = co
+        self.up_blocks = _Seq(blocks)
+        self.conv_norm_out = _Vec(rev[-1], device)
+        self.conv_out = _Conv(rev[-1], cfg.out_channels, 3, device)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class AutoencoderKL(nn.Module):
+    """Decoder half of diffusers' AutoencoderKL with the FLUX configuration as defaults."""
+
+    def __init__(self, latent_channels=16, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 norm_num_groups=32, scaling_factor=0.3611, shift_factor=0.1159, device="cuda"):
+        super().__init__()
+        self.config = _Cfg(latent_channels=latent_channels, out_channels=out_channels, block_out_channels=tuple(block_out_channels),
+                           layers_per_block=layers_per_block, norm_num_groups=norm_num_groups, scaling_factor=scaling_factor,
+                           shift_factor=shift_factor)
+        if any(c % 64 for c in block_out_channels):
+            raise ValueError("x2i_amd VAE: block_out_channels must be multiples of 64 (implicit-GEMM conv)")
+        self.decoder = _Decoder(self.config, device)
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        for m in self.modules():
+            if isinstance(m, _Conv):
+                m._packed = None
+        return r
+
+    def load_state_dict(self, sd, strict=True):
+        """Accepts a full AutoencoderKL checkpoint: encoder.* / quant_conv.* / post_quant_conv.* keys are ignored."""
+        dec = {k: v for k, v in sd.items() if k.startswith("decoder.")}
+        return super().load_state_dict(dec, strict=strict)
+
+    @torch.no_grad()
+    def decode(self, z, return_dict=True):
+        cfg, d = self.config, self.decoder
+        G = cfg.norm_num_groups
+        B, Cz, H, W = z.shape
+        x = torch.zeros((B, H, W, 64), device=z.device, dtype=torch.bfloat16)  # latent channels zero-padded to one K-step
+        x[..., :Cz] = z.to(torch.bfloat16).permute(0, 2, 3, 1)
+        rev = list(reversed(cfg.block_out_channels))
+        w, b = d.conv_in.packed(cin_pad=64)
+        x = ops.conv2d_nhwc(x, w, b, H, W, 64, rev[0], 3, 3, 1, 1)
+        x = d.mid_block.resnets[0].run(x, H, W, G)
+        x = d.mid_block.attentions[0].run(x, H, W, G)
+        x = d.mid_block.resnets[1].run(x, H, W, G)
+        for i, co in enumerate(rev):
+            blk = d.up_blocks[i]
+            for j in range(len(blk.resnets)):
+                x = blk.resnets[j].run(x, H, W, G)
+            if hasattr(blk, "upsamplers"):
+                w, b = blk.upsamplers[0].conv.packed()
+                x = ops.conv2d_nhwc(x, w, b, H, W, co, co, 3, 3, 1, 1, up=True)  # F.interpolate(nearest, x2) + conv
+                H, W = 2 * H, 2 * W
+        n = ops.groupnorm_nhwc(x, d.conv_norm_out.weight, d.conv_norm_out.bias, G, 1e-6, act=ACT_SILU)
+        w, b = d.conv_out.packed(cout_pad=8)  # 3 -> 8 output channels so that rows are 16-byte aligned
+        y = ops.conv2d_nhwc(n, w, b, H, W, rev[-1], 8, 3, 3, 1, 1)
+        img = y[..., :cfg.out_channels].permute(0, 3, 1, 2).contiguous()
+        if not return_dict:
+            return (img,)
+        return _Cfg(sample=img)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+        """diffusers directory layout: <path>/<subfolder>/config.json + *.safetensors (decoder.* keys are used)."""
+        import glob
+        import json
+        import os
+
+        from safetensors import safe_open
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, "config.json")) as fh:
+            c = json.load(fh)
+        keys = ("latent_channels", "out_channels", "block_out_channels", "layers_per_block", "norm_num_groups", "scaling_factor",
+                "shift_factor")
+        vae = cls(**{k: c[k] for k in keys if k in c}, device=device)
+        own = dict(vae.named_parameters())
+        seen = set()
+        for shard in sorted(glob.glob(os.path.join(d, "*.safetensors"))):
+            with safe_open(shard, framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    if k in own:
+                        own[k].data.copy_(sf.get_tensor(k))
+                        seen.add(k)
+        missing = set(own) - seen
+        if missing:
+            raise KeyError("VAE checkpoint is missing decoder keys: %s ..." % sorted(missing)[:6])
+        return vae.eval()
+
+    @torch.no_grad()
+    def init_random_(self, seed=0):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n, p in self.named_parameters():
+            if p.dim() >= 2:
+                v = torch.randn(p.shape, generator=g) / p[0].numel() ** 0.5
+            elif n.endswith("weight"):
+                v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+            else:
+                v = 0.02 * torch.randn(p.shape, generator=g)
+            p.copy_(v)
+        return self
