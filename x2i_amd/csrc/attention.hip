@@ -45,7 +45,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 template <int NW, int THR, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S,
-                                                           int Spad, int ldo, long long o_bs, float scale_log2) {
+                                                           int Spad, int ldo, long long o_bs, float scale_log2, int nbatch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K 16K | VT 16K]
   constexpr int NT = NW * 64;
   constexpr int CH = 1024 / NT;  // 16-byte chunks per thread per tile (1024 chunks per 16 KiB tile)
@@ -54,8 +54,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;     // which half-wave
   const int li = lane & 31;     // MFMA row/col index owned by this lane
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  // XCD-aware block order (workgroup id % 8 = XCD): each XCD walks a contiguous range of (batch, head, q-tile) triples,
+  // so all query tiles of one head -- which stream the same 2.4 MB of K / V^T -- hit the same 4 MiB L2.
+  const int nqt = gridDim.x / (H * nbatch);
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qt = bid % nqt, h = (bid / nqt) % H, b = bid / (nqt * H);
+  const int q0 = qt * (32 * NW) + wave * 32;
   const long long bh = (long long)b * H + h;
   const bf16_t* Qh = Q + bh * Spad * 128;
   const bf16_t* Kh = K + bh * Spad * 128;
@@ -240,9 +248,9 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, THR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)shm);                                                                           \
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));                          \
-    dim3 grid((S + 32 * NW_ - 1) / (32 * NW_), H, B);                                                                       \
+    dim3 grid(((S + 32 * NW_ - 1) / (32 * NW_)) * H * B);                                                                   \
     hipLaunchKernelGGL((attn_fwd_kernel<NW_, THR_>), grid, dim3(NW_ * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);                                   \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B);                                \
   }
   const char* ab = getenv("X2I_ATTN_ABLATE");
   const int abl = ab ? atoi(ab) : 0;
@@ -251,9 +259,9 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4, 8, A_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                        (int)shm);                                                                            \
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));                           \
-    dim3 grid((S + 127) / 128, H, B);                                                                                        \
+    dim3 grid(((S + 127) / 128) * H * B);                                                                                    \
     hipLaunchKernelGGL((attn_fwd_kernel<4, 8, A_>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2);                                    \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B);                                 \
   }
   if (abl == 1) X2I_ATTN_LAUNCH_ABL(1)
   else if (abl == 2) X2I_ATTN_LAUNCH_ABL(2)
