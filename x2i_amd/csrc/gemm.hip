@@ -143,6 +143,81 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
   });
 }
 
+// LDS-staged epilogue (both tile kernels): every wave parks its finished (MT*16)x64 bf16 sub-tile in a private LDS region
+// (row stride 144 B: 16-byte aligned, spreads the 16 rows of a ds_write_b64 over the banks) and writes it out as whole
+// 128-byte row segments with 16-byte stores -- a wave store instruction covers 8 full cache lines instead of sixteen
+// 32-byte fragments (the direct accumulator layout), which is what the HBM-bound epilogue of the large-N GEMMs needs.
+constexpr int EPI_ROW_BYTES = 144;
+constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // 18 KiB per wave, 144 KiB per workgroup
+
+template <int ACT, bool RES, bool HASC2, int MT>
+__device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc)[MT][4], int z, int m_wave, int n_wave, int lane,
+                                                   char* wave_lds) {
+  const int mlane = lane & 15, ng = lane >> 4;
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+  bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
+  bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
+  constexpr int NPASS = HASC2 ? 2 : 1;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n_wave + j * 16 + ng * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (n + 3 < p.N) {
+        if (p.bias) {
+          const uint2 bb = *(const uint2*)(p.bias + n);
+          bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+          bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
+        }
+        if (b2) {
+          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+          bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
+        }
+      }
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int mrel = i * 16 + mlane;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
+        if constexpr (RES) {
+          const int m = m_wave + mrel;
+          if (m < p.M && n + 3 < p.N) {
+            const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
+            v[0] = fmaf(gv[0], v[0], __uint_as_float(r2.x << 16));
+            v[1] = fmaf(gv[1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+            v[2] = fmaf(gv[2], v[2], __uint_as_float(r2.y << 16));
+            v[3] = fmaf(gv[3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+          }
+        }
+        if (pass == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
+        }
+        *(uint2*)(wave_lds + mrel * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      });
+    });
+    // the region is private to this wave: LDS operations of one wave complete in order, only the data hazard matters
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16_t* dst = (pass == 0) ? Cz : C2z;
+#pragma unroll
+    for (int it = 0; it < MT * 2; ++it) {
+      const int row = it * 8 + (lane >> 3), c = lane & 7;
+      const bf16x8_t d = *(const bf16x8_t*)(wave_lds + row * EPI_ROW_BYTES + c * 16);
+      const int m = m_wave + row, n = n_wave + c * 8;
+      if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
+    }
+    if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // Epilogue variants are compile-time (ACT, RES, OUTF32, HASC2) so that the accumulator array is only ever indexed
 // with constants (a runtime-indexed ext_vector array is demoted to scratch memory by hipcc).
 template <int ACT, bool RES, bool OUTF32, bool HASC2, bool CONV>
@@ -265,82 +340,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     __syncthreads();                                  // ... everyone's has, and everyone is done reading `cur`
   }
 
-  epilogue_store<ACT, RES, OUTF32, HASC2, 4, 4>(p, acc, z, m0 + wm * 64 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
-}
-
-// LDS-staged epilogue of the 256x256 kernel: every wave parks its finished 128x64 bf16 sub-tile in a private LDS region
-// (row stride 144 B: 16-byte aligned, spreads the 16 rows of a ds_write_b64 over the banks) and writes it out as whole
-// 128-byte row segments with 16-byte stores -- a wave store instruction covers 8 full cache lines instead of sixteen
-// 32-byte fragments (the direct accumulator layout), which is what the HBM-bound epilogue of the large-N GEMMs needs.
-constexpr int EPI_ROW_BYTES = 144;
-constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // 18 KiB per wave, 144 KiB per workgroup
-
-template <int ACT, bool RES, bool HASC2>
-__device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc)[8][4], int z, int m_wave, int n_wave, int lane,
-                                                   char* wave_lds) {
-  const int mlane = lane & 15, ng = lane >> 4;
-  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
-  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
-  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
-  bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
-  bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
-  constexpr int NPASS = HASC2 ? 2 : 1;
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
-    static_for<4>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const int n = n_wave + j * 16 + ng * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
-      if (n + 3 < p.N) {
-        if (p.bias) {
-          const uint2 bb = *(const uint2*)(p.bias + n);
-          bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
-          bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
-        }
-        if (gz) {
-          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
-          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
-        }
-        if (b2) {
-          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
-          bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
-        }
-      }
-      static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int mrel = i * 16 + mlane;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
-        if constexpr (RES) {
-          const int m = m_wave + mrel;
-          if (m < p.M && n + 3 < p.N) {
-            const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
-            v[0] = fmaf(gv[0], v[0], __uint_as_float(r2.x << 16));
-            v[1] = fmaf(gv[1], v[1], __uint_as_float(r2.x & 0xffff0000u));
-            v[2] = fmaf(gv[2], v[2], __uint_as_float(r2.y << 16));
-            v[3] = fmaf(gv[3], v[3], __uint_as_float(r2.y & 0xffff0000u));
-          }
-        }
-        if (pass == 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
-        }
-        *(uint2*)(wave_lds + mrel * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-      });
-    });
-    // the region is private to this wave: LDS operations of one wave complete in order, only the data hazard matters
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    bf16_t* dst = (pass == 0) ? Cz : C2z;
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 8 + (lane >> 3), c = lane & 7;
-      const bf16x8_t d = *(const bf16x8_t*)(wave_lds + row * EPI_ROW_BYTES + c * 16);
-      const int m = m_wave + row, n = n_wave + c * 8;
-      if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
+  if constexpr (!OUTF32) {
+    // whole-line stores through LDS (see epilogue_store_lds); needs 16-byte aligned rows and N % 8 == 0
+    if (((p.N | p.ldc) & 7) == 0 && (!RES || (p.ldr & 3) == 0) && ((((uintptr_t)p.C) | ((uintptr_t)p.C2)) & 15) == 0 && (p.c_bs & 7) == 0) {
+      epilogue_store_lds<ACT, RES, HASC2, 4>(p, acc, z, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (EPI_WAVE_BYTES / 2));
+      return;
     }
-    if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  epilogue_store<ACT, RES, OUTF32, HASC2, 4, 4>(p, acc, z, m0 + wm * 64 + (lane & 15), n0 + wn * 64 + (lane >> 4) * 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
     // whole-line stores through LDS need 16-byte aligned rows and N % 8 == 0 (wave-uniform test)
     if (((p.N | p.ldc) & 7) == 0 && (!RES || (p.ldr & 3) == 0) && ((((uintptr_t)p.C) | ((uintptr_t)p.C2)) & 15) == 0 && (p.c_bs & 7) == 0) {
       __syncthreads();  // every wave is done reading the operand ring before it is reused as staging space
-      epilogue_store_lds<ACT, RES, HASC2>(p, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
+      epilogue_store_lds<ACT, RES, HASC2, 8>(p, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
       return;
     }
   }
