@@ -14,7 +14,7 @@
 //     row-major images filled by LDS-DMA (global_load_lds dwordx4); bank conflicts are removed with an XOR swizzle
 //     applied on the DMA source address and on the ds_read_b128 address (CDNA guide rule 21)
 //   * double-buffered tiles: DMA of tile t+1 overlaps the 32 MFMAs of tile t; one barrier per tile
-//   * O^T accumulates in 4 x f32x16; epilogue normalises by 1/l and writes token-major bf16 (8-byte stores)
+//   * O^T accumulates in 4 x f32x16; epilogue normalises by 1/l and writes token-major bf16 (16-byte stores after a half-wave exchange)
 #include "x2i_common.h"
 #include "x2i_kernels.h"
 #include <stdlib.h>
@@ -218,8 +218,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   l_run = xhalf_sum(l_run);
   const float inv = 1.f / l_run;
   const int q = q0 + li;
-  if (q < S) {
-    bf16_t* orow = O + (long long)b * o_bs + (long long)q * ldo + h * 128;
+  bf16_t* orow = O + (long long)b * o_bs + (long long)q * ldo + h * 128;
+  if ((((uintptr_t)O) & 15) == 0 && (ldo & 7) == 0 && (o_bs & 7) == 0) {
+    // half-wave exchange (v_permlane32_swap) turns two 8-byte fragments of neighbouring d-groups into one 16-byte
+    // store per lane: lanes 0-31 end up with d = 8g..8g+7, lanes 32-63 with d = 8(g+1)..8(g+1)+7
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const uint32_t a0 = pack_bf16x2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv);
+        const uint32_t a1 = pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        const uint32_t b0 = pack_bf16x2(oacc[db][4 * g + 4] * inv, oacc[db][4 * g + 5] * inv);
+        const uint32_t b1 = pack_bf16x2(oacc[db][4 * g + 6] * inv, oacc[db][4 * g + 7] * inv);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        if (q < S) *(uint4*)(orow + db * 32 + 8 * (g + hi)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+  } else if (q < S) {
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
