@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int GN_SLABS = 128;  // partial-sum slabs per sample
+constexpr int GN_SLABS = 256;  // partial-sum slabs per sample
 
 // one thread = one output pixel x 16 output channels
 __global__ __launch_bounds__(256) void conv_stem_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const bf16_t* __restrict
   *(bf16x8_t*)(yp + 8) = hi.v;
 }
 
-// grid (GN_SLABS, B); each thread owns one 8-channel chunk position (tid % (C/8)) and strides over pixels.  A chunk lies in
-// one group (channels per group a multiple of 8) or spans exactly two (channels per group == 4, the VAE's GroupNorm(32, 128)):
-// two partial-sum pairs per thread cover both cases.  partial layout: [B][GN_SLABS][G][2]
+// grid (GN_SLABS, B); each thread owns one 8-channel chunk position (tid % (C/8)) and strides over pixels, four 16-byte
+// loads in flight.  A chunk lies in one group (channels per group a multiple of 8) or spans exactly two (channels per group
+// == 4, the VAE's GroupNorm(32, 128)): two partial-sum pairs per thread cover both cases.
+// scratch layout: stats [B][G][2] (mean, rstd) followed by partial sums [B][GN_SLABS][G][2]
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, const float* __restrict__ pre_add,
                                                          float* __restrict__ partial, long long HW, int C, int G) {
   __shared__ float red[256][4];
@@ -76,17 +77,27 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     for (int j = 0; j < 8; ++j) add[j] = pre_add[(long long)b * C + chunk * 8 + j];
   }
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // first / second half of the chunk
-  const bf16_t* xb = x + (long long)b * HW * C;
-  for (long long pbase = p0 + psub; pbase < p1; pbase += ppi) {
-    const bf16x8_t v = *(const bf16x8_t*)(xb + pbase * C + chunk * 8);
+  const bf16_t* xb = x + (long long)b * HW * C + chunk * 8;
+  for (long long pbase = p0 + psub; pbase < p1; pbase += 4 * ppi) {
+    bf16x8_t v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float f = bf16_to_f32((bf16_t)v[j]) + add[j];
-      s0 += f;
-      q0 += f * f;
-      const float g = bf16_to_f32((bf16_t)v[j + 4]) + add[j + 4];
-      s1 += g;
-      q1 += g * g;
+    for (int u = 0; u < 4; ++u) {
+      const long long pp = pbase + (long long)u * ppi;
+      v[u] = (pp < p1) ? *(const bf16x8_t*)(xb + pp * C) : (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pbase + (long long)u * ppi < p1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f = bf16_to_f32((bf16_t)v[u][j]) + add[j];
+          s0 += f;
+          q0 = fmaf(f, f, q0);
+          const float g = bf16_to_f32((bf16_t)v[u][j + 4]) + add[j + 4];
+          s1 += g;
+          q1 = fmaf(g, g, q1);
+        }
+      }
     }
   }
   red[threadIdx.x][0] = s0;
@@ -108,60 +119,97 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
         bq += red[t][3];
       }
     }
-    float* o = partial + (((long long)b * GN_SLABS + slab) * G + threadIdx.x) * 2;
+    float* o = partial + (long long)gridDim.y * G * 2 + (((long long)b * GN_SLABS + slab) * G + threadIdx.x) * 2;
     o[0] = a;
     o[1] = bq;
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long HW, int C, int G,
-                                                       const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias, float eps,
-                                                       int act, const float* __restrict__ pre_add,
-                                                       const bf16_t* __restrict__ post_add, const float* __restrict__ partial) {
-  __shared__ float mean_s[32], rstd_s[32];
-  const int b = blockIdx.y;
+// grid B, 256 threads: thread (part = t / 32, g = t % 32) sums every 8th slab; parts are combined in a fixed order
+__global__ __launch_bounds__(256) void gn_finish_kernel(float* __restrict__ partial, long long HW, int C, int G, float eps) {
+  __shared__ float red[8][32][2];
+  const int b = blockIdx.x, g = threadIdx.x & 31, part = threadIdx.x >> 5;
+  float a = 0.f, q = 0.f;
+  if (g < G) {
+    const float* pp = partial + (long long)gridDim.x * G * 2 + ((long long)b * GN_SLABS * G + g) * 2;
+    for (int s = part; s < GN_SLABS; s += 8) {
+      a += pp[(long long)s * G * 2];
+      q += pp[(long long)s * G * 2 + 1];
+    }
+  }
+  red[part][g][0] = a;
+  red[part][g][1] = q;
+  __syncthreads();
   if (threadIdx.x < G) {
-    float a = 0.f, q = 0.f;
-    for (int s = 0; s < GN_SLABS; ++s) {
-      const float* pp = partial + (((long long)b * GN_SLABS + s) * G + threadIdx.x) * 2;
-      a += pp[0];
-      q += pp[1];
+    a = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a += red[k][g][0];
+      q += red[k][g][1];
     }
     const float n = (float)HW * (float)(C / G);
     const float m = a / n;
     const float var = fmaxf(q / n - m * m, 0.f);
-    mean_s[threadIdx.x] = m;
-    rstd_s[threadIdx.x] = rsqrtf(var + eps);
+    partial[((long long)b * G + g) * 2] = m;
+    partial[((long long)b * G + g) * 2 + 1] = rsqrtf(var + eps);
   }
-  __syncthreads();
+}
+
+// every thread keeps its channel chunk for the whole grid-stride loop (256 % (C/8) == 0), so the affine parameters, the
+// pre-add vector and the group statistics live in registers; two independent 16-byte loads in flight per thread
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long HW, int C, int G,
+                                                       const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
+                                                       int act, const float* __restrict__ pre_add,
+                                                       const bf16_t* __restrict__ post_add, const float* __restrict__ partial) {
+  const int b = blockIdx.y;
   const int cpp = C / 8, cpg = C / G;
   const long long total = HW * cpp;
+  const int chunk = threadIdx.x % cpp, c0 = chunk * 8;
+  const float* st = partial + (long long)b * G * 2;
+  const int g0 = c0 / cpg, g1 = (c0 + 4) / cpg;
+  float sc[8], sh[8];  // y = act(x * sc + sh)
+  {
+    const bf16x8_t wv = *(const bf16x8_t*)(w + c0), bv = *(const bf16x8_t*)(bias + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float m = st[(j < 4 ? g0 : g1) * 2], r = st[(j < 4 ? g0 : g1) * 2 + 1];
+      const float pa = pre_add ? pre_add[(long long)b * C + c0 + j] : 0.f;
+      sc[j] = r * bf16_to_f32((bf16_t)wv[j]);
+      sh[j] = fmaf(pa - m, sc[j], bf16_to_f32((bf16_t)bv[j]));
+    }
+  }
   const bf16_t* xb = x + (long long)b * HW * C;
   bf16_t* yb = y + (long long)b * HW * C;
   const bf16_t* ab = post_add ? post_add + (long long)b * HW * C : nullptr;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int chunk = (int)(i % cpp);
-    const int c0 = chunk * 8;
-    const int g0 = c0 / cpg, g1 = (c0 + 4) / cpg;
-    const float m0 = mean_s[g0], r0 = rstd_s[g0], m1 = mean_s[g1], r1 = rstd_s[g1];
-    const bf16x8_t v = *(const bf16x8_t*)(xb + i * 8);
-    const bf16x8_t wv = *(const bf16x8_t*)(w + c0), bv = *(const bf16x8_t*)(bias + c0);
-    bf16x8_t pa = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ab) pa = *(const bf16x8_t*)(ab + i * 8);
-    float o[8];
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += 2 * stride) {
+    const long long i1 = i + stride;
+    const bool has1 = i1 < total;
+    const bf16x8_t v0 = *(const bf16x8_t*)(xb + i * 8);
+    const bf16x8_t v1 = has1 ? *(const bf16x8_t*)(xb + i1 * 8) : v0;
+    bf16x8_t a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+    if (ab) {
+      a0 = *(const bf16x8_t*)(ab + i * 8);
+      if (has1) a1 = *(const bf16x8_t*)(ab + i1 * 8);
+    }
+    union { bf16x8_t v8; uint32_t u[4]; } r0, r1;
+    float o0[8], o1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float f = bf16_to_f32((bf16_t)v[j]);
-      if (pre_add) f += pre_add[(long long)b * C + c0 + j];
-      f = (f - (j < 4 ? m0 : m1)) * (j < 4 ? r0 : r1) * bf16_to_f32((bf16_t)wv[j]) + bf16_to_f32((bf16_t)bv[j]);
-      f = apply_act(f, act);
-      if (ab) f += bf16_to_f32((bf16_t)pa[j]);
-      o[j] = f;
+      o0[j] = apply_act(fmaf(bf16_to_f32((bf16_t)v0[j]), sc[j], sh[j]), act);
+      o1[j] = apply_act(fmaf(bf16_to_f32((bf16_t)v1[j]), sc[j], sh[j]), act);
+      if (ab) {
+        o0[j] += bf16_to_f32((bf16_t)a0[j]);
+        o1[j] += bf16_to_f32((bf16_t)a1[j]);
+      }
     }
-    union { bf16x8_t v8; uint32_t u[4]; } r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.u[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
-    *(bf16x8_t*)(yb + i * 8) = r.v8;
+    for (int j = 0; j < 4; ++j) {
+      r0.u[j] = pack_bf16x2(o0[2 * j], o0[2 * j + 1]);
+      r1.u[j] = pack_bf16x2(o1[2 * j], o1[2 * j + 1]);
+    }
+    *(bf16x8_t*)(yb + i * 8) = r0.v8;
+    if (has1) *(bf16x8_t*)(yb + i1 * 8) = r1.v8;
   }
 }
 
@@ -231,7 +279,7 @@ int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void*
   return x2i_check_launch("conv_stem");
 }
 
-long long x2i_groupnorm_scratch(int B, int G) { return (long long)B * GN_SLABS * G * 2; }
+long long x2i_groupnorm_scratch(int B, int G) { return (long long)B * G * 2 * (GN_SLABS + 1); }
 
 int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
                          const float* pre_add, const void* post_add, float* partial, hipStream_t stream) {
@@ -241,11 +289,15 @@ int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int
   hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SLABS, B), dim3(256), 0, stream, (const bf16_t*)x, pre_add, partial, HW, C, G);
   int rc = x2i_check_launch("groupnorm_partial");
   if (rc) return rc;
+  hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(256), 0, stream, partial, HW, C, G, eps);
+  rc = x2i_check_launch("groupnorm_finish");
+  if (rc) return rc;
   const long long total = HW * (C / 8);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  long long blocks = (total + 511) / 512;  // two chunks per thread per iteration
+  const long long cap = 8192 / B > 256 ? 8192 / B : 256;
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,
-                     (const bf16_t*)w, (const bf16_t*)b, eps, act, pre_add, (const bf16_t*)post_add, partial);
+                     (const bf16_t*)w, (const bf16_t*)b, act, pre_add, (const bf16_t*)post_add, partial);
   return x2i_check_launch("groupnorm_apply");
 }
 
