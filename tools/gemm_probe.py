@@ -23,3 +23,12 @@ if which in ("all", "attn"):
     for _ in range(3):
         ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128))
     torch.cuda.synchronize()
+if which == "conv":
+    # ControlNeXt ResnetBlock conv2 (3x3, 128 -> 128 at 512^2) with / without the residual, and the 256-wide one
+    for (h, cin, cout, res) in [(512, 128, 128, True), (512, 128, 128, False), (256, 256, 256, True)]:
+        x, wt, b = rnd(B, h, h, cin), rnd(cout, 9 * cin, scale=0.02), rnd(cout)
+        r = rnd(B, h, h, cout) if res else None
+        out = torch.empty((B, h, h, cout), device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            ops.conv2d_nhwc(x, wt, b, h, h, cin, cout, 3, 3, 1, 1, res=r, out=out)
+        torch.cuda.synchronize()

@@ -1,17 +1,18 @@
 #!/bin/bash
 # rocprofv3 PMC passes for the dominant kernels (run on the GPU box; counters in their OWN passes, kernel-trace only).
-#   tools/pmc_collect.sh <out_dir>
+#   tools/pmc_collect.sh <out_dir> [probe: all|gemm|attn|conv]
 # FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their bytes
 # (MI355X_MICROARCH.md, HBM section) -> tools/pmc_summarise.py doubles it.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=${1:-$R/gpurun_out/pmc}
 case "$OUT" in /*) ;; *) OUT="$R/$OUT" ;; esac
+WHICH=${2:-all}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
   n=$(echo $c | tr " " "_" | cut -c1-40)
-  timeout 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$n" -o p -- python "$R/tools/gemm_probe.py" > "$OUT/$n.log" 2>&1
+  timeout 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$n" -o p -- python "$R/tools/gemm_probe.py" $WHICH > "$OUT/$n.log" 2>&1
 done
 python "$R/tools/pmc_summarise.py" "$OUT" > "$OUT/summary.json"
 cat "$OUT/summary.json"

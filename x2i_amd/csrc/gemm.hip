@@ -159,6 +159,74 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
   bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
   bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
+  if constexpr (RES && !HASC2) {
+    // Gated-residual form with the residual tile fetched by LDS-DMA as whole 128-byte row segments (the direct form reads
+    // it as 32-byte accumulator-layout fragments, which is what makes short-K launches -- the ControlNeXt residual convs --
+    // epilogue-bound).  Staging image here: [MT*16 rows][128 B], 16-byte chunk c of row r holds logical chunk
+    // c ^ ((r>>1)&7) (the DMA image is lane-linear, so the swizzle is applied on the source address); results overwrite
+    // the residual in place and leave with 16-byte stores.
+    const long long res_bytes = ((long long)(p.M - 1) * p.ldr + p.N) * 2;
+    if ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && (((uintptr_t)p.res) & 15) == 0 && res_bytes < 0x7f000000LL) {
+      __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rz, 0, (uint32_t)res_bytes, 0x00020000);
+      const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+      for (int it = 0; it < MT * 2; ++it) {
+        const int row = it * 8 + srow;
+        const int m = m_wave + row, n = n_wave + ((sch ^ ((row >> 1) & 7)) << 3);
+        const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((long long)m * p.ldr + n) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (__attribute__((address_space(3))) void*)(wave_lds + it * 1024), 16, off, 0, 0, 0);
+      }
+      float bvv[4][4], gvv[4][4];
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int n = n_wave + j * 16 + ng * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bvv[j][r] = 0.f, gvv[j][r] = 1.f;
+        if (n + 3 < p.N) {
+          if (p.bias) {
+            const uint2 bb = *(const uint2*)(p.bias + n);
+            bvv[j][0] = __uint_as_float(bb.x << 16); bvv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
+            bvv[j][2] = __uint_as_float(bb.y << 16); bvv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
+          }
+          if (gz) {
+            const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+            gvv[j][0] = g4[0]; gvv[j][1] = g4[1]; gvv[j][2] = g4[2]; gvv[j][3] = g4[3];
+          }
+          if (b2) {
+            const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+            bvv[j][0] += t4[0]; bvv[j][1] += t4[1]; bvv[j][2] += t4[2]; bvv[j][3] += t4[3];
+          }
+        }
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the region is private to this wave: no barrier needed
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<MT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const int row = i * 16 + mlane;
+          char* slot = wave_lds + row * 128 + ((((j << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
+          const uint2 r2 = *(const uint2*)slot;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bvv[j][r], ACT);
+          v[0] = fmaf(gvv[j][0], v[0], __uint_as_float(r2.x << 16));
+          v[1] = fmaf(gvv[j][1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+          v[2] = fmaf(gvv[j][2], v[2], __uint_as_float(r2.y << 16));
+          v[3] = fmaf(gvv[j][3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+          *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < MT * 2; ++it) {
+        const int row = it * 8 + srow;
+        const bf16x8_t d = *(const bf16x8_t*)(wave_lds + it * 1024 + lane * 16);
+        const int m = m_wave + row, n = n_wave + ((sch ^ ((row >> 1) & 7)) << 3);
+        if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(Cz + (long long)m * p.ldc + n) = d;
+      }
+      return;
+    }
+  }
   constexpr int NPASS = HASC2 ? 2 : 1;
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -256,7 +324,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 
   // per-thread source offsets of its 4 chunks per operand tile (row r, physical chunk c holds logical chunk c^swz)
   uint32_t a_voff[4], w_voff[4];
-  int c_oy[4], c_ox[4], c_cl[4];  // CONV: output pixel of each chunk row, logical chunk
+  int c_oy[4], c_ox[4], c_cl[4];  // CONV: output pixel of each chunk row (times stride, minus pad), logical chunk
+  int c_base[4];                  // CONV: byte offset of tap (0,0), channel c_cl (may be negative: masked by c_mask)
+  uint32_t c_mask[4];             // CONV: bit (ky*KW + kx) = tap lies inside the image
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int pch = j * 256 + tid;
@@ -269,26 +339,51 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     if (n0 + row >= p.N) w_voff[j] = 0x80000000u;
     if (CONV) {
       const int m = m0 + row;
-      c_oy[j] = (m < p.M) ? m / p.cOW : -100000;  // invalid rows never pass the bounds test below
-      c_ox[j] = m - (m / p.cOW) * p.cOW;
+      const int oy = m / p.cOW, ox = m - oy * p.cOW;
+      c_oy[j] = oy * p.cStride - p.cPad;
+      c_ox[j] = ox * p.cStride - p.cPad;
       c_cl[j] = clog * 8;
+      c_base[j] = ((c_oy[j] * p.cW + c_ox[j]) * p.cCin + c_cl[j]) * 2;
+      uint32_t mask = 0;
+      if (m < p.M) {
+        const int KH = p.K / (p.cKW * p.cCin);
+        for (int ky = 0; ky < KH; ++ky)
+          for (int kx = 0; kx < p.cKW; ++kx) {
+            const int iy = c_oy[j] + ky, ix = c_ox[j] + kx;
+            if (iy >= 0 && iy < (p.cH << p.cUp) && ix >= 0 && ix < (p.cW << p.cUp)) mask |= 1u << (ky * p.cKW + kx);
+          }
+      }
+      c_mask[j] = mask;
     }
   }
-  // CONV: gather addresses for K-tile kt = one filter tap (ky,kx) and a 64-channel slice of the NHWC input;
-  // out-of-image taps (zero padding) are mapped beyond num_records so the DMA writes zeros
-  auto conv_offsets = [&](int kt) {
-    const int kbase = kt * BK;
-    const int tap = kbase / p.cCin, c0 = kbase - tap * p.cCin;
-    const int ky = tap / p.cKW, kx = tap - ky * p.cKW;
+  // CONV: gather addresses for one K-tile = one filter tap (ky,kx) and a 64-channel slice of the NHWC input; the tap
+  // state advances incrementally (wave-uniform scalars, no divisions in the loop); out-of-image taps (zero padding) are
+  // mapped beyond num_records so the DMA writes zeros
+  int s_ky = 0, s_kx = 0, s_c0 = 0;
+  auto conv_offsets = [&]() {
+    const int tap = s_ky * p.cKW + s_kx;
+    if (p.cUp) {
+      // x2 nearest upsampling fused into the gather: source pixel = coordinate >> 1 on the upsampled grid
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // coordinates on the (optionally x2 nearest-upsampled) input grid; source pixel = coordinate >> cUp
-      const int iy = c_oy[j] * p.cStride + ky - p.cPad, ix = c_ox[j] * p.cStride + kx - p.cPad;
-      const bool ok = (iy >= 0) && (iy < (p.cH << p.cUp)) && (ix >= 0) && (ix < (p.cW << p.cUp));
-      a_voff[j] = ok ? (uint32_t)((((long long)(iy >> p.cUp) * p.cW + (ix >> p.cUp)) * p.cCin + c0 + c_cl[j]) * 2) : 0x80000000u;
+      for (int j = 0; j < 4; ++j) {
+        const int iy = c_oy[j] + s_ky, ix = c_ox[j] + s_kx;
+        a_voff[j] = ((c_mask[j] >> tap) & 1) ? (uint32_t)((((iy >> 1) * p.cW + (ix >> 1)) * p.cCin + s_c0 + c_cl[j]) * 2) : 0x80000000u;
+      }
+    } else {
+      const int toff = ((s_ky * p.cW + s_kx) * p.cCin + s_c0) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a_voff[j] = ((c_mask[j] >> tap) & 1) ? (uint32_t)(c_base[j] + toff) : 0x80000000u;
+    }
+    s_c0 += BK;
+    if (s_c0 >= p.cCin) {
+      s_c0 = 0;
+      if (++s_kx == p.cKW) {
+        s_kx = 0;
+        ++s_ky;
+      }
     }
   };
-  if (CONV) conv_offsets(0);
+  if (CONV) conv_offsets();
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -317,7 +412,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     if (kt + 1 < nk) {
       char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
       const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
-      if (CONV) conv_offsets(kt + 1);
+      if (CONV) conv_offsets();
       stage_tile(a_rsrc, nxt, a_voff, CONV ? 0u : koff, wave);
       stage_tile(w_rsrc, nxt + TILE_BYTES, w_voff, koff, wave);
     }
