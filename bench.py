@@ -64,13 +64,16 @@ def gemm_roofline(B, iters=10):
     # HBM-side traffic of the same two launches from the committed rocprofv3 PMC pass (tools/pmc_collect.sh; FETCH_SIZE
     # doubled per the gfx950 correction, + WRITE_SIZE).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_attn.json")
+    pj = os.path.join(ROOT, "profiles", "r01e_pmc_gemm_attn.json")
     if B == 4 and os.path.exists(pj):
         d = json.load(open(pj))
+        # the launcher peels the last partly filled round of 256^2 tiles into a 128^2 launch: four kernels for the two GEMMs
+        grids = ("gemm256_bf16_kernel<0, false, false, false, 0> grid=3010560", "gemm_bf16_kernel<0, false, false, false, false> grid=172032",
+                 "gemm256_bf16_kernel<0, false, false, false, 0> grid=393216", "gemm_bf16_kernel<0, false, false, false, false> grid=98304")
         try:
-            traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"] for k in d
-                          if k.startswith("gemm256") and (k.endswith("grid=3096576") or k.endswith("grid=442368")))
-            src = "profiles/r01_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes for both launches)"
+            traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"] for k in grids)
+            src = ("profiles/r01e_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
+                   "boundary for both GEMMs incl. their peeled 128x128 tail launches)")
         except KeyError:
             traffic = None
     alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K) in ((B * S, 7 * D, D), (B * S, D, 5 * D)))
