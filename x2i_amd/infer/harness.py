@@ -63,6 +63,8 @@ def build_parser(family):
     p.add_argument("--batch", type=int, default=1, help="prompts per pipeline call (the reference always uses 1)")
     p.add_argument("--synthetic", action="store_true", help="no checkpoints: random weights, synthetic MLLM hidden states")
     p.add_argument("--no_graph", action="store_true")
+    p.add_argument("--full_generate", action="store_true",
+                   help="run the MLLM's 128-token generate() as the reference does instead of the single prefill forward")
     p.add_argument("--decode", action="store_true", help="with --synthetic: also run the (random-weight) VAE decoder and save images")
     return p
 

@@ -14,11 +14,17 @@ class QwenVLConditioner:
     """Qwen2_5_VLForConditionalGeneration prompt pass; inputs padded to 512 tokens, images resized to 128x128, videos at
     1 fps / 128*128 pixels, generate(max_new_tokens=128, output_hidden_states=True) -- infer/inference_qwenvl.py:136-180."""
 
-    def __init__(self, path, device, use_answer=False):
+    def __init__(self, path, device, use_answer=False, prefill_only=True):
         from transformers import AutoProcessor, Qwen2_5_VLForConditionalGeneration
         self.model = Qwen2_5_VLForConditionalGeneration.from_pretrained(path, torch_dtype=torch.bfloat16).eval().to(device)
         self.processor = AutoProcessor.from_pretrained(path)
         self.device, self.use_answer = device, use_answer
+        # the prompt-pass states are all the reference keeps unless --use_answer: take them from ONE forward, written by
+        # hooks straight into the [B,C,S,H] buffer (x2i_amd/handoff.py), instead of a 128-token generate() + torch.cat
+        self.slab = None
+        if prefill_only and not use_answer:
+            from ..handoff import HiddenStateSlab, find_decoder
+            self.slab = HiddenStateSlab(find_decoder(self.model))
 
     @torch.no_grad()
     def __call__(self, videos=None, images=None, audios=None, text_prompt=None):
@@ -39,6 +45,8 @@ class QwenVLConditioner:
         prompt = self.processor.apply_chat_template(message, tokenize=False, add_generation_prompt=True)
         inputs = self.processor(text=[prompt], images=image_list or None, videos=video_inputs, padding="max_length",
                                 max_length=512, truncation=True, return_tensors="pt").to(self.device)
+        if self.slab is not None:
+            return self.slab.prefill(self.model, **inputs)
         out = self.model.generate(**inputs, max_new_tokens=128, output_hidden_states=True, return_dict_in_generate=True)
         return stack_hidden_states(out["hidden_states"], use_answer=self.use_answer)
 
@@ -71,7 +79,7 @@ def main(argv=None):
     kind = "qwen" + args.qwen_size
     device = "cuda:%d" % int(__import__("os").environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)
-    cond = SyntheticConditioner(kind, device) if args.synthetic else QwenVLConditioner(args.qwen_path, device, args.use_answer)
+    cond = SyntheticConditioner(kind, device) if args.synthetic else QwenVLConditioner(args.qwen_path, device, args.use_answer, prefill_only=not args.full_generate)
     Harness(args, kind, cond, device).run_tasks(tasks(args))
 
 
