@@ -116,6 +116,26 @@ int x2i_qkv_split_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t 
                        const float* cos, const float* sin, void* Q, void* K, void* VT, int32_t Spad, float eps,
                        x2i_stream_t stream);
 
+/* The QKV projection with x2i_qkv_split_bf16 fused into its epilogue: C = A W^T + bias is never written; each output
+ * tile (128 or 256 columns = one or two heads of the q, k or v section) goes straight from the accumulators through
+ * LDS to the attention layout -- RMSNorm(q/k) * weight + RoPE into Q/K [B,H,Spad,128], V transposed into VT
+ * [B,H,128,Spad] (same operators and reference lines as x2i_qkv_split_bf16; the values normalised are the bf16-rounded
+ * linear outputs, as in the reference's bf16 run).  args: M/N/K/batch/A/W/bias as for x2i_gemm_bf16 with N == 3*H*128,
+ * act == 0, no residual / gate / C2 / f32 output; args->C is ignored.  Row m of batch item z of this GEMM is joint token
+ * s = tok_off + m % rows_per_sample of sample b = z + m / rows_per_sample. */
+typedef struct x2i_qkv_desc {
+  const void* norm_q;  /* bf16 [128] RMSNorm weights for the q / k heads of these rows */
+  const void* norm_k;
+  const float* cos;    /* f32 [S,128] interleaved-pair RoPE tables over joint positions */
+  const float* sin;
+  void* Q;             /* bf16 [B,H,Spad,128] */
+  void* K;
+  void* VT;            /* bf16 [B,H,128,Spad] */
+  int32_t H, Spad, tok_off, rows_per_sample;
+  float eps;
+} x2i_qkv_desc;
+int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_stream_t stream);
+
 /* LayerNorm(elementwise_affine=False, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero / ZeroSingle /
  * Continuous and `norm2(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]`, lightcontrol_flux.py:166-170,
  * 183-184,196-197,89,542).  X,Y: bf16 [B][S][D] with row strides ldx/ldy and batch strides (elements).  Rows

@@ -273,3 +273,49 @@ def test_gemm_tile_quantisation_split_is_bit_identical(ops, monkeypatch):
     assert torch.equal(split, whole)
     ref = X[1].float() + gate[1] * F.linear(A[1].float(), W.float(), b.float())
     assert rel_l2(split[1], ref.cpu()) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ fused QKV epilogue
+@pytest.mark.parametrize("B,H,St,Si,tile", [(2, 2, 40, 216, "128"), (2, 2, 64, 448, "256"), (1, 4, 700, 324, "256"),
+                                            (3, 2, 0, 600, "256"), (2, 24, 512, 1024, ""), (1, 24, 0, 5632, ""), (2, 24, 256, 2688, "")])
+def test_gemm_qkv_fused_equals_gemm_then_qkv_split(ops, monkeypatch, B, H, St, Si, tile):
+    """x2i_gemm_qkv_bf16 (norm + RoPE + head split + V transpose in the GEMM epilogue) against the two-step form
+    x2i_gemm_bf16 -> x2i_qkv_split_bf16, on both tile kernels, with ragged text lengths (St = 700: unaligned token offsets
+    take the element-wise V^T path), batched (double-block) and flattened (single-block, St = 0) row geometry; the last two
+    cases have 792 / 756 tiles of 256^2, so the launcher peels the last tile rows into the 128^2 kernel (row offset path)."""
+    if tile:
+        monkeypatch.setenv("X2I_GEMM_TILE", tile)
+    D, S, Kd = H * 128, St + Si, 256
+    Spad = ops.pad128(S)
+    W, bias = g(bf(seeded((3 * D, Kd), 40, 0.08))), g(bf(seeded((3 * D,), 41, 0.5)))
+    Wc, biasc = g(bf(seeded((3 * D, Kd), 42, 0.08))), g(bf(seeded((3 * D,), 43, 0.5)))
+    X = g(bf(seeded((B, S, Kd), 44)))
+    nq, nk, nqa, nka = (g(bf(1 + 0.2 * seeded((128,), 45 + i))) for i in range(4))
+    ang = seeded((S, 64), 50, 3.0)
+    cos, sin = g(torch.cos(ang).repeat_interleave(2, 1).contiguous()), g(torch.sin(ang).repeat_interleave(2, 1).contiguous())
+
+    def bufs():
+        return (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16), torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16),
+                torch.zeros((B, H, 128, Spad), device=DEV, dtype=torch.bfloat16))
+    Q0, K0, V0 = bufs()
+    Q1, K1, V1 = bufs()
+    if St > 0:  # double-block geometry: per-sample batched GEMMs over the image rows and the text rows
+        QKV = torch.empty((B * S, 3 * D), device=DEV, dtype=torch.bfloat16)
+        off_img = B * St * 3 * D
+        ops.gemm(X, W, bias, out=QKV, M=Si, batch=B, a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd, c_batch_stride=Si * 3 * D,
+                 ldc=3 * D, c_offset=off_img)
+        ops.gemm(X, Wc, biasc, out=QKV, M=St, batch=B, a_batch_stride=S * Kd, lda=Kd, c_batch_stride=St * 3 * D, ldc=3 * D)
+        ops.qkv_split(QKV, QKV.view(-1)[off_img:], 3 * D, 3 * D, B, S, St, H, nqa, nka, nq, nk, cos, sin, Q0, K0, V0, Spad)
+        ops.gemm_qkv(X, W, bias, Q1, K1, V1, nq, nk, cos, sin, M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B,
+                     a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd)
+        ops.gemm_qkv(X, Wc, biasc, Q1, K1, V1, nqa, nka, cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B,
+                     a_batch_stride=S * Kd, lda=Kd)
+    else:  # single-block geometry: one flattened GEMM over B*S rows
+        QKV = torch.empty((B * S, 3 * D), device=DEV, dtype=torch.bfloat16)
+        ops.gemm(X, W, bias, out=QKV, M=B * S)
+        ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, nq, nk, cos, sin, Q0, K0, V0, Spad)
+        ops.gemm_qkv(X, W, bias, Q1, K1, V1, nq, nk, cos, sin, M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S)
+    torch.cuda.synchronize()
+    assert torch.equal(V1[..., :S], V0[..., :S])          # a pure move of the same bf16 values
+    assert float(V1[..., S:].float().abs().max()) == 0.0 if Spad > S else True
+    assert torch.equal(Q1, Q0) and torch.equal(K1, K0)    # same arithmetic, same order

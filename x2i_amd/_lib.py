@@ -37,12 +37,20 @@ class ConvDesc(C.Structure):
                 ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32)]
 
 
+class QkvDesc(C.Structure):
+    _fields_ = [("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
+                ("Q", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p),
+                ("H", C.c_int32), ("Spad", C.c_int32), ("tok_off", C.c_int32), ("rows_per_sample", C.c_int32),
+                ("eps", C.c_float)]
+
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (restype is int for all but the two below); mirrors include/x2i.h exactly
 SIGNATURES = {
     "x2i_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "x2i_conv2d_nhwc_bf16": [C.POINTER(GemmArgs), C.POINTER(ConvDesc), _vp],
+    "x2i_gemm_qkv_bf16": [C.POINTER(GemmArgs), C.POINTER(QkvDesc), _vp],
     "x2i_conv_stem_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_groupnorm_nhwc_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],

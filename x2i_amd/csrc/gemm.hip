@@ -40,6 +40,12 @@ struct GemmP {
   int tilesM, tilesN;
   // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
+  // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
+  int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0;
+  float q_eps;
+  const bf16_t *q_nq, *q_nk;
+  const float *q_cos, *q_sin;
+  bf16_t *q_Q, *q_K, *q_VT;
 };
 
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
@@ -286,6 +292,139 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fused QKV epilogue (x2i_gemm_qkv_bf16).  The workgroup's finished tile -- TR tokens x TC columns, i.e. TC/128 whole
+// heads of the q, k or v section -- is parked in LDS as bf16(acc + bias) (per-wave regions of the staged epilogue, row
+// stride 144 B) and leaves in attention layout:
+//   q / k tile: 16 lanes x 8 dims per (token, head): RMSNorm over the 128 dims (fp32), * norm weight, RoPE on adjacent
+//               pairs with the fp32 cos/sin row of the token's joint position, 16-byte stores into Q/K [B,H,Spad,128]
+//   v tile:     transposed through LDS: a lane gathers two adjacent dims of 8 consecutive tokens (8 ds_read_b32) and
+//               writes two 16-byte token runs of VT [B,H,128,Spad]; 8 lanes cover a 128-byte line
+// Same arithmetic as qk_norm_rope_kernel / v_transpose_kernel (elementwise.hip), which remain the unfused form.
+// ------------------------------------------------------------------------------------------------------------
+template <int MT, int WN, int NT>
+__device__ __forceinline__ void epilogue_qkv(const GemmP& p, f32x4_t (&acc)[MT][4], int z, int m0, int n0, int wm, int wn, int lane,
+                                             int tid, char* smem) {
+  constexpr int WR = MT * 16;  // rows per wave
+  constexpr int TR = 2 * WR;   // tile rows (two waves along M in both kernels)
+  constexpr int TC = WN * 64;  // tile columns
+  constexpr int REGION = WR * EPI_ROW_BYTES;
+  constexpr int HEADS = TC / 128;
+  {
+    char* wave_lds = smem + (wm * WN + wn) * REGION;
+    const int mlane = lane & 15, ng = lane >> 4;
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n0 + wn * 64 + j * 16 + ng * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n + 3 < p.N) {
+        const uint2 bb = *(const uint2*)(p.bias + n);
+        bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+        bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+      }
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        *(uint2*)(wave_lds + (i * 16 + mlane) * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) =
+            make_uint2(pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
+      });
+    });
+  }
+  __syncthreads();
+  const int Dm = p.q_H * 128;
+  const int sec = n0 / Dm;  // 0 = q, 1 = k, 2 = v (a tile never straddles sections: Dm % TC == 0, checked by the launcher)
+  const int head0 = (n0 - sec * Dm) >> 7;
+  auto lds_at = [&](int row, int col) -> const char* {  // bf16 element (row, col) of the tile
+    return smem + ((row / WR) * WN + (col >> 6)) * REGION + (row % WR) * EPI_ROW_BYTES + (col & 63) * 2;
+  };
+  if (sec < 2) {
+    const int c = tid & 15;  // 8-dim chunk of the head; the same for every iteration (NT % 16 == 0)
+    float w[8];
+    {
+      const bf16x8_t wv = *(const bf16x8_t*)((sec ? p.q_nk : p.q_nq) + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]);
+    }
+    bf16_t* dstbase = sec ? p.q_K : p.q_Q;
+#pragma unroll 2
+    for (int u = tid >> 4; u < TR * HEADS; u += NT / 16) {
+      const int hh = u % HEADS, row = u / HEADS;
+      const int m = m0 + row;
+      const bf16x8_t xv = *(const bf16x8_t*)lds_at(row, hh * 128 + c * 8);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[j]);
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this (token, head)
+      if (m < p.M) {
+        const float r = rsqrtf(ss * (1.f / 128.f) + p.q_eps);
+        const int mg = p.q_row0 + m;
+        const int b = z + mg / p.q_rpb, st = p.q_tok_off + mg % p.q_rpb;
+        const float* cp = p.q_cos + (long long)st * 128 + c * 8;
+        const float* sp = p.q_sin + (long long)st * 128 + c * 8;
+        const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
+        const f32x4_t s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
+        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
+          o[j] = a * cs[j] - bb * sn[j];
+          o[j + 1] = bb * cs[j + 1] + a * sn[j + 1];
+        }
+        union { bf16x8_t v8; uint32_t uu[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk.uu[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+        *(bf16x8_t*)(dstbase + (((long long)b * p.q_H + head0 + hh) * p.q_Spad + st) * 128 + c * 8) = pk.v8;
+      }
+    }
+  } else {
+    const int wave = tid >> 6;
+    const int ch_lo = lane & 7, dp_lo = lane >> 3;
+    constexpr int CG = TR / 64;                  // groups of 8 token-chunks (64 tokens)
+    constexpr int WITS = CG * (TC / 16);         // wave-iterations: x groups of 8 dim-pairs (16 dims)
+    // 8-token runs are whole and 16-byte aligned in VT when every row offset is a multiple of 8
+    const bool aligned = ((p.q_tok_off | p.q_rpb | p.q_row0 | p.M | p.q_Spad) & 7) == 0;
+    for (int wi = wave; wi < WITS; wi += NT / 64) {
+      const int ch = (wi % CG) * 8 + ch_lo, dp = (wi / CG) * 8 + dp_lo;
+      const int d0 = dp * 2;  // tile column of the first of the two dims
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *(const uint32_t*)lds_at(ch * 8 + k, d0);
+      const int m = m0 + ch * 8;
+      if (m >= p.M) continue;
+      const int h = head0 + (d0 >> 7), d = d0 & 127;
+      const int mg = p.q_row0 + m;
+      const int b = z + mg / p.q_rpb, st = p.q_tok_off + mg % p.q_rpb;
+      bf16_t* row0 = p.q_VT + (((long long)b * p.q_H + h) * 128 + d) * p.q_Spad;
+      if (aligned) {
+        union { bf16x8_t v8; uint32_t uu[4]; } lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          lo.uu[k] = (v[2 * k] & 0xffffu) | (v[2 * k + 1] << 16);
+          hi.uu[k] = (v[2 * k] >> 16) | (v[2 * k + 1] & 0xffff0000u);
+        }
+        *(bf16x8_t*)(row0 + st) = lo.v8;
+        *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (m + k < p.M) {
+            const int mgk = mg + k;
+            const int bk = z + mgk / p.q_rpb, sk = p.q_tok_off + mgk % p.q_rpb;
+            bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + h) * 128 + d) * p.q_Spad + sk;
+            rk[0] = (bf16_t)(v[k] & 0xffffu);
+            rk[p.q_Spad] = (bf16_t)(v[k] >> 16);
+          }
+        }
+      }
+    }
+  }
+}
+
 // Epilogue variants are compile-time (ACT, RES, OUTF32, HASC2) so that the accumulator array is only ever indexed
 // with constants (a runtime-indexed ext_vector array is demoted to scratch memory by hipcc).
 template <int ACT, bool RES, bool OUTF32, bool HASC2, bool CONV>
@@ -435,6 +574,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     __syncthreads();                                  // ... everyone's has, and everyone is done reading `cur`
   }
 
+  if constexpr (ACT == X2I_ACT_NONE && !RES && !OUTF32 && !HASC2 && !CONV) {
+    if (p.q_on) {
+      epilogue_qkv<4, 2, 256>(p, acc, z, m0, n0, wm, wn, lane, tid, smem);
+      return;
+    }
+  }
   if constexpr (!OUTF32) {
     // whole-line stores through LDS (see epilogue_store_lds); needs 16-byte aligned rows and N % 8 == 0
     if (((p.N | p.ldc) & 7) == 0 && (!RES || (p.ldr & 3) == 0) && ((((uintptr_t)p.C) | ((uintptr_t)p.C2)) & 15) == 0 && (p.c_bs & 7) == 0) {
@@ -631,6 +776,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
     if (sacc == 12345.678f) ((float*)p.C)[tid] = sacc;
     return;
   }
+  if constexpr (ACT == X2I_ACT_NONE && !RES && !OUTF32 && !HASC2 && ABL == 0) {
+    if (p.q_on) {
+      __syncthreads();  // every wave is done reading the operand ring before it is reused as staging space
+      epilogue_qkv<8, 4, 512>(p, acc, z, m0, n0, wm, wn, lane, tid, smem);
+      return;
+    }
+  }
   if constexpr (!OUTF32) {
     // whole-line stores through LDS need 16-byte aligned rows and N % 8 == 0 (wave-uniform test)
     if (((p.N | p.ldc) & 7) == 0 && (!RES || (p.ldr & 3) == 0) && ((((uintptr_t)p.C) | ((uintptr_t)p.C2)) & 15) == 0 && (p.c_bs & 7) == 0) {
@@ -667,10 +819,30 @@ __global__ void gemm_naive_kernel(GemmP p) {
 
 }  // namespace
 
-int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) { return x2i_launch_gemm_conv(a, nullptr, stream); }
+static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream);
 
+int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) { return launch_gemm_impl(a, nullptr, nullptr, stream); }
 int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream) {
-  if (!a || !a->A || !a->W || !a->C) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
+  return launch_gemm_impl(a, cd, nullptr, stream);
+}
+int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStream_t stream) {
+  if (!a || !qd) return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: null pointer");
+  if (!qd->norm_q || !qd->norm_k || !qd->cos || !qd->sin || !qd->Q || !qd->K || !qd->VT)
+    return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: null pointer in descriptor");
+  if (qd->H <= 0 || a->N != 3 * qd->H * 128) return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv: N=%d must be 3*H*128 (H=%d)", a->N, qd->H);
+  if (qd->Spad % 128 || qd->rows_per_sample <= 0 || qd->tok_off < 0 || qd->tok_off + qd->rows_per_sample > qd->Spad)
+    return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv: bad token geometry (tok_off=%d rows_per_sample=%d Spad=%d)", qd->tok_off,
+                         qd->rows_per_sample, qd->Spad);
+  if (a->act || a->res || a->gate || a->C2 || a->out_f32 || a->bias2)
+    return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: only the plain bias epilogue can be fused");
+  if ((((uintptr_t)qd->Q | (uintptr_t)qd->K | (uintptr_t)qd->VT | (uintptr_t)qd->norm_q | (uintptr_t)qd->norm_k | (uintptr_t)qd->cos |
+        (uintptr_t)qd->sin) & 15) != 0)
+    return x2i_set_error(X2I_ERR_ALIGN, "gemm_qkv: descriptor pointers must be 16-byte aligned");
+  return launch_gemm_impl(a, nullptr, qd, stream);
+}
+
+static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream) {
+  if (!a || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
   const bool conv = cd != nullptr;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
@@ -685,6 +857,14 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
   p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
+  p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f;
+  p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
+  if (qd) {
+    p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps;
+    p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
+    p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT;
+    p.ldc = a->N; p.c_bs = 0;  // C is never written
+  }
   if (conv) {
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
@@ -747,6 +927,8 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
   }
   if (force == 128) use256 = false;
   if (force == 256) use256 = true;
+  if (qd && (qd->H * 128) % BN2) use256 = false;  // a 256-column tile must not straddle the q / k / v sections
+  if (qd && !(fast && kern)) return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv: K %% 64 == 0 and 16-byte aligned operands required");
   if (fast && kern && use256) {
     hipError_t e = hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES);
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -776,6 +958,7 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
       if (p.C2) pt.C2 = p.C2 + r0 * p.ldc;
       if (p.res) pt.res = p.res + r0 * p.ldr;
       pt.M = a->M - (int)r0;
+      pt.q_row0 = (int)r0;
       pt.tilesM = (pt.M + BM - 1) / BM; pt.tilesN = (a->N + BN - 1) / BN;
       hipLaunchKernelGGL(kern, dim3(pt.tilesM * pt.tilesN, a->batch), dim3(256), 4 * TILE_BYTES, stream, pt);
     }

@@ -5,6 +5,7 @@
 
 int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream);
 int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream);
+int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStream_t stream);
 int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout,
                          hipStream_t stream);
 long long x2i_groupnorm_scratch(int B, int G);

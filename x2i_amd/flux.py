@@ -19,6 +19,7 @@ Weights are stored fused (q|k|v, q|k|v|proj_mlp, all AdaLN linears) and exposed 
 names as views, so load_state_dict() of a diffusers checkpoint fills the fused storage directly.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -316,6 +317,8 @@ class FluxTransformer2DModel(nn.Module):
         def mod(off):
             return MOD[:, off:]
 
+        # X2I_QKV_FUSE=0 keeps the two-step form (GEMM -> x2i_qkv_split) for A/B measurements; results are bit-identical
+        fuse_qkv = os.environ.get("X2I_QKV_FUSE", "1") != "0" and D % 64 == 0
         qkv_txt = QKV  # rows [0, B*St)
         qkv_img_off = B * St * 3 * D
         # ---- double-stream blocks (lightcontrol_flux.py:159-204)
@@ -324,12 +327,20 @@ class FluxTransformer2DModel(nn.Module):
             oi = i * 12 * D
             oc = oi + 6 * D
             ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
-            ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=QKV, M=Si, batch=B, a_batch_stride=S * D, lda=D,
-                     a_offset=St * D, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
-            ops.gemm(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], out=QKV, M=St, batch=B, a_batch_stride=S * D, lda=D,
-                     c_batch_stride=St * 3 * D, ldc=3 * D)
-            ops.qkv_split(qkv_txt, QKV.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"],
-                          f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
+            if fuse_qkv:
+                # q/k RMSNorm + RoPE + head split + V transpose ride in the QKV GEMM's epilogue (no [B*S, 3D] round trip)
+                ops.gemm_qkv(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
+                             M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
+                             a_offset=St * D)
+                ops.gemm_qkv(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], Q, K, VT, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
+                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D)
+            else:
+                ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=QKV, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                         a_offset=St * D, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
+                ops.gemm(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], out=QKV, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                         c_batch_stride=St * 3 * D, ldc=3 * D)
+                ops.qkv_split(qkv_txt, QKV.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"],
+                              f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
             ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
             # hidden += gate_msa * to_out(attn_img) ; enc += c_gate_msa * to_add_out(attn_txt)
             ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
@@ -362,10 +373,15 @@ class FluxTransformer2DModel(nn.Module):
             o = base + i * 3 * D
             ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
             w, bias = f[p + ".in.w"], f[p + ".in.b"]
-            ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)
+            if fuse_qkv:
+                ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
+                             Spad=Spad, tok_off=0, rows_per_sample=S)
+            else:
+                ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)
             ops.gemm(NRM, w[3 * D:], bias[3 * D:], out=CAT, M=B * S, N=4 * D, ldc=5 * D, c_offset=D, act=ACT_GELU_TANH)
-            ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
-                          Q, K, VT, Spad)
+            if not fuse_qkv:
+                ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
+                              Q, K, VT, Spad)
             ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
             ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D,
                      lda=5 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(o + 2 * D),

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_SILU, GemmArgs, check  # noqa: F401
+from ._lib import QkvDesc, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_SILU, GemmArgs, check  # noqa: F401
 
 
 def _stream():
@@ -72,6 +72,34 @@ def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=No
     a.out_f32 = 1 if out_f32 else 0
     check(lib.x2i_gemm_bf16(C.byref(a), _stream()), "gemm")
     return out
+
+
+def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1, a_batch_stride=0,
+             lda=None, a_offset=0, eps=1e-6):
+    """QKV projection with RMSNorm(q,k) + RoPE + head split + V transpose fused into the epilogue: rows of A (row m of batch
+    item z = joint token tok_off + m % rows_per_sample of sample z + m // rows_per_sample) go straight to Q/K [B,H,Spad,128]
+    and VT [B,H,128,Spad]; the [M, 3*H*128] product is never written (include/x2i.h: x2i_gemm_qkv_bf16)."""
+    lib = _lib.load()
+    _req(A, torch.bfloat16, "A")
+    _req(W, torch.bfloat16, "W")
+    a = GemmArgs()
+    a.A = A.data_ptr() + a_offset * 2
+    a.a_batch_stride = a_batch_stride
+    a.lda = A.shape[-1] if lda is None else lda
+    a.W = W.data_ptr()
+    a.ldw = W.stride(-2)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C = None
+    a.c_batch_stride, a.ldc = 0, 3 * H * 128
+    a.C2, a.act2, a.gate, a.gate_batch_stride, a.res, a.res_batch_stride, a.ldr = None, 0, None, 0, None, 0, 0
+    a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
+    a.M, a.N, a.K, a.batch = M, 3 * H * 128, W.shape[-1], batch
+    a.act, a.out_f32 = ACT_NONE, 0
+    q = QkvDesc()
+    q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
+    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps = H, Spad, tok_off, rows_per_sample, eps
+    check(lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), _stream()), "gemm_qkv")
 
 
 def attention(Q, K, VT, out, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0):
