@@ -159,6 +159,13 @@ int x2i_skinny_linear(const void* X, int32_t x_is_bf16, const void* W, const voi
 /* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(t f_k) | sin(t f_k)] */
 int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, int32_t round_bf16, x2i_stream_t stream);
 
+/* FluxPosEmbed (diffusers 0.31; used at lightcontrol_flux.py:247,472): rotary tables for position
+ * ids f32 [S,3] over three axes of (even) widths d0,d1,d2: column c of axis a holds cos / sin of ids[s][a] *
+ * theta^(-2k/d_a), k = pair index, each value repeated for the two elements of its pair.  Frequencies and angles are
+ * evaluated in float64 like the reference; outputs f32 [S, d0+d1+d2].  Step-invariant: called once per prompt. */
+int x2i_rope_table_f32(const float* ids, int32_t S, int32_t d0, int32_t d1, int32_t d2, float theta, float* cos, float* sin,
+                       x2i_stream_t stream);
+
 /* FlowMatchEulerDiscreteScheduler.step: x = bf16(f32(x) + dt[0] * f32(eps)); dt is a DEVICE scalar so the
  * call can be captured in a hipGraph. */
 int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2i_stream_t stream);

@@ -319,3 +319,15 @@ def test_gemm_qkv_fused_equals_gemm_then_qkv_split(ops, monkeypatch, B, H, St, S
     assert torch.equal(V1[..., :S], V0[..., :S])          # a pure move of the same bf16 values
     assert float(V1[..., S:].float().abs().max()) == 0.0 if Spad > S else True
     assert torch.equal(Q1, Q0) and torch.equal(K1, K0)    # same arithmetic, same order
+
+
+def test_rope_table_matches_float64_reference(ops):
+    """x2i_rope_table_f32 vs the float64 torch restatement of FluxPosEmbed (oracle/primitives.py)."""
+    ids = torch.zeros((300, 3))
+    ids[:, 1] = torch.arange(300) // 20
+    ids[:, 2] = torch.arange(300) % 20
+    ids[:40] = 0  # text rows
+    cos, sin = ops.rope_table(g(ids), (16, 56, 56))
+    rc, rs = P.flux_pos_embed(ids, (16, 56, 56))
+    assert cos.shape == (300, 128) and torch.allclose(cos.cpu(), rc, atol=1e-6) and torch.allclose(sin.cpu(), rs, atol=1e-6)
+    assert torch.equal(cos[:40].cpu(), torch.ones(40, 128)) and torch.equal(sin[:40].cpu(), torch.zeros(40, 128))

@@ -84,6 +84,11 @@ int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, in
   return x2i_launch_timestep_sinusoid(t, out, B, dim, round_bf16, (hipStream_t)stream);
 }
 
+int x2i_rope_table_f32(const float* ids, int32_t S, int32_t d0, int32_t d1, int32_t d2, float theta, float* cos, float* sin,
+                       x2i_stream_t stream) {
+  return x2i_launch_rope_table(ids, S, d0, d1, d2, theta, cos, sin, (hipStream_t)stream);
+}
+
 int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2i_stream_t stream) {
   return x2i_launch_euler_step(x, eps, n, dt, (hipStream_t)stream);
 }

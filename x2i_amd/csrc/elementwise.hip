@@ -255,6 +255,24 @@ __global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__
   out[i] = v;
 }
 
+// FluxPosEmbed table: column c of axis a (dims d_a, pair index k = (c - start_a) / 2) holds cos / sin of
+// pos[s][a] * theta^(-2k / d_a), evaluated in float64 as diffusers does, stored as fp32.
+__global__ void rope_table_kernel(const float* __restrict__ ids, int S, int d0, int d1, int d2, double theta, float* __restrict__ cosp,
+                                  float* __restrict__ sinp) {
+  const int D = d0 + d1 + d2;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)S * D) return;
+  const int s = (int)(i / D), c = (int)(i - (long long)s * D);
+  int a = 0, start = 0, d = d0;
+  if (c >= d0 + d1) a = 2, start = d0 + d1, d = d2;
+  else if (c >= d0) a = 1, start = d0, d = d1;
+  const int k = (c - start) >> 1;
+  const double freq = 1.0 / pow(theta, (double)(2 * k) / (double)d);
+  const double ang = (double)ids[(long long)s * 3 + a] * freq;
+  cosp[i] = (float)cos(ang);
+  sinp[i] = (float)sin(ang);
+}
+
 __global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ eps, long long n8, const float* __restrict__ dt) {
   const float d = dt[0];
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
@@ -373,6 +391,15 @@ int x2i_launch_timestep_sinusoid(const float* t, float* out, int B, int dim, int
   if (!t || !out || B <= 0 || dim <= 0 || dim % 2) return x2i_set_error(X2I_ERR_ARG, "timestep_sinusoid: bad argument");
   hipLaunchKernelGGL(sinusoid_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, stream, t, out, B, dim, round_bf16);
   return x2i_check_launch("timestep_sinusoid");
+}
+
+int x2i_launch_rope_table(const float* ids, int S, int d0, int d1, int d2, float theta, float* cosp, float* sinp, hipStream_t stream) {
+  if (!ids || !cosp || !sinp || S <= 0) return x2i_set_error(X2I_ERR_ARG, "rope_table: bad argument");
+  if (d0 < 0 || d1 < 0 || d2 < 0 || (d0 | d1 | d2) & 1 || d0 + d1 + d2 <= 0 || theta <= 0.f)
+    return x2i_set_error(X2I_ERR_SHAPE, "rope_table: axis dims must be even and non-negative (%d,%d,%d)", d0, d1, d2);
+  const long long n = (long long)S * (d0 + d1 + d2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, S, d0, d1, d2, (double)theta, cosp, sinp);
+  return x2i_check_launch("rope_table");
 }
 
 int x2i_launch_euler_step(void* x, const void* eps, long long n, const float* dt, hipStream_t stream) {

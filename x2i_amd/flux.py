@@ -264,9 +264,9 @@ class FluxTransformer2DModel(nn.Module):
         # context_embedder -> text rows of X (kept in CTX so that X can be rebuilt every step)
         ctx = torch.empty((B, St, D), device=self.device, dtype=torch.bfloat16)
         ops.gemm(enc, f["context_embedder.w"], f["context_embedder.b"], out=ctx, M=B * St)
-        # RoPE tables: FluxPosEmbed semantics (float64 frequencies), computed once with torch on the device
+        # RoPE tables: FluxPosEmbed semantics (float64 frequencies), once per prompt
         ids = torch.cat((txt_ids.to(self.device), img_ids.to(self.device)), dim=0)
-        cos, sin = _flux_pos_embed(ids, cfg.axes_dims_rope)
+        cos, sin = ops.rope_table(ids, cfg.axes_dims_rope)  # FluxPosEmbed, once per prompt (x2i_rope_table_f32)
         # conditioning: text_embedder(pooled) [+ guidance_embedder(guidance*1000)]
         cond = ws["COND"]
         pooled = pooled_projections.to(device=self.device, dtype=torch.bfloat16).contiguous()
@@ -448,16 +448,3 @@ class _Config(dict):
 class Transformer2DModelOutput:
     def __init__(self, sample):
         self.sample = sample
-
-
-def _flux_pos_embed(ids, axes_dim, theta=10000):
-    """FluxPosEmbed: float64 frequencies, repeat-interleaved, returned as fp32 [S,128].
-    Step-invariant table built once per prompt with torch on the device (host plumbing, not a hot kernel)."""
-    pos = ids.float()
-    cos_out, sin_out = [], []
-    for i, d in enumerate(axes_dim):
-        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=ids.device)[: d // 2] / d))
-        ang = torch.outer(pos[:, i].to(torch.float64), freqs)
-        cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
-        sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
-    return torch.cat(cos_out, dim=-1).contiguous(), torch.cat(sin_out, dim=-1).contiguous()

@@ -160,6 +160,19 @@ def timestep_sinusoid(t, dim, round_bf16=False):
     return out
 
 
+def rope_table(ids, axes_dim, theta=10000.0):
+    """ids: f32 [S,3] -> (cos, sin) f32 [S, sum(axes_dim)] (FluxPosEmbed; float64 inside the kernel)."""
+    lib = _lib.load()
+    ids = ids.to(torch.float32).contiguous()
+    _req(ids, torch.float32, "ids")
+    d0, d1, d2 = (list(axes_dim) + [0, 0, 0])[:3]
+    S = ids.shape[0]
+    cos = torch.empty((S, d0 + d1 + d2), device=ids.device, dtype=torch.float32)
+    sin = torch.empty_like(cos)
+    check(lib.x2i_rope_table_f32(_p(ids), S, d0, d1, d2, float(theta), _p(cos), _p(sin), _stream()), "rope_table")
+    return cos, sin
+
+
 def euler_step_(x, eps, dt):
     """x <- bf16(f32(x) + dt * f32(eps)) in place; dt is a 1-element f32 DEVICE tensor."""
     lib = _lib.load()
