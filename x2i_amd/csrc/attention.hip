@@ -125,16 +125,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     const char* kb = smem + buf * (KTILE + VTILE);
     const char* vb = kb + KTILE;
 
-    // ---- S^T = K Q^T : two 32-key sub-tiles
+    // ---- S^T = K Q^T : two 32-key sub-tiles.  K fragments are read in groups of four, one group ahead of the MFMAs that
+    // consume them (hipcc otherwise serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per fragment); consecutive MFMAs
+    // alternate between the two sub-tile accumulators.  Fragment f of group g: ds = 2*g + (f>>1), sub-tile u = f & 1.
     f32x16_t sacc[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+    {
+      bf16x8_t kf[2][4];
+      auto kload = [&](int g, int f) {
+        const int ds = 2 * g + (f >> 1), u = f & 1;
+        return *(const bf16x8_t*)(kb + u * 32 * 256 + k_row_off + (((ds * 2 + hi) ^ k_swz) << 4));
+      };
 #pragma unroll
-      for (int ds = 0; ds < 8; ++ds) {
-        const bf16x8_t kf = *(const bf16x8_t*)(kb + u * 32 * 256 + k_row_off + (((ds * 2 + hi) ^ k_swz) << 4));
-        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[u], 0, 0, 0);
+      for (int f = 0; f < 4; ++f) kf[0][f] = kload(0, f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < 3) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f) kf[(g + 1) & 1][f] = kload(g + 1, f);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          sacc[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g & 1][f], qf[2 * g + (f >> 1)], sacc[f & 1], 0, 0, 0);
+        if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the next group's 4 DS reads first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);             // ... then this group's 4 MFMAs
       }
     }
     // lane (q = li, hi), sub-tile u, reg r  <->  key = kv0 + u*32 + 16*(r>>3) + 8*hi + (r&7)
@@ -197,16 +214,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
         for (int j = 0; j < 4; ++j) cv.w[j] = pack_bf16x2(sacc[u][kt * 8 + 2 * j], sacc[u][kt * 8 + 2 * j + 1]);
         pf[u][kt] = cv.v;
       }
-    // ---- O^T += V^T P^T
+    // ---- O^T += V^T P^T : same one-group-ahead fragment pipeline; group g = (u, kt) feeds the four d-block accumulators
+    {
+      bf16x8_t vf[2][4];
+      auto vload = [&](int g, int db) {
+        const int u = g >> 1, kt = g & 1;
+        return *(const bf16x8_t*)(vb + db * 32 * 128 + v_row_off + (((4 * u + 2 * kt + hi) ^ v_swz) << 4));
+      };
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db) vf[0][db] = vload(0, db);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int g = 0; g < 4; ++g) {
+        if (g < 3) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          const bf16x8_t vf = *(const bf16x8_t*)(vb + db * 32 * 128 + v_row_off + (((4 * u + 2 * kt + hi) ^ v_swz) << 4));
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u][kt], oacc[db], 0, 0, 0);
+          for (int db = 0; db < 4; ++db) vf[(g + 1) & 1][db] = vload(g + 1, db);
         }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g & 1][db], pf[g >> 1][g & 1], oacc[db], 0, 0, 0);
+        if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+    }
 
     if (!((ABL & 2) && t > 0)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA (issued by this wave) has landed
