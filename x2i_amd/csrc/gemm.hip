@@ -546,9 +546,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // all tiles but the last stage their successor unconditionally (one basic block per K-step); the last one only computes
+  auto ktile = [&](int kt, auto stage_next) {
     char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
-    if (kt + 1 < nk) {
+    if constexpr (decltype(stage_next)::value) {
       char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
       const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
       if (CONV) conv_offsets();
@@ -572,7 +573,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed
     __syncthreads();                                  // ... everyone's has, and everyone is done reading `cur`
-  }
+  };
+  for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
+  ktile(nk - 1, std::false_type{});
 
   if constexpr (ACT == X2I_ACT_NONE && !RES && !OUTF32 && !HASC2 && !CONV) {
     if (p.q_on) {
@@ -707,10 +710,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) af[0][i] = *(const bf16x8_t*)(smem + 0 * UNIT_BYTES + a_base + i * 1024);
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K-tile (4 phases).  STEADY = not one of the last two tiles: every unit issue and every wait is unconditional, so the
+  // whole tile is ONE basic block and the compiler is free to place the DMA pieces and LDS reads among the MFMAs.
+  auto ktile = [&](int kt, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value;
     const char* cur = smem + (kt & 1) * TILE2_BYTES;
     const char* nxt = smem + ((kt + 1) & 1) * TILE2_BYTES;
-    const bool more = (kt + 1 < nk);
+    const bool more = STEADY || (kt + 1 < nk);
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
       const int G = 4 * kt + ph;
@@ -720,13 +726,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
         // landed for every wave; units issued so far = G-1+LEAD, needed = G+2
         const bool need = (ph == 1) || more;
         if (need && !((ABL & 2) && kt > 0)) {
-          const int last_issued = min(G - 1 + LEAD, total_units - 1);
-          wait_units_in_flight(last_issued - (G + 2));
+          if constexpr (STEADY) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          } else {
+            const int last_issued = min(G - 1 + LEAD, total_units - 1);
+            wait_units_in_flight(last_issued - (G + 2));
+          }
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
         }
       }
-      if (G + LEAD < total_units) issue_unit(G + LEAD);
+      if (STEADY || G + LEAD < total_units) issue_unit(G + LEAD);
       // ---- LDS -> registers for phase G+1
       if (!((ABL & 1) && kt > 0)) {
         if (ph == 0) {
@@ -766,6 +776,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
         }
       }
     }
+  };
+  {
+    int kt = 0;
+    if (!(ABL & (7 | 128))) {  // ABL 128: A/B switch, run every tile through the general (branchy) form
+      for (; kt < nk - 2; ++kt) ktile(kt, std::true_type{});
+    }
+    for (; kt < nk; ++kt) ktile(kt, std::false_type{});
   }
   if (ABL & 8) {  // ablation: no epilogue (keep the accumulators alive with one predicated store)
     float sacc = 0.f;
@@ -914,6 +931,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     if (abl == 16) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 16>;
     if (abl == 32) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 32>;
     if (abl == 48) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 48>;
+    if (abl == 128) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 128>;
   }
   const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
   const int force = force_env ? atoi(force_env) : 0;
