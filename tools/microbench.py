@@ -58,7 +58,8 @@ def main():
         t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention[{nm}] B={B} H={H} S={S}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
     os.environ.pop("X2I_ATTN_VARIANT")
-    for abl, nm in (("0", "full"), ("1", "no softmax"), ("2", "no barrier/wait"), ("4", "no DMA"), ("7", "MFMA+LDS reads only"), ("0", "full")):
+    for abl, nm in (("0", "full"), ("1", "no softmax"), ("2", "no barrier/wait"), ("4", "no DMA"), ("7", "MFMA+LDS reads only"), ("0", "full"),
+                    ("32", "branchy loop (no peel)"), ("0", "full"), ("32", "branchy loop (no peel)"), ("0", "full")):
         os.environ["X2I_ATTN_ABLATE"] = abl
         t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention-ablate[{nm}]: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")

@@ -119,9 +119,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  // One key/value tile.  LAST = false: a successor tile exists and every key is valid, so the prefetch and the score path
+  // carry no branches (one basic block up to the rescale test); the final tile handles the ragged tail.
+  auto kv_tile = [&](int t, auto last_c) {
+    constexpr int MODE = decltype(last_c)::value;  // 0 steady, 1 last, 2 general (runtime tests; A/B reference, ABL & 32)
+    constexpr bool LAST = MODE != 0;
     const int buf = t & 1;
-    if (t + 1 < ntiles && !((ABL & 4) && t > 0)) stage(buf ^ 1, (t + 1) * KVB);
+    if ((MODE == 0 || (MODE == 2 && t + 1 < ntiles)) && !((ABL & 4) && t > 0)) stage(buf ^ 1, (t + 1) * KVB);
     const char* kb = smem + buf * (KTILE + VTILE);
     const char* vb = kb + KTILE;
 
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     }
     // lane (q = li, hi), sub-tile u, reg r  <->  key = kv0 + u*32 + 16*(r>>3) + 8*hi + (r&7)
     const int kv0 = t * KVB;
-    if (kv0 + KVB > S) {  // ragged last tile: mask keys >= S
+    if (LAST && kv0 + KVB > S) {  // ragged last tile: mask keys >= S
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -241,6 +245,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA (issued by this wave) has landed
       __syncthreads();
     }
+  };
+  if (ABL & 32) {
+    for (int t = 0; t < ntiles; ++t) kv_tile(t, std::integral_constant<int, 2>{});
+  } else {
+    for (int t = 0; t < ntiles - 1; ++t) kv_tile(t, std::integral_constant<int, 0>{});
+    kv_tile(ntiles - 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (q = li, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
@@ -311,6 +321,7 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   else if (abl == 2) X2I_ATTN_LAUNCH_ABL(2)
   else if (abl == 4) X2I_ATTN_LAUNCH_ABL(4)
   else if (abl == 7) X2I_ATTN_LAUNCH_ABL(7)
+  else if (abl == 32) X2I_ATTN_LAUNCH_ABL(32)
   else if (var == 1) X2I_ATTN_LAUNCH(8, 8)
   else if (var == 2) X2I_ATTN_LAUNCH(4, 0)
   else if (var == 3) X2I_ATTN_LAUNCH(8, 0)
