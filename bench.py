@@ -64,7 +64,7 @@ def gemm_roofline(B, iters=10):
     # HBM-side traffic of the same two launches from the committed rocprofv3 PMC pass (tools/pmc_collect.sh; FETCH_SIZE
     # doubled per the gfx950 correction, + WRITE_SIZE).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r01e_pmc_gemm_attn.json")
+    pj = os.path.join(ROOT, "profiles", "r01f_pmc_gemm_attn.json")
     if B == 4 and os.path.exists(pj):
         d = json.load(open(pj))
         # the launcher peels the last partly filled round of 256^2 tiles into a 128^2 launch: four kernels for the two GEMMs
@@ -72,7 +72,7 @@ def gemm_roofline(B, iters=10):
                  "gemm256_bf16_kernel<0, false, false, false, 0> grid=393216", "gemm_bf16_kernel<0, false, false, false, false> grid=98304")
         try:
             traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"] for k in grids)
-            src = ("profiles/r01e_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
+            src = ("profiles/r01f_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
                    "boundary for both GEMMs incl. their peeled 128x128 tail launches)")
         except KeyError:
             traffic = None
