@@ -133,3 +133,50 @@ def test_vae_decoder_parameter_tree_and_oracle_known_answers():
     y = OV.vae_decode(sd, torch.randn(1, 16, 4, 4), cfg)
     assert y.shape == (1, 3, 32, 32)
     assert torch.allclose(y, sd["decoder.conv_out.bias"].view(1, 3, 1, 1).expand_as(y))
+
+
+def test_c_abi_argument_validation_returns_codes_without_a_gpu():
+    """Every entry point validates its arguments before touching HIP: bad shapes / null pointers come back as negative
+    status codes with a message in x2i_last_error() (include/x2i.h error contract) -- never a crash, never a launch."""
+    import ctypes as C
+    from x2i_amd import _lib
+    lib = _lib.load()
+    lib.x2i_last_error.restype = C.c_char_p
+    fake = C.c_void_p(0x1000)  # never dereferenced: validation fails first
+
+    a = _lib.GemmArgs()
+    assert lib.x2i_gemm_bf16(C.byref(a), None) < 0 and b"null" in lib.x2i_last_error()
+    a.A, a.W, a.C = 0x1000, 0x1000, 0x1000
+    a.M, a.N, a.K, a.batch = 0, 128, 64, 1
+    assert lib.x2i_gemm_bf16(C.byref(a), None) < 0 and b"shape" in lib.x2i_last_error()
+    a.M = 128
+    a.gate = 0x1000  # gate without residual
+    assert lib.x2i_gemm_bf16(C.byref(a), None) < 0 and b"gate" in lib.x2i_last_error()
+
+    a = _lib.GemmArgs()
+    a.A, a.W, a.M, a.N, a.K, a.batch = 0x1000, 0x1000, 256, 3 * 2 * 128 + 8, 64, 1
+    q = _lib.QkvDesc()
+    q.norm_q = q.norm_k = q.cos = q.sin = q.Q = q.K = q.VT = 0x1000
+    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps = 2, 256, 0, 256, 1e-6
+    assert lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), None) < 0 and b"3*H*128" in lib.x2i_last_error()
+    a.N = 3 * 2 * 128
+    q.Spad = 200
+    assert lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), None) < 0 and b"geometry" in lib.x2i_last_error()
+    q.Spad, a.act = 256, 1
+    assert lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), None) < 0 and b"plain bias" in lib.x2i_last_error()
+    assert lib.x2i_gemm_qkv_bf16(C.byref(a), None, None) < 0
+
+    cd = _lib.ConvDesc(H=8, W=8, Cin=48, KH=3, KW=3, stride=1, pad=1, up=0)
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C, a.M, a.N, a.K, a.batch = 0x1000, 0x1000, 0x1000, 64, 64, 9 * 48, 1
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"multiple of 64" in lib.x2i_last_error()
+
+    assert lib.x2i_attention_bf16(fake, fake, fake, fake, 1, 1, 100, 100, 128, 12800, 0.1, None) < 0  # Spad % 128
+    assert lib.x2i_qkv_split_bf16(None, fake, 384, 384, 1, 64, 0, 1, None, None, fake, fake, fake, fake, fake, fake, fake, 100, 1e-6, None) < 0
+    assert lib.x2i_groupnorm_nhwc_bf16(fake, fake, 1, 64, 60, 4, fake, fake, 1e-5, 0, None, None, fake, None) < 0  # C % 8
+    assert lib.x2i_softmax_rows_bf16(fake, 4, 12, 1.0, None) < 0  # cols % 8
+    assert lib.x2i_skinny_linear(fake, 0, fake, None, fake, 8, 1, 8, 12, 0, 0, 0, None) < 0  # K % 8
+    assert lib.x2i_rope_table_f32(fake, 8, 16, 55, 56, 10000.0, fake, fake, None) < 0  # odd axis width
+    assert lib.x2i_timestep_sinusoid(fake, fake, 1, 255, 0, None) < 0
+    assert lib.x2i_conv_stem_bf16(None, None, None, None, 1, 8, 8, 64, None) < 0
+    assert lib.x2i_abi_version() >= 1
