@@ -687,7 +687,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
     if ((ABL & 4) && u >= LEAD) return;
     const int t = u >> 2, pu = u & 3;
     char* dst = smem + (u & 7) * UNIT_BYTES;
-    const uint32_t koff = (uint32_t)(t * BK + (pu >> 1) * 32) * 2;
+    // ABL 256: every unit re-reads k = 0 (cache-hot source) -- separates "data arrives late" from "issue / LDS-write cost"
+    const uint32_t koff = (ABL & 256) ? 0u : (uint32_t)(t * BK + (pu >> 1) * 32) * 2;
     if (pu & 1) stage_unit(w_rsrc, dst, w_voff, koff, wave);
     else stage_unit(a_rsrc, dst, a_voff, koff, wave);
   };
@@ -932,6 +933,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     if (abl == 32) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 32>;
     if (abl == 48) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 48>;
     if (abl == 128) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 128>;
+    if (abl == 256) kern2 = gemm256_bf16_kernel<X2I_ACT_NONE, false, false, false, 256>;
   }
   const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
   const int force = force_env ? atoi(force_env) : 0;
