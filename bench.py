@@ -64,21 +64,21 @@ def gemm_roofline(B, iters=10):
     # HBM-side traffic of the same two launches from the committed rocprofv3 PMC pass (tools/pmc_collect.sh; FETCH_SIZE
     # doubled per the gfx950 correction, + WRITE_SIZE).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r01f_pmc_gemm_attn.json")
+    pj = os.path.join(ROOT, "profiles", "r01g_pmc_gemm_attn.json")
     if B == 4 and os.path.exists(pj):
         d = json.load(open(pj))
         # the launcher peels the last partly filled round of 256^2 tiles into a 128^2 launch: four kernels for the two GEMMs
-        grids = ("gemm256_bf16_kernel<0, false, false, false, 0> grid=3010560", "gemm_bf16_kernel<0, false, false, false, false> grid=172032",
-                 "gemm256_bf16_kernel<0, false, false, false, 0> grid=393216", "gemm_bf16_kernel<0, false, false, false, false> grid=98304")
+        grids = ("gemm256l_bf16_kernel<0, false, false, false> grid=3010560", "gemm_bf16_kernel<0, false, false, false, false> grid=172032",
+                 "gemm256l_bf16_kernel<0, false, false, false> grid=393216", "gemm_bf16_kernel<0, false, false, false, false> grid=98304")
         try:
             traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"] for k in grids)
-            src = ("profiles/r01f_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
+            src = ("profiles/r01g_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
                    "boundary for both GEMMs incl. their peeled 128x128 tail launches)")
         except KeyError:
             traffic = None
     alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K) in ((B * S, 7 * D, D), (B * S, D, 5 * D)))
     return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_BF16,
-                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256_bf16_kernel",
+                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256l_bf16_kernel",
                 shapes="M=%d: N=21504,K=3072 + N=3072,K=15360 (single-block in/out GEMMs, 2.44 + 1.74 TFLOP)" % (B * S))
 
 
