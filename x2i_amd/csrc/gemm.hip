@@ -42,6 +42,7 @@ struct GemmP {
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0;
+  int gm;
   float q_eps;
   const bf16_t *q_nq, *q_nk;
   const float *q_cos, *q_sin;
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
     const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  constexpr int GM = 4;
+  const int GM = p.gm;  // tile-rows per group: the XCD's 32 concurrent tiles form a GM x 32/GM patch (chosen by the launcher)
   const int per_group = GM * p.tilesN;
   const int group = bid / per_group;
   const int first_m = group * GM;
@@ -1026,6 +1027,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
   p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
+  p.gm = 4;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   if (qd) {
@@ -1121,6 +1123,16 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       if (tm_fit >= 1 && tm_fit < tm_all) tm_main = (int)tm_fit;
     }
     GemmP pm = p;
+    {
+      // Patch shape per XCD (measured, profiles/r01g_gm_sweep.log): few tile columns and a deep K -> one tile row at a time, so
+      // the XCD's concurrent tiles share each A panel and it leaves HBM once; otherwise near-square patches (6 x 5.3) keep
+      // the L2 traffic per K-step lowest; very wide N prefers two rows.
+      const char* ge = getenv("X2I_GEMM_GM");
+      if (ge && atoi(ge) > 0) pm.gm = atoi(ge);
+      else if (tn <= 16) pm.gm = a->K >= 8192 ? 1 : 4;
+      else if (tn <= 64) pm.gm = 6;
+      else pm.gm = 2;
+    }
     pm.M = (tm_main < tm_all) ? tm_main * BM2 : a->M;
     pm.tilesM = tm_main; pm.tilesN = tn;
     hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(512), SMEM2_BYTES, stream, pm);
