@@ -10,11 +10,11 @@ def rnd(*s, scale=1.0):
     return (torch.randn(*s, device="cuda") * scale).bfloat16()
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "gemm"):
-    for (M, N, K) in [(B * S, 7 * D, D), (B * S, D, 5 * D), (B * 4096, 3 * D, D)]:
+    for (M, N, K, act) in [(B * S, 4 * D, D, 1), (B * S, D, 5 * D, 0), (B * 4096, 3 * D, D, 0)]:
         A, W, b = rnd(M, K), rnd(N, K, scale=0.02), rnd(N)
         out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
         for _ in range(3):
-            ops.gemm(A, W, b, out=out)
+            ops.gemm(A, W, b, out=out, act=act)
         torch.cuda.synchronize()
 if which in ("all", "attn"):
     Spad = ops.pad128(S)
