@@ -1096,13 +1096,14 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
   const int force = force_env ? atoi(force_env) : 0;
   const long long tiles256 = (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) * a->batch;
-  bool use256 = !conv && tiles256 >= 768 && a->M >= 256 && a->N >= 256;  // >= 3 full rounds of 256 CUs, else 128^2 tiles fill better
-  // small-batch exception (measured at B = 1, 2): with a deep K the 256^2 pipeline also wins when its one or two rounds
-  // are well filled (single-block out-projection: 216 / 432 tiles, +16 % / +21 % over the 128^2 kernel)
-  if (!conv && !use256 && a->K >= 12288 && tiles256 >= 192 && a->M >= 256 && a->N >= 256) {
-    const long long rem = tiles256 % 256;
-    use256 = tiles256 <= 256 || rem == 0 || rem >= 176;
-  }
+  // Tile choice (re-measured with the full-line staging kernel, B = 1, 2, 4): the 256^2 kernel wins from about half a round
+  // of tiles upwards (1.0-1.38 PF against 0.8-1.0 PF for 128^2 tiles), also when its last round is partly filled; only
+  // launches with very few tiles or few rows per batch item (text stream) fill the GPU better with 128^2 tiles.  The
+  // threshold can be moved with X2I_GEMM_MIN256 for A/B runs.
+  long long min256 = 128;
+  if (const char* me = getenv("X2I_GEMM_MIN256")) min256 = atoll(me);
+  // batched launches with few rows per item (text stream, 512 rows per sample) keep 128^2 tiles below three full rounds
+  bool use256 = !conv && a->N >= 256 && (tiles256 >= 768 ? a->M >= 256 : (tiles256 >= min256 && a->M >= 1024));
   if (force == 128) use256 = false;
   if (force == 256) use256 = true;
   if (qd && (qd->H * 128) % BN2) use256 = false;  // a 256-column tile must not straddle the q / k / v sections
