@@ -39,11 +39,14 @@ def test_gemm_plain_bias(ops, M, N, K):
     assert rel_l2(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("tile", ["128", "256", "256k"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (700, 520, 320), (1024, 1024, 3072)])
 def test_gemm_both_tile_kernels(ops, monkeypatch, tile, M, N, K):
-    """Force the 128x128 and the 256x256 pipelined kernels on the same problems (ragged edges, 1..48 K-tiles)."""
-    monkeypatch.setenv("X2I_GEMM_TILE", tile)
+    """Force the 128x128 kernel, the 256x256 full-line staging kernel and its k-half-unit predecessor ("256k", kept for the
+    ablation hooks) on the same problems (ragged edges, 1..48 K-tiles)."""
+    monkeypatch.setenv("X2I_GEMM_TILE", tile[:3])
+    if tile == "256k":
+        monkeypatch.setenv("X2I_GEMM_LFORM", "0")
     A, W, b = bf(seeded((M, K), 40)), bf(seeded((N, K), 41, 0.05)), bf(seeded((N,), 42))
     res = bf(seeded((M, N), 43))
     gate = seeded((1, N), 44)
