@@ -825,7 +825,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(GemmP p) {
 // double buffer -- the whole next tile (4 A + 4 W pieces per wave) is issued during phases 0 and 1 and must have landed
 // by the barrier at phase 3, where its first fragments are read; one barrier per K-tile.
 // ------------------------------------------------------------------------------------------------------------
-template <int ACT, bool RES, bool OUTF32, bool HASC2>
+// CONV = true: A is the implicit-GEMM gather of an NHWC image (one filter tap x 64 channels per K-tile, exactly one 128-byte
+// line per output pixel and piece row), as in the 128^2 kernel; used for the convolutions with >= 256 output channels.
+template <int ACT, bool RES, bool OUTF32, bool HASC2, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A image 32 KiB | W image 32 KiB]
   const int tid = threadIdx.x;
@@ -850,13 +852,15 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
   const int m0 = tm * BM2, n0 = tn * BN2;
 
   const bf16_t* Az = p.A + (long long)z * p.a_bs;
-  const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t a_bytes = CONV ? (uint32_t)((long long)p.cH * p.cW * p.cCin * 2) : (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)z * p.w_bs), 0, w_bytes, 0x00020000);
 
   // piece q = jj*8 + wave (jj = 0..3) covers row group q (rows 8q..8q+7); lane -> (k-half, row in group, physical chunk)
   uint32_t a_voff[4], w_voff[4];
+  int c_base[4], c_oy[4], c_ox[4];  // CONV: byte offset of tap (0,0) for this lane's (pixel, channel chunk); pixel origin
+  uint32_t c_mask[4];               // CONV: bit (ky*KW + kx) = tap lies inside the image
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     const int g = jj * 8 + wave;
@@ -865,7 +869,27 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
     const int kel = khl * 32 + ((cphys ^ (3 * (g & 1))) << 3);
     a_voff[jj] = (m0 + row < p.M) ? (uint32_t)(((long long)(m0 + row) * p.lda + kel) * 2) : 0x80000000u;
     w_voff[jj] = (n0 + row < p.N) ? (uint32_t)(((long long)(n0 + row) * p.ldw + kel) * 2) : 0x80000000u;
+    if constexpr (CONV) {
+      const int m = m0 + row;
+      const int oy = m / p.cOW, ox = m - oy * p.cOW;
+      c_oy[jj] = oy * p.cStride - p.cPad;
+      c_ox[jj] = ox * p.cStride - p.cPad;
+      c_base[jj] = ((c_oy[jj] * p.cW + c_ox[jj]) * p.cCin + kel) * 2;
+      uint32_t mask = 0;
+      if (m < p.M) {
+        const int KH = p.K / (p.cKW * p.cCin);
+        for (int ky = 0; ky < KH; ++ky)
+          for (int kx = 0; kx < p.cKW; ++kx) {
+            const int iy = c_oy[jj] + ky, ix = c_ox[jj] + kx;
+            if (iy >= 0 && iy < (p.cH << p.cUp) && ix >= 0 && ix < (p.cW << p.cUp)) mask |= 1u << (ky * p.cKW + kx);
+          }
+      }
+      c_mask[jj] = mask;
+      c_base[jj] -= kel * 2;  // keep the chunk offset separate: the x2-upsample form rebuilds the pixel part
+    }
   }
+  const int c_kel = ((lane >> 5) * 32 + (((lane & 3) ^ (3 * (wave & 1))) << 3)) * 2;  // CONV: this lane's channel-chunk bytes
+  int s_ky = 0, s_kx = 0, s_c0 = 0;  // CONV: tap / channel slice of the next K-tile to stage (tiles are staged in order)
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -882,10 +906,32 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
   const int nk = p.K / BK;
   auto issue_a = [&](int t) {
     char* dst = smem + (t & 1) * TILE2_BYTES;
+    if constexpr (CONV) {
+      const int tap = s_ky * p.cKW + s_kx;
+      if (p.cUp) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int iy = c_oy[jj] + s_ky, ix = c_ox[jj] + s_kx;
+          a_voff[jj] = ((c_mask[jj] >> tap) & 1) ? (uint32_t)((((iy >> 1) * p.cW + (ix >> 1)) * p.cCin + s_c0) * 2 + c_kel) : 0x80000000u;
+        }
+      } else {
+        const int toff = ((s_ky * p.cW + s_kx) * p.cCin + s_c0) * 2 + c_kel;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) a_voff[jj] = ((c_mask[jj] >> tap) & 1) ? (uint32_t)(c_base[jj] + toff) : 0x80000000u;
+      }
+      s_c0 += BK;
+      if (s_c0 >= p.cCin) {
+        s_c0 = 0;
+        if (++s_kx == p.cKW) {
+          s_kx = 0;
+          ++s_ky;
+        }
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(dst + (jj * 8 + wave) * 1024), 16,
-                                               a_voff[jj], (uint32_t)(t * BK) * 2, 0, 0);
+                                               a_voff[jj], CONV ? 0u : (uint32_t)(t * BK) * 2, 0, 0);
   };
   auto issue_w = [&](int t) {
     char* dst = smem + (t & 1) * TILE2_BYTES + 32768;
@@ -947,7 +993,7 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
 
-  if constexpr (ACT == X2I_ACT_NONE && !RES && !OUTF32 && !HASC2) {
+  if constexpr (ACT == X2I_ACT_NONE && !RES && !OUTF32 && !HASC2 && !CONV) {
     if (p.q_on) {
       __syncthreads();
       epilogue_qkv<8, 4, 512>(p, acc, z, m0, n0, wm, wn, lane, tid, smem);
@@ -1058,7 +1104,8 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     kern = conv ? gemm_bf16_kernel<A_, R_, F_, C_, true>               \
                 : gemm_bf16_kernel<A_, R_, F_, C_, false>;             \
     kern2 = gemm256_bf16_kernel<A_, R_, F_, C_>;                       \
-    kern2l = gemm256l_bf16_kernel<A_, R_, F_, C_>;                     \
+    kern2l = conv ? gemm256l_bf16_kernel<A_, R_, F_, C_, true>         \
+                  : gemm256l_bf16_kernel<A_, R_, F_, C_, false>;       \
   }
   if (!res && !f32 && !c2) {
     switch (p.act) {
@@ -1092,6 +1139,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   {  // the full-line staging form is the product kernel; X2I_GEMM_LFORM=0 selects the k-half-unit form (A/B, ablations)
     const char* lf = getenv("X2I_GEMM_LFORM");
     if (!(lf && atoi(lf) == 0) && !getenv("X2I_GEMM_ABLATE") && kern2l) kern2 = kern2l;
+    else if (conv) kern2 = nullptr;  // only the full-line kernel has the convolution gather
   }
   const char* force_env = getenv("X2I_GEMM_TILE");  // "128" / "256": debugging and A/B benchmarking override
   const int force = force_env ? atoi(force_env) : 0;
@@ -1104,8 +1152,13 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   if (const char* me = getenv("X2I_GEMM_MIN256")) min256 = atoll(me);
   // batched launches with few rows per item (text stream, 512 rows per sample) keep 128^2 tiles below three full rounds
   bool use256 = !conv && a->N >= 256 && (tiles256 >= 768 ? a->M >= 256 : (tiles256 >= min256 && a->M >= 1024));
+  // convolutions with >= 256 output channels: the full-line kernel's implicit-GEMM form (X2I_CONV256=0: 128^2 tiles, A/B)
+  bool conv256 = false;
+  if (conv && a->N >= 256 && a->N % 8 == 0 && tiles256 >= min256 && a->M >= 1024 && !(getenv("X2I_CONV256") && atoi(getenv("X2I_CONV256")) == 0))
+    conv256 = use256 = true;
   if (force == 128) use256 = false;
-  if (force == 256) use256 = true;
+  if (force == 256 && !conv) use256 = true;
+  if (conv && (!conv256 || !kern2)) use256 = false;
   if (qd && (qd->H * 128) % BN2) use256 = false;  // a 256-column tile must not straddle the q / k / v sections
   if (qd && !(fast && kern)) return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv: K %% 64 == 0 and 16-byte aligned operands required");
   if (fast && kern && use256) {
@@ -1119,7 +1172,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     const long long per_row = (long long)tn * a->batch;
     const long long full_rounds = tiles256 / 256, rem = tiles256 % 256;
     int tm_main = tm_all;
-    if (force == 0 && full_rounds >= 1 && rem > 0 && rem <= 160 && !getenv("X2I_GEMM_NOSPLIT")) {
+    if (force == 0 && !conv && full_rounds >= 1 && rem > 0 && rem <= 160 && !getenv("X2I_GEMM_NOSPLIT")) {
       const long long tm_fit = (full_rounds * 256) / per_row;
       if (tm_fit >= 1 && tm_fit < tm_all) tm_main = (int)tm_fit;
     }
