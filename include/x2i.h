@@ -12,8 +12,12 @@
  *   - bf16 tensors are raw uint16 storage; "f32" means IEEE float
  *   - every function returns 0 on success, a negative X2I_ERR_* code otherwise; x2i_last_error() returns a
  *     thread-local message.  Nothing exits or throws across the boundary.
- *   - one process per GPU; no global mutable state except per-handle objects (x2i_flux_*), which are not
- *     re-entrant
+ *   - one process per GPU.  The library is STATELESS: there are no model handles, no weight packing step and no
+ *     library-owned workspace (SURVEY.md section 8(b) sketched x2i_create / x2i_pack_weights / a workspace-size query;
+ *     they were dropped on purpose -- weights are consumed in the reference's own nn.Linear [N,K] layout, fused only by
+ *     row-concatenation on the host side, and every scratch buffer is a caller-owned argument, e.g.
+ *     x2i_groupnorm_scratch_floats).  The only process-wide state is the option table below and a per-kernel
+ *     "dynamic LDS size already raised" cache; both are mutex-protected.
  */
 #ifndef X2I_H
 #define X2I_H
@@ -42,6 +46,19 @@ typedef void* x2i_stream_t;
 
 int x2i_abi_version(void);
 const char* x2i_last_error(void);
+
+/* A/B and tuning switches.  Defaults are the product configuration; each option is initialised ONCE (first use) from the
+ * environment variable X2I_<NAME> and afterwards only changes through x2i_set_option -- nothing on the launch path reads
+ * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
+ * "conv256" (1), "attn_variant" (0), "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
+ * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
+ * return X2I_ERR_ARG.  Every setting selects between
+ * kernels with identical results (bit-identical where the tests say so); the measurement-only kernels ("wrong results by
+ * design" ablations) are NOT in this library -- they are compiled only into libx2i_hip_ablate.so (-DX2I_ABLATION), where
+ * x2i_is_ablation_build() returns 1 and the extra options "gemm_lform", "gemm_ablate", "attn_ablate" exist. */
+int x2i_set_option(const char* name, int64_t value);
+int x2i_get_option(const char* name, int64_t* value);
+int x2i_is_ablation_build(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * nn.Linear with fused epilogue.   C[z] = epi(A[z] W^T)

@@ -24,9 +24,38 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/x2i.h but not exported by libx2i_hip.so"
-    bound = set(_lib.SIGNATURES) | {"x2i_abi_version", "x2i_last_error"}
+    bound = set(_lib.SIGNATURES) | {"x2i_abi_version", "x2i_last_error", "x2i_is_ablation_build"}
     assert declared == bound, (declared ^ bound)
     assert lib.x2i_abi_version() == 1
+
+
+def test_options_are_resolved_once_and_product_library_has_no_ablation_kernels():
+    """include/x2i.h: x2i_set_option / x2i_get_option; the "wrong results by design" kernels live only in the measurement build."""
+    from x2i_amd import _lib
+    from x2i_amd._lib import X2IError
+    lib = _lib.load()
+    assert os.path.basename(_lib.LIB_PATH) == "libx2i_hip.so" and lib.x2i_is_ablation_build() == 0
+    assert _lib.get_option("gemm_tile") == 0 and _lib.get_option("gemm_min256") == 128 and _lib.get_option("conv256") == 1
+    os.environ["X2I_GEMM_TILE"] = "128"  # the environment is read once (first use): changing it now has no effect
+    try:
+        assert _lib.get_option("gemm_tile") == 0
+    finally:
+        del os.environ["X2I_GEMM_TILE"]
+    assert _lib.set_option("gemm_tile", 256) == 0 and _lib.get_option("gemm_tile") == 256
+    _lib.set_option("gemm_tile", 0)
+    for name in ("gemm_ablate", "attn_ablate", "gemm_lform", "no_such_option"):
+        with pytest.raises(X2IError):
+            _lib.set_option(name, 1)
+    # no getenv left on any launch path: only the one-time option table in c_api.hip reads the environment
+    csrc = os.path.join(ROOT, "x2i_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f != "c_api.hip":
+            assert "getenv" not in open(os.path.join(csrc, f)).read().replace("no getenv", ""), f
+    # the measurement-only build exists beside it and says what it is
+    import ctypes
+    abl = os.path.join(ROOT, "x2i_amd", "libx2i_hip_ablate.so")
+    if os.path.exists(abl):
+        assert ctypes.CDLL(abl).x2i_is_ablation_build() == 1
 
 
 def test_no_cpu_fallback():

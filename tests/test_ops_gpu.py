@@ -39,14 +39,25 @@ def test_gemm_plain_bias(ops, M, N, K):
     assert rel_l2(out, ref) < 1e-2
 
 
-@pytest.mark.parametrize("tile", ["128", "256", "256k"])
+@pytest.fixture
+def opt(ops):
+    """Set library A/B switches for one test (restored afterwards)."""
+    from x2i_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        old = _lib.set_option(name, value)
+        saved.setdefault(name, old)
+    yield set_
+    for k, v in saved.items():
+        _lib.set_option(k, v)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (700, 520, 320), (1024, 1024, 3072)])
-def test_gemm_both_tile_kernels(ops, monkeypatch, tile, M, N, K):
-    """Force the 128x128 kernel, the 256x256 full-line staging kernel and its k-half-unit predecessor ("256k", kept for the
-    ablation hooks) on the same problems (ragged edges, 1..48 K-tiles)."""
-    monkeypatch.setenv("X2I_GEMM_TILE", tile[:3])
-    if tile == "256k":
-        monkeypatch.setenv("X2I_GEMM_LFORM", "0")
+def test_gemm_both_tile_kernels(ops, opt, tile, M, N, K):
+    """Force the 128x128 kernel and the 256x256 full-line staging kernel on the same problems (ragged edges, 1..48 K-tiles)."""
+    opt("gemm_tile", tile)
     A, W, b = bf(seeded((M, K), 40)), bf(seeded((N, K), 41, 0.05)), bf(seeded((N,), 42))
     res = bf(seeded((M, N), 43))
     gate = seeded((1, N), 44)
@@ -256,7 +267,7 @@ def test_errors_are_reported_not_fatal(ops):
         ops.gemm(torch.zeros((4, 8)), torch.zeros((4, 8)))  # CPU tensors: no fallback
 
 
-def test_gemm_tile_quantisation_split_is_bit_identical(ops, monkeypatch):
+def test_gemm_tile_quantisation_split_is_bit_identical(ops, opt):
     """M=4x1152 rows, N=3072 -> 4*5*12 = 240 + ... the launcher peels the trailing rows of each batch item into a second
     (128x128-tile) launch; both kernels accumulate in the same order, so the result must equal the unsplit launch."""
     B, S, N, K = 4, 4608, 3072, 256
@@ -271,7 +282,7 @@ def test_gemm_tile_quantisation_split_is_bit_identical(ops, monkeypatch):
                  res_batch_stride=S * N, ldr=N, gate=gate, gate_batch_stride=N)
         return out
     split = run()                      # 864 tiles -> 768 in the 256-kernel + trailing 512 rows per batch item in the 128-kernel
-    monkeypatch.setenv("X2I_GEMM_NOSPLIT", "1")
+    opt("gemm_split_tail", 0)
     whole = run()
     assert torch.equal(split, whole)
     ref = X[1].float() + gate[1] * F.linear(A[1].float(), W.float(), b.float())
@@ -281,13 +292,13 @@ def test_gemm_tile_quantisation_split_is_bit_identical(ops, monkeypatch):
 # ------------------------------------------------------------------------------------------------ fused QKV epilogue
 @pytest.mark.parametrize("B,H,St,Si,tile", [(2, 2, 40, 216, "128"), (2, 2, 64, 448, "256"), (1, 4, 700, 324, "256"),
                                             (3, 2, 0, 600, "256"), (2, 24, 512, 1024, ""), (1, 24, 0, 5632, ""), (2, 24, 256, 2688, "")])
-def test_gemm_qkv_fused_equals_gemm_then_qkv_split(ops, monkeypatch, B, H, St, Si, tile):
+def test_gemm_qkv_fused_equals_gemm_then_qkv_split(ops, opt, B, H, St, Si, tile):
     """x2i_gemm_qkv_bf16 (norm + RoPE + head split + V transpose in the GEMM epilogue) against the two-step form
     x2i_gemm_bf16 -> x2i_qkv_split_bf16, on both tile kernels, with ragged text lengths (St = 700: unaligned token offsets
     take the element-wise V^T path), batched (double-block) and flattened (single-block, St = 0) row geometry; the last two
     cases have 792 / 756 tiles of 256^2, so the launcher peels the last tile rows into the 128^2 kernel (row offset path)."""
     if tile:
-        monkeypatch.setenv("X2I_GEMM_TILE", tile)
+        opt("gemm_tile", int(tile))
     D, S, Kd = H * 128, St + Si, 256
     Spad = ops.pad128(S)
     W, bias = g(bf(seeded((3 * D, Kd), 40, 0.08))), g(bf(seeded((3 * D,), 41, 0.5)))

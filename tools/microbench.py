@@ -8,7 +8,10 @@ import os
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from x2i_amd import ops  # noqa: E402
+ABLATE = "--ablate" in sys.argv  # also time the attention ablation variants (needs the measurement-only library)
+if ABLATE:
+    os.environ["X2I_LIB_VARIANT"] = "ablate"
+from x2i_amd import _lib, ops  # noqa: E402
 
 DEV = "cuda"
 
@@ -43,10 +46,10 @@ def main():
         out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
         act = 1 if "gelu" in name else 0
         for tile in ("128", "256"):
-            os.environ["X2I_GEMM_TILE"] = tile
+            _lib.set_option("gemm_tile", int(tile))
             t = timeit(lambda: ops.gemm(A, W, b, out=out, act=act))
             print(f"gemm[{tile}] {name:12s} M={M:6d} N={N:6d} K={K:6d}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:8.1f} TFLOP/s")
-        os.environ.pop("X2I_GEMM_TILE")
+        _lib.set_option("gemm_tile", 0)
         del A, W, out
     # attention
     Spad = ops.pad128(S)
@@ -54,16 +57,19 @@ def main():
     VT = rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device=DEV, dtype=torch.bfloat16)
     for var, nm in (("0", "nw4 thr8"), ("1", "nw8 thr8"), ("2", "nw4 thr0"), ("3", "nw8 thr0"), ("0", "nw4 thr8")):
-        os.environ["X2I_ATTN_VARIANT"] = var
+        _lib.set_option("attn_variant", int(var))
         t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention[{nm}] B={B} H={H} S={S}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
-    os.environ.pop("X2I_ATTN_VARIANT")
+    _lib.set_option("attn_variant", 0)
     for abl, nm in (("0", "full"), ("1", "no softmax"), ("2", "no barrier/wait"), ("4", "no DMA"), ("7", "MFMA+LDS reads only"), ("0", "full"),
                     ("32", "branchy loop (no peel)"), ("0", "full"), ("32", "branchy loop (no peel)"), ("0", "full")):
-        os.environ["X2I_ATTN_ABLATE"] = abl
+        if not ABLATE:
+            break
+        _lib.set_option("attn_ablate", int(abl))
         t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention-ablate[{nm}]: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
-    os.environ.pop("X2I_ATTN_ABLATE")
+    if ABLATE:
+        _lib.set_option("attn_ablate", 0)
     # qkv split
     qkv = rnd(B * S, 3 * D)
     nw = rnd(128)

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libx2i_hip.so")
+# X2I_LIB_VARIANT=ablate (read once, at import) makes tools/ load the measurement-only build (ablation kernels, k-half-unit
+# GEMM form); the product package never sets it.
+LIB_PATH = os.path.join(_HERE, "libx2i_hip_ablate.so" if os.environ.get("X2I_LIB_VARIANT") == "ablate" else "libx2i_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
 
@@ -67,6 +69,8 @@ SIGNATURES = {
     "x2i_softmax_rows_bf16": [_vp, _i64, _i32, _f32, _vp],
     "x2i_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "x2i_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
+    "x2i_set_option": [C.c_char_p, _i64],
+    "x2i_get_option": [C.c_char_p, C.POINTER(C.c_int64)],
 }
 
 _lib = None
@@ -89,6 +93,7 @@ def load():
     lib.x2i_last_error.restype = C.c_char_p
     lib.x2i_groupnorm_scratch_floats.argtypes = [_i32, _i32]
     lib.x2i_groupnorm_scratch_floats.restype = C.c_int64
+    lib.x2i_is_ablation_build.restype = C.c_int
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.argtypes = argtypes
@@ -97,6 +102,21 @@ def load():
         raise X2IError("x2i_amd: ABI version mismatch")
     _lib = lib
     return lib
+
+
+def set_option(name, value):
+    """A/B / tuning switch of the library (include/x2i.h: x2i_set_option); returns the previous value."""
+    lib = load()
+    old = C.c_int64(0)
+    check(lib.x2i_get_option(name.encode(), C.byref(old)), "get_option")
+    check(lib.x2i_set_option(name.encode(), int(value)), "set_option")
+    return old.value
+
+
+def get_option(name):
+    v = C.c_int64(0)
+    check(load().x2i_get_option(name.encode(), C.byref(v)), "get_option")
+    return v.value
 
 
 def check(rc, what=""):

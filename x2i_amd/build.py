@@ -13,6 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libx2i_hip.so")
+# measurement-only library for tools/ (ablation kernels that are "wrong results by design", the k-half-unit GEMM form):
+# same sources, the files below recompiled with -DX2I_ABLATION.  Never loaded by the product package.
+LIB_ABLATE = os.path.join(HERE, "libx2i_hip_ablate.so")
+ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "attention.hip", "c_api.hip")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=fast"]
 
@@ -29,33 +33,43 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+def _compile(src, force, ablate=False):
+    obj = os.path.join(OBJ, os.path.basename(src) + (".abl.o" if ablate else ".o"))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header()):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + (["-DX2I_ABLATION"] if ablate else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     return obj, True
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
-    objs = [o for o, _ in res]
-    changed = any(c for _, c in res)
-    if changed or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+def _link(lib, objs, changed, verbose):
+    if changed or not os.path.exists(lib):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
-            print("built", LIB)
+            print("built", lib)
     elif verbose:
-        print("up to date:", LIB)
+        print("up to date:", lib)
+
+
+def build(force=False, verbose=True, ablate=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    jobs = [(s, False) for s in srcs]
+    if ablate:
+        jobs += [(s, True) for s in srcs if os.path.basename(s) in ABLATE_SRCS]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
+        res = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
+    prod = {os.path.basename(j[0]): r for j, r in zip(jobs, res) if not j[1]}
+    abl = {os.path.basename(j[0]): r for j, r in zip(jobs, res) if j[1]}
+    _link(LIB, [o for o, _ in prod.values()], any(c for _, c in prod.values()), verbose)
+    if ablate:
+        objs = [(abl.get(n) or prod[n]) for n in prod]
+        _link(LIB_ABLATE, [o for o, _ in objs], any(c for _, c in objs), verbose)
     return LIB
 
 

@@ -295,24 +295,22 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   if (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)) return x2i_set_error(X2I_ERR_ALIGN, "attention: output rows must be 8-byte aligned");
   const size_t shm = 2 * (KTILE + VTILE);
   const float scale_log2 = scale * 1.4426950408889634f;
-  const char* ev = getenv("X2I_ATTN_VARIANT");  // A/B benchmarking: "nw8", "thr0", "nw8thr0"
-  const int var = ev ? atoi(ev) : 0;
+  const X2IOptions& opt = x2i_options();
+  const int var = opt.attn_variant;  // A/B benchmarking: 1 = 8 waves, 2 = no defer-max, 3 = both
 #define X2I_ATTN_LAUNCH(NW_, THR_)                                                                                          \
   {                                                                                                                         \
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, THR_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)shm);                                                                           \
-    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));                          \
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_fwd_kernel<NW_, THR_>, (int)shm);                             \
+    if (rc_) return rc_;                                                                                                    \
     dim3 grid(((S + 32 * NW_ - 1) / (32 * NW_)) * H * B);                                                                   \
     hipLaunchKernelGGL((attn_fwd_kernel<NW_, THR_>), grid, dim3(NW_ * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, \
                        (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B);                                \
   }
-  const char* ab = getenv("X2I_ATTN_ABLATE");
-  const int abl = ab ? atoi(ab) : 0;
+#ifdef X2I_ABLATION
+  const int abl = opt.attn_ablate;  // measurement-only variants (tools/microbench.py), wrong results by design
 #define X2I_ATTN_LAUNCH_ABL(A_)                                                                                              \
   {                                                                                                                          \
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4, 8, A_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                       (int)shm);                                                                            \
-    if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "attention: %s", hipGetErrorString(e));                           \
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_fwd_kernel<4, 8, A_>, (int)shm);                               \
+    if (rc_) return rc_;                                                                                                     \
     dim3 grid(((S + 127) / 128) * H * B);                                                                                    \
     hipLaunchKernelGGL((attn_fwd_kernel<4, 8, A_>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
                        (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B);                                 \
@@ -322,7 +320,9 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   else if (abl == 4) X2I_ATTN_LAUNCH_ABL(4)
   else if (abl == 7) X2I_ATTN_LAUNCH_ABL(7)
   else if (abl == 32) X2I_ATTN_LAUNCH_ABL(32)
-  else if (var == 1) X2I_ATTN_LAUNCH(8, 8)
+  else
+#endif
+  if (var == 1) X2I_ATTN_LAUNCH(8, 8)
   else if (var == 2) X2I_ATTN_LAUNCH(4, 0)
   else if (var == 3) X2I_ATTN_LAUNCH(8, 0)
   else X2I_ATTN_LAUNCH(4, 8)

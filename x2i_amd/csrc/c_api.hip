@@ -21,9 +21,99 @@ int x2i_check_launch(const char* what) {
   return X2I_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// options: environment read once, then only x2i_set_option()
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <set>
+#include <utility>
+
+namespace {
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+X2IOptions make_options() {
+  X2IOptions o;
+  o.gemm_tile = env_int("X2I_GEMM_TILE", 0);
+  o.gemm_min256 = env_int("X2I_GEMM_MIN256", 128);
+  o.gemm_gm = env_int("X2I_GEMM_GM", 0);
+  o.gemm_split_tail = env_int("X2I_GEMM_NOSPLIT", 0) ? 0 : 1;
+  o.conv256 = env_int("X2I_CONV256", 1);
+  o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
+  o.fp8 = env_int("X2I_FP8", 0);
+  o.last_gemm_tile = -1;
+  o.gemm_lform = env_int("X2I_GEMM_LFORM", 1);
+  o.gemm_ablate = env_int("X2I_GEMM_ABLATE", 0);
+  o.attn_ablate = env_int("X2I_ATTN_ABLATE", 0);
+  return o;
+}
+std::mutex g_smem_mu;
+std::set<std::pair<const void*, int>> g_smem_done;
+}  // namespace
+
+X2IOptions& x2i_options() {
+  static X2IOptions o = make_options();  // thread-safe one-time initialisation
+  return o;
+}
+
+int x2i_ensure_dynamic_smem(const void* kernel, int bytes) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  const std::pair<const void*, int> key(kernel, dev);
+  std::lock_guard<std::mutex> lk(g_smem_mu);
+  if (g_smem_done.count(key)) return X2I_OK;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
+  g_smem_done.insert(key);
+  return X2I_OK;
+}
+
 extern "C" {
 
 int x2i_abi_version(void) { return X2I_ABI_VERSION; }
+
+static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
+  *as_int = nullptr;
+#define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+#ifdef X2I_ABLATION
+  X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate)
+#endif
+#undef X2I_OPT_INT
+  if (!strcmp(name, "gemm_min256")) return &o.gemm_min256;
+  return nullptr;
+}
+
+int x2i_set_option(const char* name, int64_t value) {
+  if (!name) return x2i_set_error(X2I_ERR_ARG, "set_option: null name");
+  int* ip;
+  long long* lp = opt_slot(x2i_options(), name, &ip);
+  if (ip) *ip = (int)value;
+  else if (lp) *lp = (long long)value;
+  else return x2i_set_error(X2I_ERR_ARG, "set_option: unknown option '%s'", name);
+  return X2I_OK;
+}
+
+int x2i_get_option(const char* name, int64_t* value) {
+  if (!name || !value) return x2i_set_error(X2I_ERR_ARG, "get_option: null pointer");
+  int* ip;
+  long long* lp = opt_slot(x2i_options(), name, &ip);
+  if (ip) *value = *ip;
+  else if (lp) *value = *lp;
+  else return x2i_set_error(X2I_ERR_ARG, "get_option: unknown option '%s'", name);
+  return X2I_OK;
+}
+
+int x2i_is_ablation_build(void) {
+#ifdef X2I_ABLATION
+  return 1;
+#else
+  return 0;
+#endif
+}
 const char* x2i_last_error(void) { return g_err; }
 
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream) { return x2i_launch_gemm(args, (hipStream_t)stream); }

@@ -1,0 +1,444 @@
+// Device-side building blocks shared by the bf16 MFMA GEMM kernels (gemm128.hip, gemm256.hip, gemm_ablate.hip): the kernel
+// parameter block, LDS-DMA staging helpers and the fused epilogues.  See gemm.hip for the launcher and the operator contract.
+#pragma once
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+#include <type_traits>
+
+namespace x2i_gemm {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+struct GemmP {
+  const bf16_t* A; long long a_bs; int lda;
+  const bf16_t* W; int ldw; long long w_bs;
+  const bf16_t* bias;
+  void* C; long long c_bs; int ldc;
+  bf16_t* C2; int act2;
+  const float* gate; long long gate_bs;
+  const bf16_t* res; long long r_bs; int ldr;
+  const float* bias2; long long bias2_bs;  // optional f32 per-batch additive vector [batch][N]
+  int M, N, K;
+  int act, out_f32;
+  int tilesM, tilesN;
+  // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
+  int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
+  // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
+  int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0;
+  int gm;
+  float q_eps;
+  const bf16_t *q_nq, *q_nk;
+  const float *q_cos, *q_sin;
+  bf16_t *q_Q, *q_K, *q_VT;
+};
+
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
+                                           uint32_t koff_bytes, int wave) {
+  // 1024 16-byte chunks per tile; instruction j covers chunks [j*256 + wave*64, +64): LDS dest is wave-uniform
+  // base + lane*16 (added by hardware)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_tile + j * 4096 + wave * 1024),
+                                             16, voff[j], koff_bytes, 0, 0);
+  }
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// Shared epilogue: the wave owns MT x NT 16x16 accumulator tiles; lane owns row m = mrow + i*16 and the four
+// consecutive columns n = ncol + j*16 + 0..3 of each tile (operands were swapped in the MFMA).
+template <int ACT, bool RES, bool OUTF32, bool HASC2, int MT, int NT>
+__device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT][NT], int z, int mrow, int ncol) {
+  // ---- epilogue: lane owns m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4 + 0..3
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!RES || (p.ldr & 3) == 0);
+  static_for<NT>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = ncol + j * 16;
+    if (n < p.N) {
+      const bool full = vec_ok && (n + 3 < p.N);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+      if (full) {
+        if (p.bias) {
+          const uint2 b2 = *(const uint2*)(p.bias + n);
+          bv[0] = __uint_as_float(b2.x << 16); bv[1] = __uint_as_float(b2.x & 0xffff0000u);
+          bv[2] = __uint_as_float(b2.y << 16); bv[3] = __uint_as_float(b2.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
+        }
+        if (b2) {
+          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+          bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r < p.N) {
+            if (p.bias) bv[r] = bf16_to_f32(p.bias[n + r]);
+            if (gz) gv[r] = gz[n + r];
+            if (b2) bv[r] += b2[n + r];
+          }
+        }
+      }
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int m = mrow + i * 16;
+        if (m < p.M) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
+          const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
+          if (full) {
+            if constexpr (RES) {
+              const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
+              v[0] = fmaf(gv[0], v[0], __uint_as_float(r2.x << 16));
+              v[1] = fmaf(gv[1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+              v[2] = fmaf(gv[2], v[2], __uint_as_float(r2.y << 16));
+              v[3] = fmaf(gv[3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+            }
+            if constexpr (OUTF32) {
+              *(f32x4_t*)((float*)p.C + coff) = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+              *(uint2*)((bf16_t*)p.C + coff) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+            if constexpr (HASC2) {
+              *(uint2*)(p.C2 + coff) = make_uint2(pack_bf16x2(apply_act(v[0], p.act2), apply_act(v[1], p.act2)),
+                                                  pack_bf16x2(apply_act(v[2], p.act2), apply_act(v[3], p.act2)));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (n + r < p.N) {
+                float x = v[r];
+                if constexpr (RES) x = fmaf(gv[r], x, bf16_to_f32(rz[(long long)m * p.ldr + n + r]));
+                if constexpr (OUTF32) ((float*)p.C)[coff + r] = x;
+                else ((bf16_t*)p.C)[coff + r] = f32_to_bf16(x);
+                if constexpr (HASC2) p.C2[coff + r] = f32_to_bf16(apply_act(x, p.act2));
+              }
+            }
+          }
+        }
+      });
+    }
+  });
+}
+
+// LDS-staged epilogue (both tile kernels): every wave parks its finished (MT*16)x64 bf16 sub-tile in a private LDS region
+// (row stride 144 B: 16-byte aligned, spreads the 16 rows of a ds_write_b64 over the banks) and writes it out as whole
+// 128-byte row segments with 16-byte stores -- a wave store instruction covers 8 full cache lines instead of sixteen
+// 32-byte fragments (the direct accumulator layout), which is what the HBM-bound epilogue of the large-N GEMMs needs.
+constexpr int EPI_ROW_BYTES = 144;
+constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // 18 KiB per wave, 144 KiB per workgroup
+
+template <int ACT, bool RES, bool HASC2, int MT>
+__device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc)[MT][4], int z, int m_wave, int n_wave, int lane,
+                                                   char* wave_lds) {
+  const int mlane = lane & 15, ng = lane >> 4;
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+  bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
+  bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
+  if constexpr (RES && !HASC2) {
+    // Gated-residual form with the residual tile fetched by LDS-DMA as whole 128-byte row segments (the direct form reads
+    // it as 32-byte accumulator-layout fragments, which is what makes short-K launches -- the ControlNeXt residual convs --
+    // epilogue-bound).  Staging image here: [MT*16 rows][128 B], 16-byte chunk c of row r holds logical chunk
+    // c ^ ((r>>1)&7) (the DMA image is lane-linear, so the swizzle is applied on the source address); results overwrite
+    // the residual in place and leave with 16-byte stores.
+    const long long res_bytes = ((long long)(p.M - 1) * p.ldr + p.N) * 2;
+    if ((p.ldr & 7) == 0 && (p.r_bs & 7) == 0 && (((uintptr_t)p.res) & 15) == 0 && res_bytes < 0x7f000000LL) {
+      __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rz, 0, (uint32_t)res_bytes, 0x00020000);
+      const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+      for (int it = 0; it < MT * 2; ++it) {
+        const int row = it * 8 + srow;
+        const int m = m_wave + row, n = n_wave + ((sch ^ ((row >> 1) & 7)) << 3);
+        const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((long long)m * p.ldr + n) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (__attribute__((address_space(3))) void*)(wave_lds + it * 1024), 16, off, 0, 0, 0);
+      }
+      float bvv[4][4], gvv[4][4];
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int n = n_wave + j * 16 + ng * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bvv[j][r] = 0.f, gvv[j][r] = 1.f;
+        if (n + 3 < p.N) {
+          if (p.bias) {
+            const uint2 bb = *(const uint2*)(p.bias + n);
+            bvv[j][0] = __uint_as_float(bb.x << 16); bvv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
+            bvv[j][2] = __uint_as_float(bb.y << 16); bvv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
+          }
+          if (gz) {
+            const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+            gvv[j][0] = g4[0]; gvv[j][1] = g4[1]; gvv[j][2] = g4[2]; gvv[j][3] = g4[3];
+          }
+          if (b2) {
+            const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+            bvv[j][0] += t4[0]; bvv[j][1] += t4[1]; bvv[j][2] += t4[2]; bvv[j][3] += t4[3];
+          }
+        }
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the region is private to this wave: no barrier needed
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<MT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const int row = i * 16 + mlane;
+          char* slot = wave_lds + row * 128 + ((((j << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
+          const uint2 r2 = *(const uint2*)slot;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bvv[j][r], ACT);
+          v[0] = fmaf(gvv[j][0], v[0], __uint_as_float(r2.x << 16));
+          v[1] = fmaf(gvv[j][1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+          v[2] = fmaf(gvv[j][2], v[2], __uint_as_float(r2.y << 16));
+          v[3] = fmaf(gvv[j][3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+          *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < MT * 2; ++it) {
+        const int row = it * 8 + srow;
+        const bf16x8_t d = *(const bf16x8_t*)(wave_lds + it * 1024 + lane * 16);
+        const int m = m_wave + row, n = n_wave + ((sch ^ ((row >> 1) & 7)) << 3);
+        if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(Cz + (long long)m * p.ldc + n) = d;
+      }
+      return;
+    }
+  }
+  constexpr int NPASS = HASC2 ? 2 : 1;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n_wave + j * 16 + ng * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (n + 3 < p.N) {
+        if (p.bias) {
+          const uint2 bb = *(const uint2*)(p.bias + n);
+          bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+          bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[0] = g4[0]; gv[1] = g4[1]; gv[2] = g4[2]; gv[3] = g4[3];
+        }
+        if (b2) {
+          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+          bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
+        }
+      }
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int mrel = i * 16 + mlane;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
+        if constexpr (RES) {
+          const int m = m_wave + mrel;
+          if (m < p.M && n + 3 < p.N) {
+            const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
+            v[0] = fmaf(gv[0], v[0], __uint_as_float(r2.x << 16));
+            v[1] = fmaf(gv[1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+            v[2] = fmaf(gv[2], v[2], __uint_as_float(r2.y << 16));
+            v[3] = fmaf(gv[3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+          }
+        }
+        if (pass == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
+        }
+        *(uint2*)(wave_lds + mrel * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      });
+    });
+    // the region is private to this wave: LDS operations of one wave complete in order, only the data hazard matters
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16_t* dst = (pass == 0) ? Cz : C2z;
+#pragma unroll
+    for (int it = 0; it < MT * 2; ++it) {
+      const int row = it * 8 + (lane >> 3), c = lane & 7;
+      const bf16x8_t d = *(const bf16x8_t*)(wave_lds + row * EPI_ROW_BYTES + c * 16);
+      const int m = m_wave + row, n = n_wave + c * 8;
+      if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
+    }
+    if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused QKV epilogue (x2i_gemm_qkv_bf16).  The workgroup's finished tile -- TR tokens x TC columns, i.e. TC/128 whole
+// heads of the q, k or v section -- is parked in LDS as bf16(acc + bias) (per-wave regions of the staged epilogue, row
+// stride 144 B) and leaves in attention layout:
+//   q / k tile: 16 lanes x 8 dims per (token, head): RMSNorm over the 128 dims (fp32), * norm weight, RoPE on adjacent
+//               pairs with the fp32 cos/sin row of the token's joint position, 16-byte stores into Q/K [B,H,Spad,128]
+//   v tile:     transposed through LDS: a lane gathers two adjacent dims of 8 consecutive tokens (8 ds_read_b32) and
+//               writes two 16-byte token runs of VT [B,H,128,Spad]; 8 lanes cover a 128-byte line
+// Same arithmetic as qk_norm_rope_kernel / v_transpose_kernel (elementwise.hip), which remain the unfused form.
+// ------------------------------------------------------------------------------------------------------------
+template <int MT, int WN, int NT>
+__device__ __forceinline__ void epilogue_qkv(const GemmP& p, f32x4_t (&acc)[MT][4], int z, int m0, int n0, int wm, int wn, int lane,
+                                             int tid, char* smem) {
+  constexpr int WR = MT * 16;  // rows per wave
+  constexpr int TR = 2 * WR;   // tile rows (two waves along M in both kernels)
+  constexpr int TC = WN * 64;  // tile columns
+  constexpr int REGION = WR * EPI_ROW_BYTES;
+  constexpr int HEADS = TC / 128;
+  {
+    char* wave_lds = smem + (wm * WN + wn) * REGION;
+    const int mlane = lane & 15, ng = lane >> 4;
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n0 + wn * 64 + j * 16 + ng * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n + 3 < p.N) {
+        const uint2 bb = *(const uint2*)(p.bias + n);
+        bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+        bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+      }
+      static_for<MT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        *(uint2*)(wave_lds + (i * 16 + mlane) * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) =
+            make_uint2(pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
+      });
+    });
+  }
+  __syncthreads();
+  const int Dm = p.q_H * 128;
+  const int sec = n0 / Dm;  // 0 = q, 1 = k, 2 = v (a tile never straddles sections: Dm % TC == 0, checked by the launcher)
+  const int head0 = (n0 - sec * Dm) >> 7;
+  auto lds_at = [&](int row, int col) -> const char* {  // bf16 element (row, col) of the tile
+    return smem + ((row / WR) * WN + (col >> 6)) * REGION + (row % WR) * EPI_ROW_BYTES + (col & 63) * 2;
+  };
+  if (sec < 2) {
+    const int c = tid & 15;  // 8-dim chunk of the head; the same for every iteration (NT % 16 == 0)
+    float w[8];
+    {
+      const bf16x8_t wv = *(const bf16x8_t*)((sec ? p.q_nk : p.q_nq) + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]);
+    }
+    bf16_t* dstbase = sec ? p.q_K : p.q_Q;
+#pragma unroll 2
+    for (int u = tid >> 4; u < TR * HEADS; u += NT / 16) {
+      const int hh = u % HEADS, row = u / HEADS;
+      const int m = m0 + row;
+      const bf16x8_t xv = *(const bf16x8_t*)lds_at(row, hh * 128 + c * 8);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[j]);
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this (token, head)
+      if (m < p.M) {
+        const float r = rsqrtf(ss * (1.f / 128.f) + p.q_eps);
+        const int mg = p.q_row0 + m;
+        const int b = z + mg / p.q_rpb, st = p.q_tok_off + mg % p.q_rpb;
+        const float* cp = p.q_cos + (long long)st * 128 + c * 8;
+        const float* sp = p.q_sin + (long long)st * 128 + c * 8;
+        const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
+        const f32x4_t s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
+        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
+          o[j] = a * cs[j] - bb * sn[j];
+          o[j + 1] = bb * cs[j + 1] + a * sn[j + 1];
+        }
+        union { bf16x8_t v8; uint32_t uu[4]; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk.uu[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+        *(bf16x8_t*)(dstbase + (((long long)b * p.q_H + head0 + hh) * p.q_Spad + st) * 128 + c * 8) = pk.v8;
+      }
+    }
+  } else {
+    const int wave = tid >> 6;
+    const int ch_lo = lane & 7, dp_lo = lane >> 3;
+    constexpr int CG = TR / 64;                  // groups of 8 token-chunks (64 tokens)
+    constexpr int WITS = CG * (TC / 16);         // wave-iterations: x groups of 8 dim-pairs (16 dims)
+    // 8-token runs are whole and 16-byte aligned in VT when every row offset is a multiple of 8
+    const bool aligned = ((p.q_tok_off | p.q_rpb | p.q_row0 | p.M | p.q_Spad) & 7) == 0;
+    for (int wi = wave; wi < WITS; wi += NT / 64) {
+      const int ch = (wi % CG) * 8 + ch_lo, dp = (wi / CG) * 8 + dp_lo;
+      const int d0 = dp * 2;  // tile column of the first of the two dims
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *(const uint32_t*)lds_at(ch * 8 + k, d0);
+      const int m = m0 + ch * 8;
+      if (m >= p.M) continue;
+      const int h = head0 + (d0 >> 7), d = d0 & 127;
+      const int mg = p.q_row0 + m;
+      const int b = z + mg / p.q_rpb, st = p.q_tok_off + mg % p.q_rpb;
+      bf16_t* row0 = p.q_VT + (((long long)b * p.q_H + h) * 128 + d) * p.q_Spad;
+      if (aligned) {
+        union { bf16x8_t v8; uint32_t uu[4]; } lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          lo.uu[k] = (v[2 * k] & 0xffffu) | (v[2 * k + 1] << 16);
+          hi.uu[k] = (v[2 * k] >> 16) | (v[2 * k + 1] & 0xffff0000u);
+        }
+        *(bf16x8_t*)(row0 + st) = lo.v8;
+        *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (m + k < p.M) {
+            const int mgk = mg + k;
+            const int bk = z + mgk / p.q_rpb, sk = p.q_tok_off + mgk % p.q_rpb;
+            bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + h) * 128 + d) * p.q_Spad + sk;
+            rk[0] = (bf16_t)(v[k] & 0xffffu);
+            rk[p.q_Spad] = (bf16_t)(v[k] >> 16);
+          }
+        }
+      }
+    }
+  }
+}
+
+
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int UNIT_BYTES = 256 * 32 * 2;        // 16 KiB
+constexpr int TILE2_BYTES = 4 * UNIT_BYTES;     // 64 KiB per K-tile
+constexpr int SMEM2_BYTES = 8 * 18432;          // 144 KiB: 128 KiB operand ring, reused as 8 x 18 KiB epilogue staging
+
+typedef void (*kern_t)(GemmP);
+// kernel pickers (one per translation unit so the kernel families compile in parallel); nullptr = no MFMA instantiation
+// for this epilogue combination
+kern_t pick_gemm128(int act, bool res, bool f32, bool c2, bool conv);
+kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
+#ifdef X2I_ABLATION
+kern_t pick_gemm256u(int act, bool res, bool f32, bool c2, int abl);  // k-half-unit form + measurement-only variants
+#endif
+
+// One table of the epilogue combinations that have MFMA instantiations (anything else takes the generic kernel).
+#define X2I_GEMM_PICK_TABLE(PICK)                                                   \
+  if (!res && !f32 && !c2) {                                                        \
+    switch (act) {                                                                  \
+      case X2I_ACT_NONE: PICK(X2I_ACT_NONE, false, false, false) break;             \
+      case X2I_ACT_GELU_TANH: PICK(X2I_ACT_GELU_TANH, false, false, false) break;   \
+      case X2I_ACT_GELU_ERF: PICK(X2I_ACT_GELU_ERF, false, false, false) break;     \
+      case X2I_ACT_SILU: PICK(X2I_ACT_SILU, false, false, false) break;             \
+      case X2I_ACT_RELU: PICK(X2I_ACT_RELU, false, false, false) break;             \
+    }                                                                               \
+  } else if (act == X2I_ACT_NONE) {                                                 \
+    if (res && !f32 && !c2) PICK(X2I_ACT_NONE, true, false, false)                  \
+    else if (!res && f32 && !c2) PICK(X2I_ACT_NONE, false, true, false)             \
+    else if (!res && !f32 && c2) PICK(X2I_ACT_NONE, false, false, true)             \
+  }
+
+}  // namespace x2i_gemm

@@ -20,6 +20,27 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 int x2i_set_error(int code, const char* fmt, ...);
 int x2i_check_launch(const char* what);
 
+// A/B and tuning switches (include/x2i.h: x2i_set_option).  Resolved ONCE, on first use, from the X2I_* environment
+// variables; afterwards only x2i_set_option() changes them -- no getenv on the launch path.
+struct X2IOptions {
+  int gemm_tile;          // 0 = automatic tile choice; 128 / 256 force a kernel (A/B, race screen)        X2I_GEMM_TILE
+  long long gemm_min256;  // minimum number of 256^2 tiles for the 256^2 kernel (default 128)            X2I_GEMM_MIN256
+  int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
+  int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
+  int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
+  int attn_variant;       // 0 = product kernel (4 waves, defer-max 8); 1..3 = A/B variants                X2I_ATTN_VARIANT
+  int fp8;                // reserved for the fp8 path switch                                               X2I_FP8
+  int last_gemm_tile;     // read-only introspection for the parity tests: tile edge of the kernel the last GEMM / conv launch used
+                          // (256, 128, 0 = generic kernel), + 1000 when a peeled 128^2 tail launch followed the 256^2 launch
+  // measurement-only library (libx2i_hip_ablate.so, -DX2I_ABLATION); ignored by the product library
+  int gemm_lform;         // 0 = k-half-unit 256^2 kernel                                                   X2I_GEMM_LFORM
+  int gemm_ablate;        // ablation bit mask, wrong results by design                                     X2I_GEMM_ABLATE
+  int attn_ablate;        //                                                                                X2I_ATTN_ABLATE
+};
+X2IOptions& x2i_options();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch
+int x2i_ensure_dynamic_smem(const void* kernel, int bytes);
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // float -> bf16, round-to-nearest-even (== torch .to(bfloat16)); hipcc lowers these casts to v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

@@ -180,6 +180,8 @@ class FluxTransformer2DModel(nn.Module):
         self.proj_out = lin("proj_out", patch_size * patch_size * self.out_channels, D)
         self._ws = {}
         self._H = H
+        # X2I_QKV_FUSE=0 (read once, here) keeps the two-step form GEMM -> x2i_qkv_split for A/B measurements; bit-identical results
+        self.fuse_qkv = os.environ.get("X2I_QKV_FUSE", "1") != "0"
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property
@@ -317,8 +319,7 @@ class FluxTransformer2DModel(nn.Module):
         def mod(off):
             return MOD[:, off:]
 
-        # X2I_QKV_FUSE=0 keeps the two-step form (GEMM -> x2i_qkv_split) for A/B measurements; results are bit-identical
-        fuse_qkv = os.environ.get("X2I_QKV_FUSE", "1") != "0" and D % 64 == 0
+        fuse_qkv = self.fuse_qkv and D % 64 == 0
         qkv_txt = QKV  # rows [0, B*St)
         qkv_img_off = B * St * 3 * D
         # ---- double-stream blocks (lightcontrol_flux.py:159-204)

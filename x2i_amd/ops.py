@@ -10,6 +10,19 @@ from . import _lib
 from ._lib import QkvDesc, ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_SILU, GemmArgs, check  # noqa: F401
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def option(name, value):
+    """Temporarily set a library A/B switch (include/x2i.h: x2i_set_option) -- used by tests and tools, never by the product path."""
+    old = _lib.set_option(name, value)
+    try:
+        yield
+    finally:
+        _lib.set_option(name, old)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
