@@ -7,7 +7,8 @@ reference algorithm for the path named in BASELINE.json `north_star`:
   * FLUX DiT blocks + model        -> oracle/flux.py        (lightcontrol/lightcontrol_flux.py)
   * diffusers 0.31.0 primitives    -> oracle/primitives.py  (third-party, NOT under /root/reference)
   * sampling loop + scheduler      -> oracle/sampler.py     (diffusers FluxPipeline / FlowMatchEuler...)
-  * ControlNeXt hint encoder       -> oracle/controlnext.py (lightcontrol/lightcontrol_flux.py:575-749)
+  * ControlNeXt hint encoder       -> oracle/flux.py `controlnext_forward` (lightcontrol/lightcontrol_flux.py:575-749)
+  * VAE decode (next row N1)       -> oracle/vae.py         (diffusers AutoencoderKL.decode, third-party)
 
 Who may import it: tests/, __graft_entry__.smoke(), and bench.py's
 `cpu_baseline` leg -- always as the checker / reported baseline, never as the
@@ -28,7 +29,15 @@ How it is pinned (see DESIGN.md "Oracle"):
     UNPINNED.  diffusers is an un-vendored third-party dependency
     (requirements.txt:3, `diffusers==0.31.0`), absent from /root/reference and
     from this image; primitives.py restates its published algorithm and is
-    anchored by known-answer tests (tests/test_oracle_known_answers.py) and by
-    the in-repo copies of pack/unpack/ids/calculate_shift
-    (train/train_qwenvl.py:216-246, lightcontrol/train_lightcontrol.py:403-410).
+    anchored by (1) known-answer tests (tests/test_oracle_known_answers.py), (2) an
+    independent SECOND derivation of every primitive -- complex-multiplication RoPE,
+    explicit float64 softmax(QK^T/sqrt d)V with text-first joint order, float64
+    RMSNorm with the bf16 weight-cast rule, AdaLN chunk orders with distinguishable
+    constants, scalar-loop Timesteps / schedule closed forms
+    (tests/test_oracle_second_derivation.py; no expected value there comes from
+    primitives.py), (3) the in-repo copies of pack/unpack/ids/calculate_shift
+    (train/train_qwenvl.py:216-246, lightcontrol/train_lightcontrol.py:403-410) and
+    (4) the reference's own retrieve_timesteps / sigma construction / get_sigmas /
+    noising statements executed against the build's scheduler
+    (tests/golden/scheduler_protocol.safetensors).
 """

@@ -14,6 +14,12 @@ What executes reference code:
   * train/train_qwenvl.py, lightcontrol/train_lightcontrol.py: the helper
     functions _pack_latents/_unpack_latents/_prepare_latent_image_ids/
     calculate_shift are extracted with `ast` and executed         -> helpers.safetensors
+  * train/train_qwenvl.py: retrieve_timesteps (:248-281) and the sigma / mu / timestep construction statements of the
+    teacher step (:753-771); lightcontrol/train_lightcontrol.py: get_sigmas (:412-421) and the flow-matching noising
+    statement (:706) -- extracted with `ast` and executed against the build's scheduler class (diffusers' own class is
+    not installed), which pins the scheduler's call protocol and attributes            -> scheduler_protocol.safetensors
+
+  python tests/golden/make_golden.py scheduler   # regenerate only the named sections (manifest is merged)
 Weights are NOT stored: they are regenerated from seeds by oracle.*.random_*_state_dict
 and loaded into the reference modules with load_state_dict(strict=True) (which
 also checks our key/shape tables against the reference module tree).
@@ -145,10 +151,11 @@ def gen_legacy():
 
 
 # --------------------------------------------------------------------------- helpers extracted by ast
-def _extract(path, names):
+def _extract(path, names, extra_ns=None):
     src = open(path).read()
     tree = ast.parse(src)
     ns = {"torch": torch}
+    ns.update(extra_ns or {})
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:
             code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
@@ -167,6 +174,76 @@ def gen_helpers():
     shifts115 = torch.tensor([a["calculate_shift"](n, 256, 4096, 0.5, 1.15) for n in (256, 1024, 4096)], dtype=torch.float64)
     save("helpers", dict(lat=lat, packed=packed, ids=ids, unpacked=unpacked, shifts=shifts, shifts115=shifts115),
          dict(ref="train/train_qwenvl.py:216-246; lightcontrol/train_lightcontrol.py:403-410", seq_lens=[256, 1024, 4096]))
+
+
+# --------------------------------------------------------------------------- scheduler protocol (reference statements, our class)
+def _extract_statements(path, func_pred, targets):
+    """The Assign statements with the given target names, in source order, from the first function accepted by func_pred."""
+    tree = ast.parse(open(path).read())
+
+    def names(t):
+        return tuple(e.id for e in t.elts) if isinstance(t, ast.Tuple) else (getattr(t, "id", None),)
+
+    for fn in ast.walk(tree):
+        if isinstance(fn, ast.FunctionDef) and func_pred(fn):
+            body = [n for n in ast.walk(fn) if isinstance(n, ast.Assign) and len(n.targets) == 1 and names(n.targets[0]) in targets]
+            body.sort(key=lambda n: n.lineno)
+            return body
+    raise RuntimeError("statements not found in " + path)
+
+
+def gen_scheduler():
+    import inspect
+    from typing import List, Optional, Union
+
+    import numpy as np
+
+    from x2i_amd.pipeline import FlowMatchEulerDiscreteScheduler  # host-side class, no GPU needed
+
+    qw = os.path.join(REF, "train/train_qwenvl.py")
+    lc = os.path.join(REF, "lightcontrol/train_lightcontrol.py")
+    ns = _extract(qw, {"retrieve_timesteps", "calculate_shift"},
+                  dict(inspect=inspect, List=List, Optional=Optional, Union=Union, np=np))  # annotations are evaluated at def time
+    calls_rt = lambda fn: any(isinstance(n, ast.Call) and getattr(n.func, "id", "") == "retrieve_timesteps" for n in ast.walk(fn))  # noqa: E731
+    stmts = _extract_statements(qw, calls_rt, {("sigmas",), ("image_seq_len",), ("mu",), ("timesteps", "num_inference_steps")})
+    lines = [n.lineno for n in stmts]
+    code = compile(ast.Module(body=stmts, type_ignores=[]), qw, "exec")
+    out, meta_cases = {}, []
+    cases = [("schnell", dict(shift=1.0, use_dynamic_shifting=False), 4, 4096), ("dev", dict(shift=3.0, use_dynamic_shifting=True), 20, 4096),
+             ("dev", dict(shift=3.0, use_dynamic_shifting=True), 1, 4096), ("dev", dict(shift=3.0, use_dynamic_shifting=True), 20, 1024),
+             ("shift3", dict(shift=3.0, use_dynamic_shifting=False), 8, 2304)]
+    for kind, kw, n, seq in cases:
+        sch = FlowMatchEulerDiscreteScheduler(**kw)
+        env = dict(ns, scheduler=sch, infer_device="cpu", latents=torch.zeros(1, seq, 64))
+        # the reference sets num_inference_steps = 1 on the line before (:752); we vary it, the statements are unchanged
+        src_n = [m for m in stmts if m.targets[0].__class__ is ast.Name and m.targets[0].id == "num_inference_steps"]
+        assert not src_n
+        env["num_inference_steps"] = n
+        exec(code, env)
+        tag = f"{kind}_n{n}_s{seq}"
+        out[tag + ".timesteps"] = env["timesteps"].to(torch.float32)
+        out[tag + ".sigmas"] = sch.sigmas.to(torch.float32)
+        out[tag + ".mu"] = torch.tensor([env["mu"]], dtype=torch.float64)
+        assert env["num_inference_steps"] == n
+        meta_cases.append(dict(tag=tag, config=kw, num_inference_steps=n, image_seq_len=seq))
+    # training-side use of the same class: get_sigmas + the noising statement (z_t = (1 - sigma) x + sigma z1)
+    ns2 = _extract(lc, {"get_sigmas"})
+    noising = _extract_statements(lc, lambda fn: any(isinstance(n, ast.Call) and getattr(n.func, "id", "") == "get_sigmas" for n in ast.walk(fn)),
+                                  {("noisy_model_input",)})
+    noising = [n for n in noising if isinstance(n.value, ast.BinOp)][:1]
+    sch = FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True)  # FLUX.1-dev training scheduler (:495-499)
+    idx = torch.tensor([0, 17, 500, 999])
+    ts = sch.timesteps[idx]
+    x, z = seeded((4, 16, 8, 8), 410), seeded((4, 16, 8, 8), 411)
+    sig = ns2["get_sigmas"](ts, sch, "cpu", n_dim=4, dtype=torch.float32)
+    env = dict(sigmas=sig, model_input=x, noise=z)
+    exec(compile(ast.Module(body=noising, type_ignores=[]), lc, "exec"), env)
+    out.update({"train.indices": idx, "train.timesteps": ts, "train.sigmas": sig, "train.model_input": x, "train.noise": z,
+                "train.noisy": env["noisy_model_input"]})
+    save("scheduler_protocol", out,
+         dict(ref="train/train_qwenvl.py:248-281 (retrieve_timesteps), statements at lines %s; lightcontrol/train_lightcontrol.py:412-421 "
+                  "(get_sigmas), noising statement at line %d" % (lines, noising[0].lineno),
+              executed_against="x2i_amd.pipeline.FlowMatchEulerDiscreteScheduler (diffusers is not installed)", cases=meta_cases))
 
 
 # --------------------------------------------------------------------------- composition (lightcontrol_flux.py under shim)
@@ -267,14 +344,15 @@ def gen_flux():
 
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
-    print("legacy:")
-    gen_legacy()  # before gen_flux: its permissive stub modules must not shadow the shim
-    print("projector:")
-    gen_projector()
-    print("helpers:")
-    gen_helpers()
-    print("flux composition:")
-    gen_flux()
+    sections = [("legacy", gen_legacy),  # before gen_flux: its permissive stub modules must not shadow the shim
+                ("projector", gen_projector), ("helpers", gen_helpers), ("scheduler", gen_scheduler), ("flux", gen_flux)]
+    only = set(sys.argv[1:])
+    if only:  # partial regeneration: keep the other sections' manifest entries
+        MANIFEST.update(json.load(open(os.path.join(HERE, "manifest.json"))))
+    for name, fn in sections:
+        if not only or name in only:
+            print(name + ":")
+            fn()
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=1, sort_keys=True)
     print("manifest written")

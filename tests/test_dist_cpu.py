@@ -24,6 +24,25 @@ def _fake_pipeline(prompt_embeds=None, pooled_prompt_embeds=None, latents=None, 
     return _FakeOut(latents * 2 + prompt_embeds.mean(dim=(1, 2))[:, None, None] + pooled_prompt_embeds.sum(1)[:, None, None])
 
 
+class _FakeTransformer:
+    device = torch.device("cpu")
+
+    class config:
+        in_channels = 12
+
+
+class _FakePipelineObj:
+    """Callable with the attributes sample_sharded uses when it has to draw the global noise itself."""
+    transformer = _FakeTransformer()
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        return torch.randn((batch_size, 6, num_channels_latents), generator=generator, dtype=dtype), None
+
+    def __call__(self, **kw):
+        assert "generator" not in kw  # the helper consumed it: a per-rank generator would duplicate noise across ranks
+        return _fake_pipeline(**kw)
+
+
 def _worker(rank, world, port, total, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from x2i_amd import dist as xd
@@ -34,6 +53,11 @@ def _worker(rank, world, port, total, out):
     full = xd.sample_sharded(_fake_pipeline, pe, pooled, latents=lat)
     want = _fake_pipeline(pe, pooled, lat).images
     ok = torch.equal(full, want)
+    # latents=None + generator=: every rank must see the GLOBAL noise draw, sliced -- same result as the unsharded run
+    pipe = _FakePipelineObj()
+    got = xd.sample_sharded(pipe, pe, pooled, generator=torch.Generator().manual_seed(7), height=64, width=64)
+    lat_global, _ = pipe.prepare_latents(total, 3, 64, 64, pe.dtype, "cpu", torch.Generator().manual_seed(7))
+    ok = ok and torch.equal(got, _fake_pipeline(pe, pooled, lat_global).images)
     lo, hi = xd.shard_range(total, rank, world)
     out.put((rank, ok, lo, hi))
     torch.distributed.destroy_process_group()

@@ -50,6 +50,9 @@ class _LazyF32(dict):
     def __getitem__(self, k):
         return dict.__getitem__(self, k).float()
 
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
 
 # ---------------------------------------------------------------------------------------------------- (a) conv on 256^2 tiles
 @pytest.mark.parametrize("Cin,Cout,k,s,p,H,W,up", [

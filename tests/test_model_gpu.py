@@ -167,3 +167,28 @@ def test_legacy_proj_front_stage_vs_reference_golden():
     m = XP.ProjFrontStage(in_channels=3, input_dim=64, layer_norm_eps=meta["eps"])
     m.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
     assert rel_l2(m(t["x"].to(DEV)), t["pre"]) < 2e-2
+
+
+def test_two_prepared_states_do_not_share_conditioning():
+    """prepare A, prepare B, denoise A (true-CFG style positive / negative prompts): A's result must not pick up B's pooled /
+    guidance conditioning (`cond` used to live in the shared per-shape workspace)."""
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32,
+               guidance_embeds=True)
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: v.bfloat16() for k, v in OF.random_flux_state_dict(cfg, seed=3, std=0.05).items()}, strict=True)
+    g = torch.Generator().manual_seed(1)
+    hid = torch.randn((2, 48, 64), generator=g).bfloat16().to(DEV)
+    encA, encB = (torch.randn((2, 24, 64), generator=g).bfloat16().to(DEV) for _ in range(2))
+    poolA, poolB = (torch.randn((2, 32), generator=g).bfloat16().to(DEV) for _ in range(2))
+    ids, tids = OS.prepare_latent_image_ids(6, 8).to(DEV), torch.zeros(24, 3, device=DEV)
+    t = torch.tensor([0.5, 0.5], device=DEV).bfloat16()
+    gA, gB = torch.full((2,), 3.5, device=DEV), torch.full((2,), 1.0, device=DEV)
+    alone = m.denoise(m.prepare_conditioning(encA, poolA, tids, ids, gA), hid, t).clone()
+    sA = m.prepare_conditioning(encA, poolA, tids, ids, gA)
+    sB = m.prepare_conditioning(encB, poolB, tids, ids, gB)
+    outA = m.denoise(sA, hid, t).clone()
+    outB = m.denoise(sB, hid, t).clone()
+    assert torch.equal(outA, alone) and not torch.equal(outB, outA)
+    assert torch.equal(m.denoise(sA, hid, t), alone)

@@ -26,8 +26,10 @@ def _strip(sd):
     return {re.sub(r"^(module\.)+", "", k): v for k, v in sd.items()}
 
 
-def projector_config_from_state_dict(sd):
-    """Recover the Proj7Exp constructor arguments from tensor shapes (the flat .bin carries no config)."""
+def projector_config_from_state_dict(sd, in_channels=None):
+    """Recover the Proj7Exp constructor arguments from tensor shapes (the flat .bin carries no config).  The plain layer-mean
+    fusion (use_scale=False, use_cnn=False; utils/proj.py:70-71) has no parameter that records the layer count: pass
+    `in_channels` (it only documents the expected C; the mean accepts any)."""
     H = sd["mlp.layernorm.weight"].shape[0]
     cfg = dict(kernel_size=5, input_dim=H, output_dim0=sd["mlp.fc.1.weight"].shape[0],
                output_dim1=sd["mlp.projector.2.weight"].shape[0], norm_eps=1e-6, use_t5=False)
@@ -35,14 +37,16 @@ def projector_config_from_state_dict(sd):
         cfg.update(in_channels=sd["cha_scale"].shape[1], use_scale=True, use_cnn=False)
     elif "conv.weight" in sd:
         cfg.update(in_channels=sd["conv.weight"].shape[1], use_scale=False, use_cnn=True, kernel_size=sd["conv.weight"].shape[-1])
+    elif in_channels is not None:
+        cfg.update(in_channels=int(in_channels), use_scale=False, use_cnn=False)
     else:
-        raise KeyError("projector checkpoint has neither conv.weight nor cha_scale: in_channels cannot be inferred")
+        raise KeyError("projector checkpoint has neither conv.weight nor cha_scale (plain layer-mean fusion): pass in_channels=")
     if any(k.startswith("t5stack.") for k in sd):
         raise NotImplementedError("checkpoint contains a T5Stack (use_t5=True): dead path in the reference, unsupported here")
     return cfg
 
 
-def load_projector_checkpoint(path, device="cuda"):
+def load_projector_checkpoint(path, device="cuda", in_channels=None):
     """-> x2i_amd.proj.Proj7Exp in eval mode, whichever of the two packagings `path` holds."""
     blob = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(blob, dict) and "state_dict" in blob and "config" in blob:
@@ -50,7 +54,7 @@ def load_projector_checkpoint(path, device="cuda"):
         cfg = {k: blob["config"][k] for k in _PROJ_KW if k in blob["config"]}
     else:
         sd = _strip(blob)
-        cfg = projector_config_from_state_dict(sd)
+        cfg = projector_config_from_state_dict(sd, in_channels)
     proj = xproj.Proj7Exp(device=device, **cfg)
     proj.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
     return proj.eval()

@@ -62,13 +62,19 @@ def sample_sharded(pipeline, prompt_embeds, pooled_prompt_embeds, latents=None, 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     total = prompt_embeds.shape[0]
     lo, hi = shard_range(total, rank, world)
+    if latents is None:
+        # draw the GLOBAL noise on every rank (same generator state everywhere) and slice it: forwarding `generator=` to the
+        # local call would give sample j of every rank the same noise and a result that differs from the unsharded run
+        gen = kw.pop("generator", None)
+        tr = pipeline.transformer
+        latents, _ = pipeline.prepare_latents(total, tr.config.in_channels // 4, kw.get("height") or 1024, kw.get("width") or 1024,
+                                              prompt_embeds.dtype, tr.device, gen)
+    else:
+        kw.pop("generator", None)  # unused once latents are given (as in the pipeline itself)
     if hi > lo:
         local = pipeline(prompt_embeds=prompt_embeds[lo:hi], pooled_prompt_embeds=pooled_prompt_embeds[lo:hi],
                          latents=None if latents is None else latents[lo:hi],
                          guided_hint=None if guided_hint is None else guided_hint[lo:hi], **kw).images
     else:  # more ranks than samples: contribute an empty shard
-        ref = latents if latents is not None else prompt_embeds
-        local = ref.new_zeros((0,) + tuple(latents.shape[1:])) if latents is not None else None
-        if local is None:
-            raise ValueError("sample_sharded: a rank with an empty shard needs `latents=` to know the output shape")
+        local = latents.new_zeros((0,) + tuple(latents.shape[1:]))
     return all_gather_batch(local, total, group)

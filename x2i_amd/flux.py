@@ -239,7 +239,6 @@ class FluxTransformer2DModel(nn.Module):
             CAT=torch.empty((B * S, 5 * D), **bf), NRMF=torch.empty((B * Si, D), **bf),
             MOD=torch.empty((B, self._mod_rows), device=dev, dtype=torch.float32),
             TEMB=torch.empty((B, D), device=dev, dtype=torch.float32),
-            COND=torch.empty((B, D), device=dev, dtype=torch.float32),
             H1=torch.empty((B, D), device=dev, dtype=torch.float32),
         )
         self._ws = {key: ws}  # keep one shape resident
@@ -270,7 +269,9 @@ class FluxTransformer2DModel(nn.Module):
         ids = torch.cat((txt_ids.to(self.device), img_ids.to(self.device)), dim=0)
         cos, sin = ops.rope_table(ids, cfg.axes_dims_rope)  # FluxPosEmbed, once per prompt (x2i_rope_table_f32)
         # conditioning: text_embedder(pooled) [+ guidance_embedder(guidance*1000)]
-        cond = ws["COND"]
+        # per-state buffer (NOT the shared workspace): two prepared states of the same shape -- positive / negative prompts,
+        # prepare A, prepare B, denoise A -- must not see each other's pooled / guidance conditioning
+        cond = torch.empty((B, D), device=self.device, dtype=torch.float32)
         pooled = pooled_projections.to(device=self.device, dtype=torch.bfloat16).contiguous()
         h1 = ops.skinny_linear(pooled, f["tte.text_embedder.1.w"], f["tte.text_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
         ops.skinny_linear(h1, f["tte.text_embedder.2.w"], f["tte.text_embedder.2.b"], out=cond)
@@ -413,7 +414,7 @@ class FluxTransformer2DModel(nn.Module):
         return cls(**{k: config[k] for k in keys if k in config}, **kw)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder: Optional[str] = None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+    def from_pretrained(cls, path, subfolder: Optional[str] = None, torch_dtype=torch.bfloat16, device=None, **kw):
         """Load a diffusers-format FLUX transformer directory (config.json + *.safetensors shards)."""
         import glob
         import json
@@ -421,6 +422,8 @@ class FluxTransformer2DModel(nn.Module):
 
         from safetensors import safe_open
 
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, "config.json")) as fh:
             cfg = json.load(fh)
@@ -432,7 +435,7 @@ class FluxTransformer2DModel(nn.Module):
                 for k in sf.keys():
                     if k not in own:
                         raise KeyError(f"unexpected key {k} in {shard}")
-                    own[k].data.copy_(sf.get_tensor(k))
+                    own[k].copy_(sf.get_tensor(k))  # (not .data.copy_: keeps the version counter honest)
                     seen.add(k)
         missing = set(own) - seen
         if missing:

@@ -93,8 +93,8 @@ def load_projector(kind, path=None, device="cuda", seed=0):
     if path is None:
         return make(in_channels=C, device=device, **kw).init_random_(seed).eval()
     from ..checkpoints import load_projector_checkpoint
-    proj = load_projector_checkpoint(path, device)
-    got_c = proj.cha_scale.shape[1] if proj.use_scale else proj.conv.weight.shape[1]
+    proj = load_projector_checkpoint(path, device, in_channels=C)
+    got_c = proj.cha_scale.shape[1] if proj.use_scale else (proj.conv.weight.shape[1] if proj.use_cnn else C)
     if got_c != C or proj.mlp.layernorm.weight.shape[0] != HIDDEN[kind]:
         raise ValueError("projector checkpoint %s (C=%d, H=%d) does not match --%s (C=%d, H=%d)"
                          % (path, got_c, proj.mlp.layernorm.weight.shape[0], kind, C, HIDDEN[kind]))

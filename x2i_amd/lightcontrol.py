@@ -33,9 +33,10 @@ class _Conv(nn.Module):
 
     def packed(self):
         """[Cout, ky, kx, Cin] bf16, K-contiguous for the implicit GEMM (repacked once; reference layout is OIHW)."""
-        if self._packed is None or self._packed.device != self.weight.device:
-            self._packed = self.weight.permute(0, 2, 3, 1).reshape(self.weight.shape[0], -1).contiguous()
-        return self._packed
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._packed is None or self._packed[1] != key:  # load_state_dict / in-place updates / moves invalidate the copy
+            self._packed = (self.weight.permute(0, 2, 3, 1).reshape(self.weight.shape[0], -1).contiguous(), key)
+        return self._packed[0]
 
 
 class _Affine(nn.Module):

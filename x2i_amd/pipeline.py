@@ -102,8 +102,48 @@ class FluxPipeline:
         self.control_nets = control_nets
         self._graphs = {}
 
-    def to(self, device):
-        self.transformer.to(device)
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, text_encoder=None, text_encoder_2=None, tokenizer=None,
+                        tokenizer_2=None, vae=None, revision=None, torch_dtype=torch.bfloat16, transformer=None, scheduler=None,
+                        **unused):
+        """The reference's one construction call, unchanged (infer/inference_qwenvl.py:72-73 and the three sibling scripts):
+
+            pipeline = FluxPipeline.from_pretrained(flux_path, text_encoder=None, text_encoder_2=None, tokenizer=None,
+                                                    tokenizer_2=None, vae=None, revision="refs/pr/1", torch_dtype=dtype).to(device)
+
+        Reads `<path>/transformer` (config.json + safetensors shards, diffusers key names) and
+        `<path>/scheduler/scheduler_config.json` (never hard-coded: schnell / shuttle-3 / dev differ).  Text encoders and
+        tokenizers are never used on this path (every script passes None); a `vae` object is kept as given.  `revision`
+        is a hub concept and is ignored for a local directory.  Weights land on the current HIP device when one is visible
+        (the HIP path has no CPU execution) and `.to(device)` moves them like the reference's call chain does."""
+        import json
+        import os
+        for name, v in (("text_encoder", text_encoder), ("text_encoder_2", text_encoder_2), ("tokenizer", tokenizer),
+                        ("tokenizer_2", tokenizer_2)):
+            if v is not None:
+                raise ValueError("x2i_amd FluxPipeline is driven by prompt_embeds: pass %s=None (as the reference does)" % name)
+        if torch_dtype != torch.bfloat16:
+            raise ValueError("x2i_amd: the HIP path computes in bf16 (torch_dtype=torch.bfloat16, the reference's dtype)")
+        path = pretrained_model_name_or_path
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        if transformer is None:
+            from .flux import FluxTransformer2DModel
+            transformer = FluxTransformer2DModel.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype, device=device)
+        if scheduler is None:
+            with open(os.path.join(path, "scheduler", "scheduler_config.json")) as fh:
+                scheduler = FlowMatchEulerDiscreteScheduler.from_config(json.load(fh))
+        return cls(transformer, scheduler, vae=vae)
+
+    def to(self, device=None, dtype=None, **unused):
+        if dtype not in (None, torch.bfloat16):
+            raise ValueError("x2i_amd FluxPipeline is bf16-only")
+        if device is not None:
+            self.transformer.to(device)
+            for n in (self.control_nets or []):
+                n.to(device)
+            if self.vae is not None and hasattr(self.vae, "to"):
+                self.vae.to(device)
+            self._graphs = {}
         return self
 
     @property
@@ -238,6 +278,33 @@ class FluxPipeline:
             return None
         from .lightcontrol import make_control_fn
         return make_control_fn(self.control_nets, hint)
+
+
+class VaeImageProcessor:
+    """diffusers.image_processor.VaeImageProcessor(vae_scale_factor).postprocess(image, output_type=) as the reference uses it
+    after vae.decode (infer/inference_qwenvl.py:210,216): denormalise [-1,1] -> [0,1], clamp, NCHW -> NHWC uint8 -> PIL."""
+
+    def __init__(self, vae_scale_factor: int = 8, do_normalize: bool = True):
+        self.vae_scale_factor = vae_scale_factor
+        self.do_normalize = do_normalize
+
+    @staticmethod
+    def denormalize(images):
+        return (images / 2 + 0.5).clamp(0, 1)
+
+    def postprocess(self, image, output_type: str = "pil"):
+        image = image.detach().float()
+        if self.do_normalize:
+            image = self.denormalize(image)
+        if output_type == "pt":
+            return image
+        arr = image.cpu().permute(0, 2, 3, 1).numpy()
+        if output_type == "np":
+            return arr
+        if output_type != "pil":
+            raise ValueError("output_type must be 'pil', 'np' or 'pt'")
+        from PIL import Image
+        return [Image.fromarray(a) for a in (arr * 255).round().astype("uint8")]
 
 
 class _Cfg(dict):

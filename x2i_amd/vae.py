@@ -30,7 +30,8 @@ class _Conv(nn.Module):
 
     def packed(self, cin_pad=None, cout_pad=None):
         """[Cout, ky, kx, Cin] bf16; optionally zero-padded along Cin (16 -> 64) or Cout."""
-        if self._packed is None or self._packed[0].device != self.weight.device:
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), cin_pad, cout_pad)
+        if self._packed is None or self._packed[2] != key:  # load_state_dict / in-place updates / other pads invalidate
             w = self.weight.permute(0, 2, 3, 1)
             b = self.bias
             if cin_pad and cin_pad > w.shape[3]:
@@ -38,8 +39,8 @@ class _Conv(nn.Module):
             if cout_pad and cout_pad > w.shape[0]:
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
                 b = torch.nn.functional.pad(b, (0, cout_pad - b.shape[0]))
-            self._packed = (w.reshape(w.shape[0], -1).contiguous(), b.contiguous())
-        return self._packed
+            self._packed = (w.reshape(w.shape[0], -1).contiguous(), b.contiguous(), key)
+        return self._packed[0], self._packed[1]
 
 
 class _Vec(nn.Module):
@@ -184,6 +185,8 @@ class AutoencoderKL(nn.Module):
 
     def load_state_dict(self, sd, strict=True):
         """Accepts a full AutoencoderKL checkpoint: encoder.* / quant_conv.* / post_quant_conv.* keys are ignored."""
+        if any(k.startswith("post_quant_conv.") for k in sd) and self.config.get("use_post_quant_conv", False):
+            raise NotImplementedError("x2i_amd VAE: use_post_quant_conv=True is not supported (the FLUX VAE has none)")
         dec = {k: v for k, v in sd.items() if k.startswith("decoder.")}
         return super().load_state_dict(dec, strict=strict)
 
@@ -217,18 +220,22 @@ class AutoencoderKL(nn.Module):
         return _Cfg(sample=img)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, torch_dtype=torch.bfloat16, device="cuda", **kw):
+    def from_pretrained(cls, path, subfolder=None, torch_dtype=torch.bfloat16, device=None, **kw):
         """diffusers directory layout: <path>/<subfolder>/config.json + *.safetensors (decoder.* keys are used)."""
         import glob
         import json
         import os
 
         from safetensors import safe_open
+        if device is None:  # `.from_pretrained(...).to(device)` call chains: land on the visible HIP device, else the CPU
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, "config.json")) as fh:
             c = json.load(fh)
         keys = ("latent_channels", "out_channels", "block_out_channels", "layers_per_block", "norm_num_groups", "scaling_factor",
                 "shift_factor")
+        if c.get("use_post_quant_conv", False):
+            raise NotImplementedError("x2i_amd VAE: config has use_post_quant_conv=true; the decoder here starts at conv_in (FLUX)")
         vae = cls(**{k: c[k] for k in keys if k in c}, device=device)
         own = dict(vae.named_parameters())
         seen = set()
@@ -236,7 +243,7 @@ class AutoencoderKL(nn.Module):
             with safe_open(shard, framework="pt", device="cpu") as sf:
                 for k in sf.keys():
                     if k in own:
-                        own[k].data.copy_(sf.get_tensor(k))
+                        own[k].copy_(sf.get_tensor(k))  # (not .data.copy_: keeps the version counter honest)
                         seen.add(k)
         missing = set(own) - seen
         if missing:
