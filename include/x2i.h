@@ -87,6 +87,40 @@ typedef struct x2i_gemm_args {
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * fp8 path (BASELINE north_star: "MFMA bf16/fp8 for the QKV/out-proj and MLP GEMMs"; the reference has no fp8 code -- the
+ * linears this stands behind are the same as x2i_gemm_bf16's, first of all FeedForward ff.net.0 / ff.net.2 and the single
+ * blocks' proj_mlp / proj_out, lightcontrol_flux.py:64-66,150-153).  Operands are OCP e4m3fn bytes; the product is
+ *     C[z][m][n] = epi( a_scale[z][m] * w_scale[n] * alpha * sum_k A8[z][m][k] * W8[n][k] )
+ * with the epilogue of x2i_gemm_bf16 (bias, GELU-tanh, gate * v + residual; bf16 output) or, with out_fp8, an e4m3 output
+ * sat(epi * out_inv_scale) that is the next GEMM's A operand.  `args` is read as for x2i_gemm_bf16 with A / W pointing at e4m3
+ * bytes and lda / ldw / K counted in elements (= bytes); ldc counts output elements.  Served shapes: K % 128 == 0, lda / ldw %
+ * 16 == 0, N % 8 == 0 (N % 16 for out_fp8); anything else returns X2I_ERR_ALIGN / X2I_ERR_SHAPE -- callers keep such linears on
+ * the bf16 entry point.  bf16 remains the default arithmetic of the path; fp8 is opt-in per model (x2i_amd: fp8= argument). */
+typedef struct x2i_fp8_desc {
+  const float* a_scale;          /* f32 [batch][M] per-row dequantisation scale of A (NULL: 1) */
+  int64_t a_scale_batch_stride;
+  const float* w_scale;          /* f32 [N] per-output-channel dequantisation scale of W (NULL: 1) */
+  float alpha;                   /* scalar factor on the product (static per-tensor activation scale), normally 1 */
+  int32_t out_fp8;               /* 1: C is e4m3 */
+  float out_inv_scale;           /* e4m3 output = sat(value * out_inv_scale); the consumer passes alpha = 1 / out_inv_scale */
+} x2i_fp8_desc;
+int x2i_gemm_fp8(const x2i_gemm_args* args, const x2i_fp8_desc* fp8, x2i_stream_t stream);
+
+/* Row-wise e4m3 quantisation of a bf16 matrix x [rows][cols] (row stride ldx elements): scale[r] = amax(|x[r]|) / 448 (1 when the
+ * row is zero), y[r][c] = e4m3_rne(x[r][c] / scale[r]).  Used once per weight (per-output-channel scales) and for activations
+ * that have no producing kernel to fuse into.  scale == NULL: static quantisation y = sat(x * static_inv_scale).  cols % 8 == 0. */
+int x2i_quantize_rows_fp8(const void* x, int64_t rows, int32_t cols, int64_t ldx, void* y, int64_t ldy, float* scale,
+                          float static_inv_scale, x2i_stream_t stream);
+
+/* x2i_ln_modulate_bf16 with an additional e4m3 output: Y8[b][s][:] = e4m3(y / row_scale[b*S + s]), row_scale = amax(|y|) / 448,
+ * where y is the modulated LayerNorm output (the A operand of the following fp8 GEMM).  Y (bf16) may be NULL when no bf16
+ * consumer exists (the double blocks' feed-forward norm); Y8 row stride ldy8 bytes. */
+int x2i_ln_modulate_fp8(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64_t y_bs, int32_t ldy, void* Y8, int64_t y8_bs,
+                        int32_t ldy8, float* row_scale, int32_t B, int32_t S, int32_t D, int32_t S0, const float* shift0,
+                        const float* scale0, const float* shift1, const float* scale1, int64_t mod_bs, float eps,
+                        x2i_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * nn.Conv2d as an implicit GEMM on NHWC bf16 activations (ControlNeXt hint encoder, lightcontrol_flux.py:593-668,
  * diffusers ResnetBlock2D / Downsample2D convs).  `args` is the GEMM view: A = input [batch][H][W][Cin] (a_batch_stride
  * = H*W*Cin; lda unused), W = weight repacked to [Cout][KH][KW][Cin] (ldw = KH*KW*Cin), M = OH*OW per batch,

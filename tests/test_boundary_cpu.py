@@ -54,12 +54,14 @@ def test_descriptor_structs_header_and_binding_agree():
     from x2i_amd import _lib
     assert ctypes_struct(_lib.ConvDesc) == header_struct("x2i_conv_desc")
     assert ctypes_struct(_lib.QkvDesc) == header_struct("x2i_qkv_desc")
+    assert ctypes_struct(_lib.Fp8Desc) == header_struct("x2i_fp8_desc")
 
 
 def test_struct_layout_matches_the_compiled_abi(tmp_path):
     """sizeof / offsetof from a C compiler over the public header == ctypes' layout (same natural-alignment rules, but checked)."""
     from x2i_amd import _lib
-    structs = {"x2i_gemm_args": _lib.GemmArgs, "x2i_conv_desc": _lib.ConvDesc, "x2i_qkv_desc": _lib.QkvDesc}
+    structs = {"x2i_gemm_args": _lib.GemmArgs, "x2i_conv_desc": _lib.ConvDesc, "x2i_qkv_desc": _lib.QkvDesc,
+               "x2i_fp8_desc": _lib.Fp8Desc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "x2i.h"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -1,0 +1,115 @@
+"""fp8 (OCP e4m3fn) path, row F8: quantisation kernels bit-exact against torch's float8_e4m3fn conversion, the MX-scaled K = 128
+MFMA GEMM against an fp32 matmul of the SAME dequantised operands (tight: only the accumulation order differs), its epilogues,
+and the stated end-to-end tolerance of fp8 against the unquantised fp32 result (per GEMM rel-L2 <= 6e-2: two operands with a
+3-bit mantissa each)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP8 = torch.float8_e4m3fn
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def deq(x8, scale=None):
+    x = x8.float().cpu()
+    return x if scale is None else x * scale.float().cpu()[:, None]
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 64), (300, 3072), (64, 12288), (7, 520)])
+def test_quantize_rows_bit_exact_vs_torch_e4m3fn(rows, cols):
+    from x2i_amd import ops
+    x = bf(seeded((rows, cols), 1, 3.0))
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -2e-3, 448.0, -448.0, 0.0156, 0.3])
+    if rows > 4:
+        x[3] = 0  # an all-zero row: scale 1, zeros out
+    y, s = ops.quantize_rows_fp8(x.to(DEV))
+    amax = x.float().abs().amax(1)
+    want_s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    assert torch.equal(s.cpu(), want_s)
+    want = (x.float() * (1.0 / want_s)[:, None]).clamp(-448, 448).to(FP8)
+    assert torch.equal(y.cpu().view(torch.uint8), want.view(torch.uint8))
+    # static form: saturating
+    y2, s2 = ops.quantize_rows_fp8(x.to(DEV), static_inv_scale=200.0)
+    assert s2 is None
+    want2 = (x.float() * 200.0).clamp(-448, 448).to(FP8)
+    assert torch.equal(y2.cpu().view(torch.uint8), want2.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 256), (700, 520, 1152), (4096, 3072, 3072), (1024, 12288, 3072)])
+def test_gemm_fp8_vs_fp32_matmul_of_the_same_operands(M, N, K):
+    """Asymmetric operands + per-row / per-column scales: catches any k-permutation or row/column mix-up of the MX MFMA."""
+    from x2i_amd import ops
+    A, W = bf(seeded((M, K), 2)), bf(seeded((N, K), 3, 0.05))
+    A[:, ::7] *= 3.0  # make columns distinguishable
+    b = bf(seeded((N,), 4))
+    A8, sa = ops.quantize_rows_fp8(A.to(DEV))
+    W8, sw = ops.quantize_rows_fp8(W.to(DEV))
+    out = ops.gemm_fp8(A8, W8, b.to(DEV), a_scale=sa, w_scale=sw)
+    ref = deq(A8, sa) @ deq(W8, sw).T + b.float()
+    assert out.shape == (M, N) and rel_l2(out, ref) < 4e-3  # bf16 output rounding dominates
+    assert rel_l2(out, F.linear(A.float(), W.float(), b.float())) < 6e-2  # fp8 vs unquantised fp32 (stated tolerance)
+    ident = ops.gemm_fp8(A8, W8, None, alpha=0.5)  # unit scales, alpha only
+    assert rel_l2(ident, 0.5 * (deq(A8) @ deq(W8).T)) < 4e-3
+
+
+def test_gemm_fp8_epilogues_gelu_e4m3_out_and_gated_residual():
+    from x2i_amd import ops
+    B, S, K, N = 2, 1536, 512, 1024
+    X = bf(seeded((B, S, K), 5))
+    W1, b1 = bf(seeded((N, K), 6, 0.05)), bf(seeded((N,), 7))
+    W2, b2 = bf(seeded((K, N), 8, 0.03)), bf(seeded((K,), 9))
+    X8, sx = ops.quantize_rows_fp8(X.to(DEV).view(B * S, K))
+    W18, sw1 = ops.quantize_rows_fp8(W1.to(DEV))
+    W28, sw2 = ops.quantize_rows_fp8(W2.to(DEV))
+    # ff.net.0 + GELU(tanh) -> e4m3 hidden (static scale 1: GELU outputs live well inside +-448)
+    H8 = ops.gemm_fp8(X8, W18, b1.to(DEV), a_scale=sx, w_scale=sw1, act=ops.ACT_GELU_TANH, out_fp8=True, out_inv_scale=1.0)
+    assert H8.dtype == FP8
+    h_ref = F.gelu(deq(X8, sx) @ deq(W18, sw1).T + b1.float(), approximate="tanh")
+    want8 = h_ref.clamp(-448, 448).to(FP8)
+    got = H8.float().cpu()
+    # e4m3 rounding of a value that sits within fp32 accumulation noise of a rounding boundary may flip by one code
+    mism = (H8.cpu().view(torch.uint8) != want8.view(torch.uint8)).float().mean()
+    assert mism < 2e-3 and rel_l2(got, h_ref) < 4e-2
+    # ff.net.2 with gate * v + residual, batched like the model launches it
+    res = bf(seeded((B, S, K), 10))
+    gate = seeded((B, K), 11)
+    out = res.to(DEV).clone()
+    ops.gemm_fp8(H8, W28, b2.to(DEV), out=out, M=S, batch=B, a_batch_stride=S * N, lda=N, w_scale=sw2, c_batch_stride=S * K, ldc=K,
+                 res=out, res_batch_stride=S * K, ldr=K, gate=gate.to(DEV), gate_batch_stride=K)
+    ref = res.float() + gate[:, None, :] * ((got.view(B, S, N) @ deq(W28, sw2).T) + b2.float())
+    assert rel_l2(out, ref) < 4e-3
+    # unsupported shapes are refused loudly (no silent slow path)
+    from x2i_amd._lib import X2IError
+    with pytest.raises(X2IError):
+        ops.gemm_fp8(X8[:, :192].contiguous(), W18[:, :192].contiguous(), None)  # K % 128 != 0
+
+
+def test_ln_modulate_fp8_matches_bf16_kernel_and_torch():
+    from x2i_amd import ops
+    B, S, D, S0 = 2, 300, 3072, 44
+    X = bf(seeded((B, S, D), 12, 2.0) + 0.3)
+    mod = seeded((B, 4 * D), 13, 0.3)
+    Xd, md = X.to(DEV), mod.to(DEV)
+    Y = torch.empty_like(Xd)
+    ops.ln_modulate(Xd, Y, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)
+    Y2 = torch.empty_like(Xd)
+    Y8 = torch.empty((B, S, D), device=DEV, dtype=FP8)
+    rs = torch.empty((B * S,), device=DEV, dtype=torch.float32)
+    ops.ln_modulate_fp8(Xd, Y2, Y8, rs, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)
+    assert torch.equal(Y2, Y)  # the bf16 output is the same arithmetic
+    ln = F.layer_norm(X.float(), (D,), eps=1e-6)
+    sh = torch.cat([mod[:, None, :D].expand(B, S0, D), mod[:, None, 2 * D:3 * D].expand(B, S - S0, D)], 1)
+    sc = torch.cat([mod[:, None, D:2 * D].expand(B, S0, D), mod[:, None, 3 * D:].expand(B, S - S0, D)], 1)
+    y = ln * (1 + sc) + sh
+    want_s = y.abs().amax(-1).flatten() / 448
+    assert torch.allclose(rs.cpu(), want_s, rtol=1e-4)
+    assert rel_l2(Y8.float().cpu() * rs.cpu().view(B, S, 1), y) < 3e-2  # e4m3: 3 mantissa bits
+    assert float(Y8.float().abs().max()) == 448.0
+    ops.ln_modulate_fp8(Xd, None, Y8, rs, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)  # bf16 output optional

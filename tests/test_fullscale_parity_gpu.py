@@ -144,7 +144,7 @@ def full_dev_model():
 def test_full_depth_19_38_forward_at_512_vs_oracle(full_dev_model):
     """All 57 blocks (11.9 B parameters) at BASELINE configs[0]'s shape -- 512x512, S = 512 + 1024, B = 1 -- against the fp32
     CPU oracle evaluated on the same bf16-rounded weights.  Stated drift bound: the bf16 residual stream + bf16 GEMM inputs
-    accumulate rounding over 57 blocks; rel-L2 of the final noise prediction <= 3e-2 (measured ~1e-2), and no worse than
+    accumulate rounding over 57 blocks; rel-L2 of the final noise prediction <= 3e-2 (measured 1.47e-2 on MI355X), and no worse than
     3x the single-block error budget used elsewhere (2e-2 for 1+1 blocks)."""
     m = full_dev_model
     sd = _LazyF32({k: v.detach().to("cpu") for k, v in m.state_dict().items()})
@@ -155,7 +155,10 @@ def test_full_depth_19_38_forward_at_512_vs_oracle(full_dev_model):
     out = m(hidden_states=hidden.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV),
             timestep=ts.to(DEV), img_ids=img_ids.to(DEV), txt_ids=txt_ids.to(DEV), guidance=gd.to(DEV), control_nets=[],
             guided_hint=None, return_dict=False)
-    ref = OF.flux_forward(sd, cfg, hidden.float(), enc.float(), pooled.float(), ts, img_ids, txt_ids, guidance=gd)
+    # the reference multiplies timestep / guidance by 1000 in the caller's dtype (lightcontrol_flux.py:447,449): in its bf16 run
+    # 3.5 * 1000 rounds to 3504, so the fp32 oracle is handed the value the bf16 run really embeds (0.5 * 1000 = 500 is exact)
+    gd_eff = (gd.bfloat16() * 1000).float() / 1000
+    ref = OF.flux_forward(sd, cfg, hidden.float(), enc.float(), pooled.float(), ts, img_ids, txt_ids, guidance=gd_eff)
     err = rel_l2(out, ref)
     print(f"full-depth 19+38 @512^2 rel-L2 vs fp32 oracle: {err:.3e}")
     assert out.shape == (1, 1024, 64) and torch.isfinite(out.float()).all()

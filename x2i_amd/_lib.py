@@ -46,6 +46,11 @@ class QkvDesc(C.Structure):
                 ("eps", C.c_float)]
 
 
+class Fp8Desc(C.Structure):
+    _fields_ = [("a_scale", C.c_void_p), ("a_scale_batch_stride", C.c_int64), ("w_scale", C.c_void_p), ("alpha", C.c_float),
+                ("out_fp8", C.c_int32), ("out_inv_scale", C.c_float)]
+
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (restype is int for all but the two below); mirrors include/x2i.h exactly
@@ -53,6 +58,10 @@ SIGNATURES = {
     "x2i_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "x2i_conv2d_nhwc_bf16": [C.POINTER(GemmArgs), C.POINTER(ConvDesc), _vp],
     "x2i_gemm_qkv_bf16": [C.POINTER(GemmArgs), C.POINTER(QkvDesc), _vp],
+    "x2i_gemm_fp8": [C.POINTER(GemmArgs), C.POINTER(Fp8Desc), _vp],
+    "x2i_quantize_rows_fp8": [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _f32, _vp],
+    "x2i_ln_modulate_fp8": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64,
+                            _f32, _vp],
     "x2i_conv_stem_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_groupnorm_nhwc_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],

@@ -118,6 +118,23 @@ const char* x2i_last_error(void) { return g_err; }
 
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream) { return x2i_launch_gemm(args, (hipStream_t)stream); }
 
+int x2i_gemm_fp8(const x2i_gemm_args* args, const x2i_fp8_desc* fp8, x2i_stream_t stream) {
+  return x2i_launch_gemm_fp8(args, fp8, (hipStream_t)stream);
+}
+
+int x2i_quantize_rows_fp8(const void* x, int64_t rows, int32_t cols, int64_t ldx, void* y, int64_t ldy, float* scale,
+                          float static_inv_scale, x2i_stream_t stream) {
+  return x2i_launch_quantize_rows_fp8(x, rows, cols, ldx, y, ldy, scale, static_inv_scale, (hipStream_t)stream);
+}
+
+int x2i_ln_modulate_fp8(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64_t y_bs, int32_t ldy, void* Y8, int64_t y8_bs,
+                        int32_t ldy8, float* row_scale, int32_t B, int32_t S, int32_t D, int32_t S0, const float* shift0,
+                        const float* scale0, const float* shift1, const float* scale1, int64_t mod_bs, float eps,
+                        x2i_stream_t stream) {
+  return x2i_launch_ln_modulate_fp8(X, x_bs, ldx, Y, y_bs, ldy, Y8, y8_bs, ldy8, row_scale, B, S, D, S0, shift0, scale0, shift1, scale1,
+                                    mod_bs, eps, (hipStream_t)stream);
+}
+
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream) {
   if (!conv) return x2i_set_error(X2I_ERR_ARG, "conv2d: null descriptor");
   return x2i_launch_gemm_conv(args, conv, (hipStream_t)stream);

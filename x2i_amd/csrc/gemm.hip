@@ -86,6 +86,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   p.gm = 4;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
+  p.f_sa = p.f_sw = nullptr; p.f_sa_bs = 0; p.f_alpha = p.f_oinv = 1.f; p.f_out8 = 0;
   if (qd) {
     p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps;
     p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
@@ -200,4 +201,52 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     opt.last_gemm_tile = 0;
   }
   return x2i_check_launch("gemm");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp8 (e4m3) operands: x2i_gemm_fp8.  One kernel family (256^2 tiles, gemm256_fp8.hip); shapes it does not serve are refused
+// with a message -- the host keeps those GEMMs on the bf16 path (there is no silent slow fallback).
+int x2i_launch_gemm_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, hipStream_t stream) {
+  if (!a || !f || !a->A || !a->W || !a->C) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: null pointer");
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm_fp8: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
+  if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: gate without residual");
+  if (a->C2 || a->out_f32 || a->w_batch_stride) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: C2 / f32 output / per-batch W are not supported");
+  if (a->K % 128 || a->lda % 16 || a->ldw % 16 || (a->a_batch_stride & 15) || (((uintptr_t)a->A | (uintptr_t)a->W) & 15))
+    return x2i_set_error(X2I_ERR_ALIGN, "gemm_fp8: needs K %% 128 == 0 (K=%d), lda / ldw / a_batch_stride %% 16 == 0, 16-byte aligned A / W", a->K);
+  if ((long long)a->M * a->lda >= 0x7f000000LL || (long long)a->N * a->ldw >= 0x7f000000LL)
+    return x2i_set_error(X2I_ERR_SHAPE, "gemm_fp8: operand larger than 2 GB per batch item");
+  const bool out8 = f->out_fp8 != 0, res = a->res != nullptr;
+  const int nal = out8 ? 15 : 7;
+  if ((a->N & nal) || (a->ldc & nal) || (a->c_batch_stride & nal) || (((uintptr_t)a->C) & 15) || (res && ((a->ldr & 7) || (a->res_batch_stride & 7))))
+    return x2i_set_error(X2I_ERR_ALIGN, "gemm_fp8: N, ldc and c_batch_stride must be multiples of %d, C 16-byte aligned", nal + 1);
+  if (out8 && (res || a->gate)) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: e4m3 output has no residual form");
+  kern_t kern = pick_gemm256_fp8(a->act, res, out8);
+  if (!kern) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: epilogue (act=%d%s%s) is not instantiated", a->act, res ? ", residual" : "", out8 ? ", e4m3 out" : "");
+  GemmP p;
+  p.A = (const bf16_t*)a->A; p.a_bs = a->a_batch_stride; p.lda = a->lda;
+  p.W = (const bf16_t*)a->W; p.ldw = a->ldw; p.w_bs = 0;
+  p.bias = (const bf16_t*)a->bias;
+  p.C = a->C; p.c_bs = a->c_batch_stride; p.ldc = a->ldc;
+  p.C2 = nullptr; p.act2 = 0;
+  p.gate = a->gate; p.gate_bs = a->gate_batch_stride;
+  p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
+  p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
+  p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f;
+  p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
+  p.f_sa = f->a_scale; p.f_sa_bs = f->a_scale_batch_stride; p.f_sw = f->w_scale; p.f_alpha = f->alpha; p.f_oinv = f->out_inv_scale;
+  p.f_out8 = out8 ? 1 : 0;
+  const int tm = (a->M + BM2 - 1) / BM2, tn = (a->N + BN2 - 1) / BN2;
+  p.tilesM = tm; p.tilesN = tn;
+  const X2IOptions& opt = x2i_options();
+  if (opt.gemm_gm > 0) p.gm = opt.gemm_gm;
+  else if (tn <= 16) p.gm = a->K >= 16384 ? 1 : 4;
+  else if (tn <= 64) p.gm = 6;
+  else p.gm = 2;
+  const int rc = x2i_ensure_dynamic_smem((const void*)kern, SMEM2_BYTES);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(tm * tn, a->batch), dim3(512), SMEM2_BYTES, stream, p);
+  return x2i_check_launch("gemm_fp8");
 }

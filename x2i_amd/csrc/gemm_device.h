@@ -31,6 +31,12 @@ struct GemmP {
   const bf16_t *q_nq, *q_nk;
   const float *q_cos, *q_sin;
   bf16_t *q_Q, *q_K, *q_VT;
+  // fp8 (e4m3) operands (x2i_gemm_fp8): acc * f_sa[z][m] * f_sw[n] * f_alpha replaces acc in every epilogue; f_out8 = 1: C is
+  // e4m3, value = sat(epi * f_oinv)
+  const float* f_sa; long long f_sa_bs;
+  const float* f_sw;
+  float f_alpha, f_oinv;
+  int f_out8;
 };
 
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
@@ -421,6 +427,7 @@ typedef void (*kern_t)(GemmP);
 // for this epilogue combination
 kern_t pick_gemm128(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
+kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION
 kern_t pick_gemm256u(int act, bool res, bool f32, bool c2, int abl);  // k-half-unit form + measurement-only variants
 #endif

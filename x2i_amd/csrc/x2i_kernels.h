@@ -6,6 +6,12 @@
 int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream);
 int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream);
 int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStream_t stream);
+int x2i_launch_gemm_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, hipStream_t stream);
+int x2i_launch_quantize_rows_fp8(const void* x, long long rows, int cols, long long ldx, void* y, long long ldy, float* scale,
+                                 float static_inv_scale, hipStream_t stream);
+int x2i_launch_ln_modulate_fp8(const void* X, long long x_bs, int ldx, void* Y, long long y_bs, int ldy, void* Y8, long long y8_bs,
+                               int ldy8, float* row_scale, int B, int S, int D, int S0, const float* shift0, const float* scale0,
+                               const float* shift1, const float* scale1, long long mod_bs, float eps, hipStream_t stream);
 int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout,
                          hipStream_t stream);
 long long x2i_groupnorm_scratch(int B, int G);

@@ -319,3 +319,84 @@ def softmax_rows_(x, scale=1.0):
     cols = x.shape[-1]
     check(lib.x2i_softmax_rows_bf16(_p(x), x.numel() // cols, cols, scale, _stream()), "softmax_rows")
     return x
+
+
+# ---------------------------------------------------------------------------------------------------- fp8 (e4m3) path
+from ._lib import Fp8Desc  # noqa: E402
+
+FP8 = torch.float8_e4m3fn
+E4M3_MAX = 448.0
+
+
+def quantize_rows_fp8(x, static_inv_scale=None):
+    """bf16 [rows, cols] -> (e4m3 [rows, cols], f32 [rows] scales) with scale = amax / 448 per row; or, with
+    `static_inv_scale`, (e4m3, None) with y = sat(x * static_inv_scale)."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty(x.shape, device=x.device, dtype=FP8)
+    scale = None if static_inv_scale is not None else torch.empty((rows,), device=x.device, dtype=torch.float32)
+    check(lib.x2i_quantize_rows_fp8(_p(x), rows, cols, x.stride(-2) if x.dim() > 1 else cols, _p(y), cols, _p(scale),
+                                    1.0 if static_inv_scale is None else float(static_inv_scale), _stream()), "quantize_rows_fp8")
+    return y, scale
+
+
+def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_batch_stride=0, lda=None, a_offset=0, a_scale=None,
+             a_scale_batch_stride=0, w_scale=None, alpha=1.0, c_batch_stride=0, ldc=None, c_offset=0, act=ACT_NONE, gate=None,
+             gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, res_offset=0, out_fp8=False, out_inv_scale=1.0):
+    """C = epi(a_scale[m] * w_scale[n] * alpha * A8 W8^T) on e4m3 operands (include/x2i.h: x2i_gemm_fp8)."""
+    lib = _lib.load()
+    _req(A8, FP8, "A8")
+    _req(W8, FP8, "W8")
+    N = W8.shape[-2] if N is None else N
+    K = W8.shape[-1] if K is None else K
+    if M is None:
+        M = A8.numel() // A8.shape[-1]
+    lda = A8.shape[-1] if lda is None else lda
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=A8.device, dtype=FP8 if out_fp8 else torch.bfloat16)
+        if batch > 1:
+            c_batch_stride = M * N
+    ldc = N if ldc is None else ldc
+    esz = 1 if out_fp8 else 2
+    a = GemmArgs()
+    a.A = A8.data_ptr() + a_offset
+    a.a_batch_stride, a.lda = a_batch_stride, lda
+    a.W, a.ldw = W8.data_ptr(), W8.stride(-2)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C = out.data_ptr() + c_offset * esz
+    a.c_batch_stride, a.ldc = c_batch_stride, ldc
+    a.C2, a.act2 = None, 0
+    a.gate = gate.data_ptr() if gate is not None else None
+    a.gate_batch_stride = gate_batch_stride
+    a.res = (res.data_ptr() + res_offset * 2) if res is not None else None
+    a.res_batch_stride = res_batch_stride
+    a.ldr = ldc if ldr is None else ldr
+    a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.act, a.out_f32 = act, 0
+    f = Fp8Desc()
+    f.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    f.a_scale_batch_stride = a_scale_batch_stride
+    f.w_scale = w_scale.data_ptr() if w_scale is not None else None
+    f.alpha, f.out_fp8, f.out_inv_scale = float(alpha), 1 if out_fp8 else 0, float(out_inv_scale)
+    check(lib.x2i_gemm_fp8(C.byref(a), C.byref(f), _stream()), "gemm_fp8")
+    return out
+
+
+def ln_modulate_fp8(X, Y, Y8, row_scale, B, S, D, S0, shift0, scale0, shift1, scale1, mod_bs, eps=1e-6, x_bs=None, ldx=None,
+                    y_bs=None, ldy=None, x_offset=0, y_offset=0, y8_bs=None, ldy8=None, y8_offset=0):
+    """ln_modulate with an extra e4m3 output + per-row scales (Y may be None)."""
+    lib = _lib.load()
+    ldx = D if ldx is None else ldx
+    ldy = D if ldy is None else ldy
+    ldy8 = D if ldy8 is None else ldy8
+    x_bs = S * ldx if x_bs is None else x_bs
+    y_bs = S * ldy if y_bs is None else y_bs
+    y8_bs = S * ldy8 if y8_bs is None else y8_bs
+    yp = C.c_void_p(Y.data_ptr() + 2 * y_offset) if Y is not None else C.c_void_p(0)
+    check(lib.x2i_ln_modulate_fp8(C.c_void_p(X.data_ptr() + 2 * x_offset), x_bs, ldx, yp, y_bs, ldy,
+                                  C.c_void_p(Y8.data_ptr() + y8_offset), y8_bs, ldy8, _p(row_scale), B, S, D, S0, _p(shift0), _p(scale0),
+                                  _p(shift1), _p(scale1), mod_bs, eps, _stream()), "ln_modulate_fp8")
+    return Y8
