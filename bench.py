@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8 = 5.0e15   # dense MFMA fp8 (MX-scaled K=128), same guide
 PEAK_HBM = 8.0e12
 
 
@@ -81,6 +82,40 @@ def gemm_roofline(B, iters=10):
     return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_BF16,
                 traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256l_bf16_kernel",
                 shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out as launched, 1.39 + 1.74 TFLOP)" % (B * S))
+
+
+def gemm_roofline_fp8(B, iters=10):
+    """--dtype fp8: the same two launches on the e4m3 kernel (gemm256_fp8_kernel: MX-scaled K=128 MFMA), priced against the 5 PF
+    dense fp8 peak.  proj_mlp + GELU writes e4m3, proj_out carries the gated residual, exactly as the fp8 model issues them."""
+    from x2i_amd import ops
+    D, S = 3072, 4608
+    res = []
+    for (M, N, K, gelu) in ((B * S, 4 * D, D, True), (B * S, D, 5 * D, False)):
+        A8, sa = ops.quantize_rows_fp8(torch.randn(M, K, device="cuda").bfloat16())
+        W8, sw = ops.quantize_rows_fp8((torch.randn(N, K, device="cuda") * 0.02).bfloat16())
+        bias = torch.randn(N, device="cuda").bfloat16()
+        out = torch.empty(M, N, device="cuda", dtype=ops.FP8 if gelu else torch.bfloat16)
+        gate = torch.randn(1, N, device="cuda")
+        if gelu:
+            fn = lambda: ops.gemm_fp8(A8, W8, bias, out=out, a_scale=sa, w_scale=sw, act=1, out_fp8=True)  # noqa: E731
+        else:
+            fn = lambda: ops.gemm_fp8(A8, W8, bias, out=out, w_scale=sw, res=out, gate=gate)  # noqa: E731
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        res.append((2.0 * M * N * K, s.elapsed_time(e) / iters * 1e-3))
+        del A8, W8, out
+    fl, tt = sum(r[0] for r in res), sum(r[1] for r in res)
+    alg_bytes = (B * S * D + 4 * D * D + B * S * 4 * D) + (B * S * 5 * D + 5 * D * D + 2 * 2 * B * S * D)
+    return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_FP8 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_FP8, traffic=None,
+                algorithmic_bytes=float(alg_bytes), kernel="gemm256_fp8_kernel",
+                shapes="M=%d: N=12288,K=3072 (+GELU, e4m3 out) + N=3072,K=15360 (gated residual), e4m3 operands" % (B * S))
 
 
 def _pick_cpu_threads():
@@ -146,6 +181,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = Qwen-3B/shuttle-3 (default, the bench line), 3 = MiniCPM projector, "
                          "4 = InternVL-4B projector, 5 = LightControl edit branch (FLUX.1-dev schedule, 20 steps, 19 ControlNeXt)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="bf16 (default, the headline arithmetic = the reference's) or fp8: the MLP GEMMs (72 %% of the GEMM FLOPs) on "
+                         "e4m3 MFMA (FluxTransformer2DModel.enable_fp8), reported as a separate line with its own tolerance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -195,6 +233,8 @@ def main():
     else:
         model = FluxTransformer2DModel(device=dev).init_random_(seed=1234 + rank)
         pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
+    if args.dtype == "fp8":
+        model.enable_fp8("mlp")
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     mllm_hidden = (torch.randn((B, C, St, Hm), device=dev, generator=g) * 3.0).bfloat16()
     noise = torch.randn((B, (args.size // 16) ** 2, 64), device=dev, generator=g).bfloat16()
@@ -252,7 +292,15 @@ def main():
             line["metric"] = "images/sec, LightControl FLUX.1-dev 1024x1024 %d-step (projector + denoise loop), whole job" % N
             line["model_tflops_per_gpu"] = (fl + 8.30e12 * B) * N / (ms_pass * 1e-3) / 1e12  # + 19 x 436.8 GFLOP per image-step
             line["model_frac_of_bf16_peak"] = line["model_tflops_per_gpu"] * 1e12 / PEAK_BF16
-        line["roofline"] = gemm_roofline(B)
+        if args.dtype == "fp8":
+            line["dtype"] = "fp8"
+            line["dtype_detail"] = ("e4m3 (OCP) operands with fp32 accumulation for ff.net.0/ff.net.2 (image stream) and the single blocks' "
+                                    "proj_mlp/proj_out = 72% of the GEMM FLOPs; everything else bf16 as in the headline run; stated tolerance "
+                                    "vs the fp32 oracle in tests/test_fp8_gpu.py")
+            line["metric"] += " [fp8 MLP GEMMs]"
+            line["roofline"] = gemm_roofline_fp8(B)
+        else:
+            line["roofline"] = gemm_roofline(B)
         if not args.no_cpu_baseline and world == 1 and args.config == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -156,6 +156,11 @@ int x2i_groupnorm_nhwc_bf16(const void* x, void* y, int32_t B, int64_t HW, int32
 int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
                        int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
 
+/* The same attention with an e4m3 output O8[b][s][h*128 + d] = sat(o * out_inv_scale) (ldo / o_batch_stride in bytes, multiples
+ * of 8): the A operand of an fp8 projection (single blocks' proj_out in the fp8 configuration), no bf16 round trip. */
+int x2i_attention_e4m3out(const void* Q, const void* K, const void* VT, void* O8, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                          int32_t ldo, int64_t o_batch_stride, float scale, float out_inv_scale, x2i_stream_t stream);
+
 /* RMSNorm(q,k) + RoPE + head split + V transpose, from fused QKV rows to attention layout.
  * Stands behind FluxAttnProcessor2_0's view/transpose, norm_q/norm_k/norm_added_q/norm_added_k (RMSNorm, eps
  * 1e-6), torch.cat([txt, img], dim=2) and apply_rotary_emb.

@@ -113,3 +113,98 @@ def test_ln_modulate_fp8_matches_bf16_kernel_and_torch():
     assert rel_l2(Y8.float().cpu() * rs.cpu().view(B, S, 1), y) < 3e-2  # e4m3: 3 mantissa bits
     assert float(Y8.float().abs().max()) == 448.0
     ops.ln_modulate_fp8(Xd, None, Y8, rs, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)  # bf16 output optional
+
+
+def test_attention_e4m3_output_equals_quantised_bf16_output():
+    import math
+    from x2i_amd import ops
+    B, H, S = 2, 4, 600
+    Spad = ops.pad128(S)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Q = torch.randn((B, H, Spad, 128), device=DEV, generator=g).bfloat16()
+    K = torch.randn((B, H, Spad, 128), device=DEV, generator=g).bfloat16()
+    VT = (torch.randn((B, H, 128, Spad), device=DEV, generator=g) * 3).bfloat16()
+    ld = H * 128 + 256  # strided destination, like the CAT buffer of the single blocks
+    O = torch.zeros((B, S, ld), device=DEV, dtype=torch.bfloat16)
+    O8 = torch.zeros((B, S, ld), device=DEV, dtype=FP8)
+    ops.attention(Q, K, VT, O, B, H, S, Spad, ld, S * ld, 1 / math.sqrt(128))
+    ops.attention_e4m3out(Q, K, VT, O8, B, H, S, Spad, ld, S * ld, 1 / math.sqrt(128))
+    a, b8 = O[..., :H * 128].float(), O8[..., :H * 128].float()
+    assert float(O8[..., H * 128:].float().abs().max()) == 0.0  # nothing written outside the head columns
+    assert rel_l2(b8, a) < 3e-2  # one e4m3 rounding apart
+    # e4m3(fp32 result) vs e4m3(bf16(result)): identical except where the bf16 rounding crosses an e4m3 boundary
+    assert (b8 != a.to(FP8).float()).float().mean() < 0.03
+
+
+def _tiny(fp8):
+    from oracle import flux as OF
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32)
+    sd = OF.random_flux_state_dict(cfg, seed=11, std=0.05)
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
+    if fp8:
+        m.enable_fp8("mlp")
+    return m, sd, cfg
+
+
+def test_fp8_model_vs_bf16_model_and_fp32_oracle_and_graph_replay():
+    """Stated tolerance of the fp8 configuration: transformer output rel-L2 <= 6e-2 vs the fp32 oracle (bf16: <= 2e-2), 4-step latents
+    <= 8e-2; per-sample results stay batch independent and hipGraph replay is bit-identical to eager."""
+    from oracle import flux as OF
+    from oracle import sampler as OS
+    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+    m8, sd, cfg = _tiny(True)
+    m16, _, _ = _tiny(False)
+    g = torch.Generator().manual_seed(0)
+    B, St, h2, w2 = 3, 24, 6, 8
+    hid = torch.randn((B, h2 * w2, 64), generator=g).bfloat16()
+    enc, pooled = torch.randn((B, St, 64), generator=g).bfloat16(), torch.randn((B, 32), generator=g).bfloat16()
+    ts = torch.tensor([0.5, 0.25, 1.0])
+    ids, tids = OS.prepare_latent_image_ids(h2, w2), torch.zeros(St, 3)
+    kw = dict(hidden_states=hid.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV), timestep=ts.to(DEV),
+              img_ids=ids.to(DEV), txt_ids=tids.to(DEV), return_dict=False)
+    o8, o16 = m8(**kw)[0], m16(**kw)[0]
+    ref = OF.flux_forward({k: v.bfloat16().float() for k, v in sd.items()}, cfg, hid.float(), enc.float(), pooled.float(), ts, ids, tids)
+    e8, e16 = rel_l2(o8, ref), rel_l2(o16, ref)
+    print(f"tiny 2+2 blocks: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
+    assert e16 < 2e-2 and e8 < 6e-2 and not torch.equal(o8, o16)
+    kw1 = dict(kw, hidden_states=kw["hidden_states"][1:2], encoder_hidden_states=kw["encoder_hidden_states"][1:2],
+               pooled_projections=kw["pooled_projections"][1:2], timestep=kw["timestep"][1:2])
+    assert torch.equal(m8(**kw1)[0][0], o8[1])  # batch independence holds in fp8 too (per-row scales, no cross-sample statistic)
+    pipe = FluxPipeline(m8, FlowMatchEulerDiscreteScheduler())
+    pk = dict(prompt_embeds=enc.to(DEV), pooled_prompt_embeds=pooled.to(DEV), num_inference_steps=4, height=96, width=128,
+              output_type="latent", latents=hid.to(DEV))
+    a = pipe(**pk).images
+    b = pipe(**pk, use_graph=True).images
+    assert torch.equal(a, b)
+    lat16 = FluxPipeline(m16, FlowMatchEulerDiscreteScheduler())(**pk).images
+    assert rel_l2(a, lat16) < 8e-2
+    m8.enable_fp8(None)
+    assert torch.equal(m8(**kw)[0], o16)  # switching back restores the bf16 path bit for bit
+
+
+def test_fp8_full_width_blocks_vs_oracle():
+    """D = 3072, one double + one single block on 512 + 1024 tokens: the real GEMM shapes of the fp8 configuration."""
+    from oracle import flux as OF
+    from oracle import sampler as OS
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=1, num_single_layers=1)
+    sd = OF.random_flux_state_dict(cfg, seed=21, std=0.02)
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
+    hidden, enc, pooled = seeded((2, 1024, 64), 1), seeded((2, 512, 4096), 2), seeded((2, 768), 3)
+    ts = torch.tensor([0.5, 0.75])
+    img_ids, txt_ids = OS.prepare_latent_image_ids(32, 32), torch.zeros(512, 3)
+    kw = dict(hidden_states=hidden.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV), timestep=ts.to(DEV),
+              img_ids=img_ids.to(DEV), txt_ids=txt_ids.to(DEV), return_dict=False)
+    o16 = m(**kw)[0].clone()
+    m.enable_fp8("mlp")
+    o8 = m(**kw)[0]
+    ref = OF.flux_forward({k: v.bfloat16().float() for k, v in sd.items()}, cfg, hidden.bfloat16().float(), enc.bfloat16().float(),
+                          pooled.bfloat16().float(), ts, img_ids, txt_ids)
+    e8, e16 = rel_l2(o8, ref), rel_l2(o16, ref)
+    print(f"full-width 1+1 blocks: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
+    assert e16 < 2e-2 and e8 < 6e-2

@@ -65,6 +65,7 @@ SIGNATURES = {
     "x2i_conv_stem_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_groupnorm_nhwc_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
+    "x2i_attention_e4m3out": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _f32, _vp],
     "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
     "x2i_ln_modulate_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     "x2i_ln_affine_bf16": [_vp, _vp, _i64, _i32, _vp, _vp, _f32, _vp],

@@ -42,10 +42,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 
 // ABL (measurement only, wrong results; tools/microbench.py): 1 = no softmax VALU, 2 = no barrier/wait after the first
 // tile, 4 = no DMA after the first tile.  ABL = 0 is the product kernel.
-template <int NW, int THR, int ABL = 0>
+// OUT8: the output is e4m3 (sat(o * oinv)), 8 bytes per lane and d-group -- the A operand of an fp8 projection (x2i_attention_e4m3out)
+template <int NW, int THR, int ABL = 0, bool OUT8 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S,
-                                                           int Spad, int ldo, long long o_bs, float scale_log2, int nbatch) {
+                                                           int Spad, int ldo, long long o_bs, float scale_log2, int nbatch,
+                                                           float oinv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K 16K | VT 16K]
   constexpr int NT = NW * 64;
   constexpr int CH = 1024 / NT;  // 16-byte chunks per thread per tile (1024 chunks per 16 KiB tile)
@@ -257,6 +259,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   l_run = xhalf_sum(l_run);
   const float inv = 1.f / l_run;
   const int q = q0 + li;
+  if constexpr (OUT8) {
+    uint8_t* orow8 = (uint8_t*)O + (long long)b * o_bs + (long long)q * ldo + h * 128;
+    const float sc = inv * oinv;
+    auto pk4 = [&](float a, float bq, float c, float d) {
+      int v = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f), __builtin_amdgcn_fmed3f(bq * sc, -448.f, 448.f), 0, false);
+      return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c * sc, -448.f, 448.f), __builtin_amdgcn_fmed3f(d * sc, -448.f, 448.f), v, true);
+    };
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const uint32_t a4 = pk4(oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]);
+        const uint32_t b4 = pk4(oacc[db][4 * g + 4], oacc[db][4 * g + 5], oacc[db][4 * g + 6], oacc[db][4 * g + 7]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a4, b4, false, false);
+        if (q < S) *(uint2*)(orow8 + db * 32 + 8 * (g + hi)) = make_uint2(s0[0], s0[1]);
+      }
+    return;
+  }
   bf16_t* orow = O + (long long)b * o_bs + (long long)q * ldo + h * 128;
   if ((((uintptr_t)O) & 15) == 0 && (ldo & 7) == 0 && (o_bs & 7) == 0) {
     // half-wave exchange (v_permlane32_swap) turns two 8-byte fragments of neighbouring d-groups into one 16-byte
@@ -289,10 +309,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 }  // namespace
 
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
-                         long long o_bs, float scale, hipStream_t stream) {
+                         long long o_bs, float scale, hipStream_t stream, int out8, float oinv) {
   if (!Q || !K || !VT || !O) return x2i_set_error(X2I_ERR_ARG, "attention: null pointer");
   if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention: need Spad %% 128 == 0 and Spad >= S (S=%d Spad=%d)", S, Spad);
-  if (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)) return x2i_set_error(X2I_ERR_ALIGN, "attention: output rows must be 8-byte aligned");
+  if (out8 ? (ldo % 8 || o_bs % 8 || (((uintptr_t)O) & 7)) : (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)))
+    return x2i_set_error(X2I_ERR_ALIGN, "attention: output rows must be 8-byte aligned");
   const size_t shm = 2 * (KTILE + VTILE);
   const float scale_log2 = scale * 1.4426950408889634f;
   const X2IOptions& opt = x2i_options();
@@ -303,7 +324,15 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     if (rc_) return rc_;                                                                                                    \
     dim3 grid(((S + 32 * NW_ - 1) / (32 * NW_)) * H * B);                                                                   \
     hipLaunchKernelGGL((attn_fwd_kernel<NW_, THR_>), grid, dim3(NW_ * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B);                                \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, 1.f);                           \
+  }
+  if (out8) {
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_fwd_kernel<4, 8, 0, true>, (int)shm);
+    if (rc_) return rc_;
+    dim3 grid(((S + 127) / 128) * H * B);
+    hipLaunchKernelGGL((attn_fwd_kernel<4, 8, 0, true>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
+    return x2i_check_launch("attention");
   }
 #ifdef X2I_ABLATION
   const int abl = opt.attn_ablate;  // measurement-only variants (tools/microbench.py), wrong results by design
@@ -313,7 +342,7 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     if (rc_) return rc_;                                                                                                     \
     dim3 grid(((S + 127) / 128) * H * B);                                                                                    \
     hipLaunchKernelGGL((attn_fwd_kernel<4, 8, A_>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B);                                 \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, 1.f);                            \
   }
   if (abl == 1) X2I_ATTN_LAUNCH_ABL(1)
   else if (abl == 2) X2I_ATTN_LAUNCH_ABL(2)

@@ -163,6 +163,11 @@ int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, in
   return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream);
 }
 
+int x2i_attention_e4m3out(const void* Q, const void* K, const void* VT, void* O8, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                          int32_t ldo, int64_t o_batch_stride, float scale, float out_inv_scale, x2i_stream_t stream) {
+  return x2i_launch_attention(Q, K, VT, O8, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream, 1, out_inv_scale);
+}
+
 int x2i_qkv_split_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t ld1, int32_t B, int32_t S, int32_t S0, int32_t H,
                        const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cos, const float* sin,
                        void* Q, void* K, void* VT, int32_t Spad, float eps, x2i_stream_t stream) {

@@ -182,6 +182,36 @@ class FluxTransformer2DModel(nn.Module):
         self._H = H
         # X2I_QKV_FUSE=0 (read once, here) keeps the two-step form GEMM -> x2i_qkv_split for A/B measurements; bit-identical results
         self.fuse_qkv = os.environ.get("X2I_QKV_FUSE", "1") != "0"
+        self._fp8 = None  # see enable_fp8()
+
+    # ------------------------------------------------------------------ fp8 (e4m3) configuration, opt-in
+    @torch.no_grad()
+    def enable_fp8(self, mode="mlp"):
+        """Switch the large image-/joint-stream MLP linears to the e4m3 MFMA path (BASELINE north_star "MFMA bf16/fp8"; bf16 stays
+        the default).  mode "mlp": double blocks' ff.net.0 / ff.net.2 on the image rows and the single blocks' proj_mlp / proj_out
+        (72 % of the GEMM FLOPs); QKV / attention-output projections, every text-stream linear and all small linears stay bf16.
+        Weights are quantised ONCE here (per-output-channel scales, x2i_quantize_rows_fp8) from the bf16 parameters currently
+        loaded -- call again after load_state_dict().  Activations: the preceding LayerNorm+modulate emits e4m3 rows with
+        per-row scales; GELU outputs and the single blocks' attention output are written as e4m3 with a static scale of 1
+        (saturating at 448).  mode None / "off" returns to bf16."""
+        if mode in (None, "off", False):
+            self._fp8 = None
+            self._ws = {}
+            return self
+        if mode != "mlp":
+            raise ValueError("enable_fp8: mode must be 'mlp' or None")
+        if self.inner_dim % 128:
+            raise ValueError("enable_fp8: inner_dim must be a multiple of 128 (K-tile of the e4m3 MFMA kernel)")
+        D, f, q = self.inner_dim, self._fused, {}
+        for i in range(self.config.num_layers):
+            for nm in (f"d{i}.ff.0", f"d{i}.ff.2"):
+                q[nm] = ops.quantize_rows_fp8(f[nm + ".w"])
+        for i in range(self.config.num_single_layers):
+            q[f"s{i}.mlp"] = ops.quantize_rows_fp8(f[f"s{i}.in.w"][3 * D:])
+            q[f"s{i}.proj_out"] = ops.quantize_rows_fp8(f[f"s{i}.proj_out.w"])
+        self._fp8 = q
+        self._ws = {}
+        return self
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property
@@ -202,6 +232,8 @@ class FluxTransformer2DModel(nn.Module):
         for p, name, sl in self._views:
             p.data = self._fused[name][sl]
         self._ws = {}
+        if getattr(self, "_fp8", None) is not None:
+            self.enable_fp8("mlp")  # re-quantise on the new device
         return self
 
     @torch.no_grad()
@@ -241,6 +273,10 @@ class FluxTransformer2DModel(nn.Module):
             TEMB=torch.empty((B, D), device=dev, dtype=torch.float32),
             H1=torch.empty((B, D), device=dev, dtype=torch.float32),
         )
+        if self._fp8 is not None:
+            f8 = dict(device=dev, dtype=ops.FP8)
+            ws.update(NRM8=torch.empty((B, S, D), **f8), RS=torch.empty((B * S,), device=dev, dtype=torch.float32),
+                      H8=torch.empty((B * Si, 4 * D), **f8), CAT8=torch.empty((B * S, 5 * D), **f8))
         self._ws = {key: ws}  # keep one shape resident
         return ws
 
@@ -321,6 +357,7 @@ class FluxTransformer2DModel(nn.Module):
             return MOD[:, off:]
 
         fuse_qkv = self.fuse_qkv and D % 64 == 0
+        fp8 = self._fp8
         qkv_txt = QKV  # rows [0, B*St)
         qkv_img_off = B * St * 3 * D
         # ---- double-stream blocks (lightcontrol_flux.py:159-204)
@@ -352,13 +389,28 @@ class FluxTransformer2DModel(nn.Module):
                      c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
                      gate_batch_stride=Ntot)
             # feed-forward of both streams
-            ops.ln_modulate(X, NRM, B, S, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oi + 3 * D), mod(oi + 4 * D), Ntot)
             ffh_img_off = B * St * 4 * D
-            ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=CAT, M=Si, batch=B, a_batch_stride=S * D, lda=D,
-                     a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ffh_img_off, act=ACT_GELU_TANH)
-            ops.gemm(CAT, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D,
-                     a_offset=ffh_img_off, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D,
-                     ldr=D, res_offset=St * D, gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
+            if fp8 is None:
+                ops.ln_modulate(X, NRM, B, S, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oi + 3 * D), mod(oi + 4 * D), Ntot)
+                ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=CAT, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                         a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ffh_img_off, act=ACT_GELU_TANH)
+                ops.gemm(CAT, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D,
+                         a_offset=ffh_img_off, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D,
+                         ldr=D, res_offset=St * D, gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
+            else:
+                # text rows: bf16 norm for the bf16 ff_context; image rows: the norm emits the e4m3 operand + per-row scales
+                if St > 0:
+                    ops.ln_modulate(X, NRM, B, St, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oc + 3 * D), mod(oc + 4 * D), Ntot,
+                                    x_bs=S * D, y_bs=S * D)
+                ops.ln_modulate_fp8(X, None, ws["NRM8"], ws["RS"], B, Si, D, 0, None, None, mod(oi + 3 * D), mod(oi + 4 * D), Ntot,
+                                    x_bs=S * D, x_offset=St * D, y8_bs=S * D, y8_offset=St * D)
+                (w0, s0), (w2, s2) = fp8[p + ".ff.0"], fp8[p + ".ff.2"]
+                ops.gemm_fp8(ws["NRM8"], w0, f[p + ".ff.0.b"], out=ws["H8"], M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                             a_scale=ws["RS"], a_scale_batch_stride=Si, w_scale=s0, c_batch_stride=Si * 4 * D, ldc=4 * D,
+                             act=ACT_GELU_TANH, out_fp8=True)
+                ops.gemm_fp8(ws["H8"], w2, f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, w_scale=s2,
+                             c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D, res_offset=St * D,
+                             gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
             ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=CAT, M=St, batch=B, a_batch_stride=S * D,
                      lda=D, c_batch_stride=St * 4 * D, ldc=4 * D, act=ACT_GELU_TANH)
             ops.gemm(CAT, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=X, M=St, batch=B,
@@ -373,21 +425,36 @@ class FluxTransformer2DModel(nn.Module):
         for i in range(cfg.num_single_layers):
             p = f"s{i}"
             o = base + i * 3 * D
-            ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
+            if fp8 is None:
+                ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
+            else:
+                ops.ln_modulate_fp8(X, NRM, ws["NRM8"], ws["RS"], B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
             w, bias = f[p + ".in.w"], f[p + ".in.b"]
             if fuse_qkv:
                 ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
                              Spad=Spad, tok_off=0, rows_per_sample=S)
             else:
                 ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)
-            ops.gemm(NRM, w[3 * D:], bias[3 * D:], out=CAT, M=B * S, N=4 * D, ldc=5 * D, c_offset=D, act=ACT_GELU_TANH)
+            if fp8 is None:
+                ops.gemm(NRM, w[3 * D:], bias[3 * D:], out=CAT, M=B * S, N=4 * D, ldc=5 * D, c_offset=D, act=ACT_GELU_TANH)
+            else:
+                wm, sm = fp8[p + ".mlp"]
+                ops.gemm_fp8(ws["NRM8"], wm, bias[3 * D:], out=ws["CAT8"], M=B * S, a_scale=ws["RS"], w_scale=sm, ldc=5 * D, c_offset=D,
+                             act=ACT_GELU_TANH, out_fp8=True)
             if not fuse_qkv:
                 ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
                               Q, K, VT, Spad)
-            ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
-            ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D,
-                     lda=5 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(o + 2 * D),
-                     gate_batch_stride=Ntot)
+            if fp8 is None:
+                ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+                ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D,
+                         lda=5 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(o + 2 * D),
+                         gate_batch_stride=Ntot)
+            else:
+                ops.attention_e4m3out(Q, K, VT, ws["CAT8"], B, H, S, Spad, 5 * D, S * 5 * D, scale)
+                wo, so = fp8[p + ".proj_out"]
+                ops.gemm_fp8(ws["CAT8"], wo, f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D, lda=5 * D, w_scale=so,
+                             c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(o + 2 * D),
+                             gate_batch_stride=Ntot)
         # ---- norm_out (AdaLayerNormContinuous: scale first, then shift) + proj_out on the image tokens (:540-543)
         o = base + cfg.num_single_layers * 3 * D
         NRMF = ws["NRMF"]

@@ -400,3 +400,11 @@ def ln_modulate_fp8(X, Y, Y8, row_scale, B, S, D, S0, shift0, scale0, shift1, sc
                                   C.c_void_p(Y8.data_ptr() + y8_offset), y8_bs, ldy8, _p(row_scale), B, S, D, S0, _p(shift0), _p(scale0),
                                   _p(shift1), _p(scale1), mod_bs, eps, _stream()), "ln_modulate_fp8")
     return Y8
+
+
+def attention_e4m3out(Q, K, VT, out8, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0, out_inv_scale=1.0):
+    """attention() writing e4m3 (include/x2i.h: x2i_attention_e4m3out); ldo / o_batch_stride / o_offset in bytes."""
+    lib = _lib.load()
+    check(lib.x2i_attention_e4m3out(_p(Q), _p(K), _p(VT), C.c_void_p(out8.data_ptr() + o_offset), B, H, S, Spad, ldo, o_batch_stride,
+                                    scale, out_inv_scale, _stream()), "attention_e4m3out")
+    return out8
