@@ -103,3 +103,41 @@ def random_proj_state_dict(kind, seed=0, use_scale=None, dtype=torch.float32, de
     sd["mlp.fc.1.weight"] = torch.randn(768, 4096, generator=g) / 64.0
     sd["mlp.fc.1.bias"] = 0.02 * torch.randn(768, generator=g)
     return {k: v.to(device=device, dtype=dtype) for k, v in sd.items()}
+
+
+def _t5stack(cfg, sd, device="cpu"):
+    """transformers' T5Stack with the reference's configuration (model_internvl/proj.py:152-153) -- third-party code on both sides."""
+    from transformers import T5Config
+    from transformers.models.t5.modeling_t5 import T5Stack
+    config = T5Config(num_heads=cfg["num_heads"], num_layers=cfg["num_layers"], num_decoder_layers=0, layer_norm_epsilon=cfg["layer_norm_eps"],
+                      is_encoder_decoder=False, is_decoder=False, d_ff=cfg["input_dim"] * 4, d_kv=cfg["head_dim"], d_model=cfg["input_dim"],
+                      dense_act_fn="gelu_new", feed_forward_proj="gated-gelu", use_cache=False)
+    m = T5Stack(config).eval()
+    m.load_state_dict({k[len("t5stack."):]: v for k, v in sd.items() if k.startswith("t5stack.")}, strict=True)
+    return m
+
+
+def legacy_proj(sd, x, cfg, t5_first=False):
+    """Proj / Proj2 (t5_first=False, model_internvl/proj.py:162-167,182-187) and Proj3 (t5_first=True, :203-211):
+    front stage (LN -> conv5x5 -> LN) and MLP / MLP2 head restated here, T5Stack from `transformers` (as in the reference)."""
+    t5 = _t5stack(cfg, sd)
+    mlp = {k[4:]: v for k, v in sd.items() if k.startswith("mlp.")}
+    with torch.no_grad():
+        if t5_first:
+            B, C, S, H = x.shape
+            x = t5(inputs_embeds=x.contiguous().view(B * C, S, H)).last_hidden_state
+            x = legacy_proj_pre(sd, x.view(B, C, S, H), cfg["layer_norm_eps"])
+        else:
+            x = t5(inputs_embeds=legacy_proj_pre(sd, x, cfg["layer_norm_eps"])).last_hidden_state
+        return legacy_mlp(mlp, x, eps=cfg["layer_norm_eps"])
+
+
+def transformer_proj(sd, x, d_model, n_heads, num_layers):
+    """Transformer_proj (model_internvl/proj.py:133-147); nn.TransformerEncoder from torch on both sides."""
+    layer = torch.nn.TransformerEncoderLayer(d_model=d_model, nhead=n_heads, dim_feedforward=2048, batch_first=True)
+    enc = torch.nn.TransformerEncoder(layer, num_layers=num_layers).eval()
+    enc.load_state_dict({k[len("transformer_encoder."):]: v for k, v in sd.items() if k.startswith("transformer_encoder.")}, strict=True)
+    with torch.no_grad():
+        x = enc(x)
+        x1 = torch.mean(F.linear(x, sd["linear1.weight"], sd["linear1.bias"]), 1)
+        return x1, F.linear(x, sd["linear2.weight"], sd["linear2.bias"])

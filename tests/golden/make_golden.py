@@ -131,6 +131,35 @@ def gen_legacy():
         t.update(x=x, x1=x1, x2=x2)
         eps = 1e-5
         save(f"legacy_{cls_name}", t, dict(ref="model_internvl/proj.py", cls=cls_name, eps=eps))
+    # full legacy Proj / Proj2 / Proj3 / Transformer_proj forwards (T5Stack / TransformerEncoder as installed: transformers 5.15)
+    pkw = dict(in_channels=3, kernel_size=5, input_dim=64, output_dim0=32, output_dim1=128, num_layers=2, num_heads=2,
+               layer_norm_eps=1e-6, head_dim=32)
+    for i, cls_name in enumerate(("Proj", "Proj2", "Proj3")):
+        torch.manual_seed(20 + i)
+        m = getattr(lp, cls_name)(**pkw).eval()
+        with torch.no_grad():
+            for n, prm in m.named_parameters():  # liven up the default inits (LayerNorm = identity), then round to bf16 so that
+                if prm.dim() == 1:               # the fixture stores exactly the weights the reference forward used, at half the size
+                    prm.add_(0.1 * torch.randn(prm.shape))
+                prm.copy_(prm.bfloat16().float())
+            x = seeded((2, 3, 6, 64), 310 + i, 2.0)
+            x1, x2 = m(x)
+        # the token-embedding table (32128 x 64) is never read with inputs_embeds=: kept out of the fixture
+        t = {"sd." + k: v.bfloat16() for k, v in m.state_dict().items() if k != "t5stack.embed_tokens.weight"}
+        t.update(x=x, x1=x1, x2=x2)
+        save(f"legacy_{cls_name}_full", t, dict(ref="model_internvl/proj.py:149-211", cls=cls_name, cfg=pkw,
+                                                t5stack="transformers " + transformers.__version__))
+    torch.manual_seed(30)
+    m = lp.Transformer_proj(64, 2, 32, 48, num_layers=2).eval()
+    x = seeded((2, 6, 64), 320, 1.0)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(prm.bfloat16().float())
+        x1, x2 = m(x)
+    t = {"sd." + k: v.bfloat16() for k, v in m.state_dict().items()}
+    t.update(x=x, x1=x1, x2=x2)
+    save("legacy_Transformer_proj", t, dict(ref="model_internvl/proj.py:133-147", d_model=64, n_heads=2, out_dim1=32, out_dim2=48,
+                                             num_layers=2))
     # Proj front stage (norm0 -> conv -> norm1), captured with a forward hook on the reference module
     try:
         m = lp.Proj(in_channels=3, kernel_size=5, input_dim=64, output_dim0=32, output_dim1=128, num_layers=1,

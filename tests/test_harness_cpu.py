@@ -38,3 +38,9 @@ def test_projector_table_and_prefix_strip():
     for kind, (make, C, kw) in H.PROJECTORS.items():
         p = make(in_channels=C, device="meta", **kw)
         assert p.mlp.layernorm.weight.shape[0] == H.HIDDEN[kind]
+
+
+def test_real_prompt_batching_groups_by_text_length():
+    """generate_jobs packs prompts per text length (FLUX's joint attention has no mask, so padding is not an option)."""
+    conds = [(torch.zeros(1, 768), torch.zeros(1, s, 4096)) for s in (512, 77, 512, 300, 77)]
+    assert H.Harness.group_by_length(conds) == [[0, 2], [1, 4], [3]]

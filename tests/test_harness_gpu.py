@@ -28,3 +28,36 @@ def test_qwenvl_harness_synthetic_with_vae_decode(tmp_path):
     assert len(files) == 2
     from PIL import Image
     assert Image.open(files[0]).size == (256, 256)
+
+
+def test_real_prompt_batches_match_one_prompt_at_a_time(tmp_path):
+    """Row H batching: five prompts of two different text lengths through generate_jobs (packed per length into batched sampling
+    calls) give exactly the latents of five B = 1 calls with the same global noise -- i.e. what the reference's one-prompt loop
+    computes -- because a sample's result is bit-independent of its batch."""
+    from x2i_amd.infer import harness as H
+    from x2i_amd.infer.inference_qwenvl import tasks  # noqa: F401  (import check)
+    args = H.build_parser("minicpm").parse_args(["--synthetic", "--height", "256", "--width", "256", "--outputs", str(tmp_path),
+                                                 "--batch", "4", "--seed", "3", "--num_steps", "2"])
+    lens = {"a": 96, "b": 40, "c": 96, "d": 40, "e": 96}
+
+    class Cond:  # stands in for the MLLM: deterministic hidden states per prompt, unpadded (MiniCPM-style) lengths
+        def __call__(self, text_prompt=None, **kw):
+            g = torch.Generator(device="cuda").manual_seed(sum(map(ord, text_prompt)))
+            return (torch.randn((1, 29, lens[text_prompt], 3584), device="cuda", generator=g) * 3).bfloat16()
+
+    h = H.Harness(args, "minicpm", Cond(), "cuda")
+    args.synthetic = False  # weights stay synthetic; the run path is the real-prompt one
+    jobs = [dict(filename=k, text_prompt=k) for k in lens]
+    h.run_tasks({"text2image": jobs})
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "text2image", "*_latents.pt")))
+    assert [os.path.basename(f) for f in files] == ["%s_0_latents.pt" % k for k in lens]
+    # first chunk = 4 prompts (lengths 96, 40, 96, 40 -> two sampling calls of B = 2), second chunk = 1 prompt
+    C = h.pipeline.transformer.config.in_channels // 4
+    for chunk in (list(lens)[:4], list(lens)[4:]):
+        noise, _ = h.pipeline.prepare_latents(len(chunk), C, 256, 256, torch.bfloat16, h.device, torch.Generator("cuda").manual_seed(3))
+        for i, k in enumerate(chunk):
+            pooled, embeds = h.embeds(text_prompt=k)
+            one = h.pipeline(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=2, guidance_scale=3.5, height=256,
+                             width=256, output_type="latent", latents=noise[i:i + 1]).images
+            got = torch.load(os.path.join(str(tmp_path), "text2image", "%s_0_latents.pt" % k))
+            assert torch.equal(got, one.cpu()), k

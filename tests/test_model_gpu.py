@@ -192,3 +192,28 @@ def test_two_prepared_states_do_not_share_conditioning():
     outB = m.denoise(sB, hid, t).clone()
     assert torch.equal(outA, alone) and not torch.equal(outB, outA)
     assert torch.equal(m.denoise(sA, hid, t), alone)
+
+
+@pytest.mark.parametrize("cls", ["Proj", "Proj2", "Proj3"])
+def test_legacy_proj_t5_classes_vs_reference_golden(cls):
+    """Row A3: legacy Proj / Proj2 / Proj3 -- HIP front stage and MLP head around the `transformers` T5Stack (bf16 on the GPU) -- against
+    the reference's own fp32 forward (tests/golden/legacy_*_full, weights bf16-rounded before the reference ran)."""
+    import x2i_amd.proj as XP
+    t, meta = golden("legacy_%s_full" % cls)
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("sd.")}
+    m = getattr(XP, cls)(device=DEV, **meta["cfg"])
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert list(missing) == ["t5stack.embed_tokens.weight"] and not unexpected  # the unused token table is not in the fixture
+    x1, x2 = m(t["x"].to(DEV))
+    assert x1.shape == t["x1"].shape and x2.shape == t["x2"].shape
+    assert rel_l2(x2, t["x2"]) < 3e-2 and rel_l2(x1, t["x1"]) < 3e-2
+
+
+def test_legacy_transformer_proj_vs_reference_golden():
+    import x2i_amd.proj as XP
+    t, meta = golden("legacy_Transformer_proj")
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("sd.")}
+    m = XP.Transformer_proj(meta["d_model"], meta["n_heads"], meta["out_dim1"], meta["out_dim2"], num_layers=meta["num_layers"], device=DEV)
+    m.load_state_dict(sd, strict=True)
+    x1, x2 = m(t["x"].to(DEV))
+    assert rel_l2(x2, t["x2"]) < 3e-2 and rel_l2(x1, t["x1"]) < 3e-2

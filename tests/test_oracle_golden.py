@@ -97,3 +97,35 @@ def test_controlnext_full():
     o = OF.controlnext_forward(sd, "", t["hint"], t["timestep"])
     assert o["scale"] == meta["scale"]
     assert rel_l2(o["out"], t["out"]) < TOL
+
+
+@pytest.mark.parametrize("cls", ["Proj", "Proj2", "Proj3"])
+def test_legacy_proj_full_forward_matches_reference(cls):
+    """model_internvl/proj.py:149-211 run by the reference itself (T5Stack as installed: transformers 5.15) vs the oracle wiring."""
+    t, meta = golden("legacy_%s_full" % cls)
+    sd = {k[3:]: v.float() for k, v in t.items() if k.startswith("sd.")}
+    cfg = meta["cfg"]
+    sd["t5stack.embed_tokens.weight"] = torch.zeros(32128, cfg["input_dim"])  # unused with inputs_embeds=; not stored in the fixture
+    x1, x2 = OP.legacy_proj(sd, t["x"], cfg, t5_first=(cls == "Proj3"))
+    assert rel_l2(x2, t["x2"]) < TOL and rel_l2(x1, t["x1"]) < TOL
+
+
+def test_legacy_transformer_proj_matches_reference():
+    t, meta = golden("legacy_Transformer_proj")
+    sd = {k[3:]: v.float() for k, v in t.items() if k.startswith("sd.")}
+    x1, x2 = OP.transformer_proj(sd, t["x"], meta["d_model"], meta["n_heads"], meta["num_layers"])
+    assert rel_l2(x2, t["x2"]) < TOL and rel_l2(x1, t["x1"]) < TOL
+
+
+@pytest.mark.parametrize("cls", ["Proj", "Proj2", "Proj3"])
+def test_legacy_proj_classes_mirror_the_reference_parameter_tree(cls):
+    """x2i_amd.proj.Proj / Proj2 / Proj3: same constructor arguments and state-dict keys as the reference classes (CPU, no kernels)."""
+    import x2i_amd.proj as XP
+    t, meta = golden("legacy_%s_full" % cls)
+    want = {k[3:]: tuple(v.shape) for k, v in t.items() if k.startswith("sd.")}
+    want["t5stack.embed_tokens.weight"] = (32128, meta["cfg"]["input_dim"])
+    m = getattr(XP, cls)(device="cpu", **meta["cfg"])
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    m2 = XP.Transformer_proj(64, 2, 32, 48, num_layers=2, device="cpu")
+    t2, _ = golden("legacy_Transformer_proj")
+    assert {k: tuple(v.shape) for k, v in m2.state_dict().items()} == {k[3:]: tuple(v.shape) for k, v in t2.items() if k.startswith("sd.")}

@@ -34,9 +34,13 @@ class HiddenStateSlab:
         self.slab = None
         self._handles = []
         self._seen = 0
+        self._extra = 0
 
     # ---- hooks
     def _store(self, idx, h):
+        if self._seen >= self.C:  # a later decoder pass (a decode step of generate()): the conditioning is the PROMPT pass only
+            self._extra += 1
+            return
         if self.slab is None or self.slab.shape[0] != h.shape[0] or self.slab.shape[2] != h.shape[1] or self.slab.device != h.device:
             self.slab = torch.empty((h.shape[0], self.C, h.shape[1], h.shape[2]), device=h.device, dtype=self.dtype)
         self.slab[:, idx].copy_(h)
@@ -66,11 +70,20 @@ class HiddenStateSlab:
     # ---- one prefill forward -> [B, C, S, H]
     @torch.no_grad()
     def prefill(self, model, **inputs):
-        self._seen = 0
+        return self.capture(lambda: model(**inputs, use_cache=False))
+
+    @torch.no_grad()
+    def capture(self, run):
+        """Drive the MLLM with any callable -- a plain forward, or the model's own multimodal `generate(max_new_tokens=1)` /
+        `chat()` wrapper that builds inputs_embeds from pixels / audio first (MiniCPM-o, InternVL) -- and keep the hidden states
+        of the FIRST decoder pass, i.e. the prompt pass the reference stacks (infer/inference_minicpm.py:116-118,174-177;
+        infer/inference_internvl.py:159-188).  Later passes (decode steps) are ignored, so this works with the stock HF
+        remote code and does not need the reference's patched `generate()` that returns hidden states."""
+        self._seen = self._extra = 0
         with self:
-            model(**inputs, use_cache=False)
+            run()
         if self._seen != self.C:
-            raise RuntimeError("handoff: captured %d hidden states, expected %d (decoder ran more than one pass?)" % (self._seen, self.C))
+            raise RuntimeError("handoff: captured %d hidden states, expected %d (did the decoder stack run?)" % (self._seen, self.C))
         return self.slab
 
 

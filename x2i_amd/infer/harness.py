@@ -60,7 +60,9 @@ def build_parser(family):
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--outputs", type=str, default=None)
     p.add_argument("--assets", type=str, default="./data", help="directory holding image/ video/ audio/ demo assets")
-    p.add_argument("--batch", type=int, default=1, help="prompts per pipeline call (the reference always uses 1)")
+    p.add_argument("--batch", type=int, default=1,
+                   help="prompts per pipeline call and rank (the reference always uses 1); under torchrun a task's prompts are packed "
+                        "batch x world_size at a time and sharded over the ranks")
     p.add_argument("--synthetic", action="store_true", help="no checkpoints: random weights, synthetic MLLM hidden states")
     p.add_argument("--no_graph", action="store_true")
     p.add_argument("--full_generate", action="store_true",
@@ -186,18 +188,89 @@ class Harness:
             Image.fromarray(img[i]).save(os.path.join(out_dir, "%s%s.jpg" % (filename, "" if B == 1 else "_b%d" % i)))
         return latents
 
+    # ---- batched real prompts (new in this build; the reference calls the pipeline with B = 1)
+    @torch.no_grad()
+    def condition_jobs(self, jobs):
+        """MLLM + projector for a list of jobs -> [(pooled [1,768], prompt_embeds [1,S,4096])], one entry per job.  Conditioners
+        take one prompt at a time (their processors build one multimodal message); S may differ per job (MiniCPM inputs are
+        unpadded, infer/inference_minicpm.py:160-177), which is why batching happens AFTER this step."""
+        out = []
+        for job in jobs:
+            pooled, embeds = self.embeds(**job)
+            for b in range(embeds.shape[0]):
+                out.append((pooled[b:b + 1], embeds[b:b + 1]))
+        return out
+
+    @staticmethod
+    def group_by_length(conds):
+        """Indices of `conds` grouped by text length S, in first-seen order: samples of equal S ride in one pipeline call.
+        (Zero-padding a shorter prompt is NOT equivalent: FLUX's joint attention has no mask, padded text rows would be attended.)"""
+        groups = {}
+        for i, (_, e) in enumerate(conds):
+            groups.setdefault(e.shape[1], []).append(i)
+        return list(groups.values())
+
+    @torch.no_grad()
+    def generate_jobs(self, jobs, subdir, filenames, seed=None):
+        """Up to --batch prompts in one sampling call per text length; under torchrun rank r conditions and samples ONLY its
+        shard of the prompts (x2i_amd.dist.shard_range) and one all-gather returns every rank the full set of latents."""
+        a = self.args
+        n = len(jobs)
+        lo, hi = xdist.shard_range(n, self.rank, self.world)
+        C = self.pipeline.transformer.config.in_channels // 4
+        gen = torch.Generator(self.device).manual_seed(seed) if seed is not None else None
+        # the GLOBAL noise is drawn identically on every rank and sliced, so results do not depend on the number of ranks
+        noise, _ = self.pipeline.prepare_latents(n, C, a.height, a.width, torch.bfloat16, self.device, gen)
+        conds = self.condition_jobs(jobs[lo:hi])
+        local = torch.empty((hi - lo,) + tuple(noise.shape[1:]), device=self.device, dtype=noise.dtype)
+        for idx in self.group_by_length(conds):
+            pooled = torch.cat([conds[i][0] for i in idx], 0)
+            embeds = torch.cat([conds[i][1] for i in idx], 0)
+            lat = self.pipeline(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=a.num_steps, guidance_scale=3.5,
+                                height=a.height, width=a.width, output_type="latent",
+                                latents=noise[[lo + i for i in idx]], use_graph=not a.no_graph).images
+            local[idx] = lat
+        latents = xdist.all_gather_batch(local, n) if self.world > 1 else local
+        if self.rank == 0:
+            self.save_outputs(latents, subdir, filenames, a.height, a.width)
+        return latents
+
+    def save_outputs(self, latents, subdir, filenames, height, width):
+        out_dir = os.path.join(self.outputs, subdir)
+        os.makedirs(out_dir, exist_ok=True)
+        if self.vae is None:
+            for i, fn in enumerate(filenames):
+                torch.save(latents[i:i + 1].cpu(), os.path.join(out_dir, fn + "_latents.pt"))
+            return
+        vsf = 2 ** len(self.vae.config.block_out_channels)
+        x = FluxPipeline._unpack_latents(latents, height, width, vsf)
+        x = (x / self.vae.config.scaling_factor) + self.vae.config.shift_factor
+        from ..pipeline import VaeImageProcessor
+        images = VaeImageProcessor(vae_scale_factor=vsf).postprocess(self.vae.decode(x, return_dict=False)[0], output_type="pil")
+        for im, fn in zip(images, filenames):
+            im.save(os.path.join(out_dir, fn + ".jpg"))
+
     def run_tasks(self, tasks):
-        """tasks: {name: [dict(filename=..., **conditioner_inputs)]}; runs the ones selected by --task."""
+        """tasks: {name: [dict(filename=..., **conditioner_inputs)]}; runs the ones selected by --task.  --synthetic keeps the
+        one-job-per-call form with a synthetic batch of --batch samples; with a real MLLM the jobs of a task are packed --batch at a
+        time into one sampling call (generate_jobs)."""
         a = self.args
         for name, jobs in tasks.items():
             if a.task not in ("all", name):
                 continue
             for i in range(a.num_gen_imgs):
-                for job in jobs:
-                    job = dict(job)
-                    fn = job.pop("filename")
-                    pooled, embeds = self.embeds(batch=a.batch, **job) if a.synthetic else self.embeds(**job)
-                    self.generate(pooled, embeds, name, "%s_%d" % (fn, i), seed=a.seed)
+                if a.synthetic:
+                    for job in jobs:
+                        job = dict(job)
+                        fn = job.pop("filename")
+                        pooled, embeds = self.embeds(batch=a.batch, **job)
+                        self.generate(pooled, embeds, name, "%s_%d" % (fn, i), seed=a.seed)
+                    continue
+                bs = max(1, a.batch) * self.world
+                for j0 in range(0, len(jobs), bs):
+                    chunk = [dict(j) for j in jobs[j0:j0 + bs]]
+                    fns = ["%s_%d" % (j.pop("filename"), i) for j in chunk]
+                    self.generate_jobs(chunk, name, fns, seed=a.seed)
 
 
 def asset(args, *parts):

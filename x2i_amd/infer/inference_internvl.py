@@ -9,11 +9,29 @@ from .harness import Harness, SyntheticConditioner, asset, build_parser
 
 
 class InternVLConditioner:
-    def __init__(self, path, device):
-        from transformers import AutoModel, AutoTokenizer
-        self.model = AutoModel.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.bfloat16).eval().to(device)
-        self.tokenizer = AutoTokenizer.from_pretrained(path, trust_remote_code=True, use_fast=False)
+    """prefill_only (default): hooks on the language model's decoder stack fill the [1, C, 512, H] tensor during the first
+    decoder pass of the chat model's generate() (x2i_amd/handoff.py, row N2).  That works with the STOCK InternVL2.5 remote code
+    (whose generate() returns token ids); full_generate expects the reference's locally modified modeling_internvl_chat.py, whose
+    generate() is one forward returning every layer's hidden states (model_internvl/internvl/modeling_internvl_chat.py:314-363)."""
+
+    def __init__(self, path, device, prefill_only=True, model=None, tokenizer=None):
+        if model is None:
+            from transformers import AutoModel, AutoTokenizer
+            model = AutoModel.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.bfloat16).eval().to(device)
+            tokenizer = AutoTokenizer.from_pretrained(path, trust_remote_code=True, use_fast=False)
+        self.model, self.tokenizer = model, tokenizer
         self.device = device
+        self.slab = None
+        if prefill_only:
+            from ..handoff import HiddenStateSlab, find_decoder
+            self.slab = HiddenStateSlab(find_decoder(self.model))
+
+    def hidden_states(self, pixel_values, input_ids, attention_mask):
+        if self.slab is not None:
+            return self.slab.capture(lambda: self.model.generate(pixel_values=pixel_values, input_ids=input_ids,
+                                                                 attention_mask=attention_mask, max_new_tokens=1))
+        hs = self.model.generate(pixel_values=pixel_values, input_ids=input_ids, attention_mask=attention_mask)
+        return torch.stack(tuple(hs), dim=1)
 
     @torch.no_grad()
     def __call__(self, videos=None, images=None, audios=None, text_prompt=None):
@@ -30,8 +48,7 @@ class InternVLConditioner:
             pixel_values = torch.stack(tiles).to(self.device, torch.bfloat16)
         q = ("<image>\n" * len(images or [])) + (text_prompt or "")
         tok = self.tokenizer(q, padding="max_length", max_length=512, truncation=True, return_tensors="pt").to(self.device)
-        hs = self.model.generate(pixel_values=pixel_values, input_ids=tok.input_ids, attention_mask=tok.attention_mask)
-        return torch.stack(tuple(hs), dim=1)
+        return self.hidden_states(pixel_values, tok.input_ids, tok.attention_mask)
 
 
 def tasks(args):
@@ -50,7 +67,8 @@ def main(argv=None):
     kind = "internvl" + args.internvl_size
     device = "cuda:%d" % int(__import__("os").environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)
-    cond = SyntheticConditioner(kind, device) if args.synthetic else InternVLConditioner(args.internvl_path, device)
+    cond = SyntheticConditioner(kind, device) if args.synthetic else InternVLConditioner(args.internvl_path, device,
+                                                                                         prefill_only=not args.full_generate)
     Harness(args, kind, cond, device).run_tasks(tasks(args))
 
 

@@ -21,12 +21,29 @@ def encode_video(path):
 
 
 class MiniCPMConditioner:
-    def __init__(self, path, device):
-        from transformers import AutoModel, AutoProcessor, AutoTokenizer
-        self.model = AutoModel.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.bfloat16).eval().to(device)
-        self.tokenizer = AutoTokenizer.from_pretrained(path, trust_remote_code=True)
-        self.processor = AutoProcessor.from_pretrained(path, trust_remote_code=True)
+    """prefill_only (default): the [1, C, S, H] conditioning tensor is written by hooks on the LLM decoder during the ONE prompt
+    pass of generate(max_new_tokens=1) (x2i_amd/handoff.py, row N2) -- no hidden-state tuple, no torch.stack copy, and no
+    dependence on the reference's patched generate() returning `.hidden_states`.  full_generate: the reference's form."""
+
+    def __init__(self, path, device, prefill_only=True, model=None, tokenizer=None, processor=None):
+        if model is None:
+            from transformers import AutoModel, AutoProcessor, AutoTokenizer
+            model = AutoModel.from_pretrained(path, trust_remote_code=True, torch_dtype=torch.bfloat16).eval().to(device)
+            tokenizer = AutoTokenizer.from_pretrained(path, trust_remote_code=True)
+            processor = AutoProcessor.from_pretrained(path, trust_remote_code=True)
+        self.model, self.tokenizer, self.processor = model, tokenizer, processor
         self.device = device
+        self.slab = None
+        if prefill_only:
+            from ..handoff import HiddenStateSlab, find_decoder
+            self.slab = HiddenStateSlab(find_decoder(self.model))
+
+    def hidden_states(self, inputs):
+        """processor outputs -> [B, C, S, H]"""
+        run = lambda: self.model.generate(**inputs, tokenizer=self.tokenizer, max_new_tokens=1, decode_text=False)  # noqa: E731
+        if self.slab is not None:
+            return self.slab.capture(run)
+        return stack_hidden_states(run().hidden_states)
 
     @torch.no_grad()
     def __call__(self, videos=None, images=None, audios=None, text_prompt=None):
@@ -52,8 +69,7 @@ class MiniCPMConditioner:
                                 chunk_input=True, return_tensors="pt", max_length=32768, sampling_rate=16000,
                                 add_special_tokens=True).to(self.device)
         inputs.pop("image_sizes")
-        hs = self.model.generate(**inputs, tokenizer=self.tokenizer, max_new_tokens=1, decode_text=False).hidden_states
-        return stack_hidden_states(hs)
+        return self.hidden_states(inputs)
 
 
 def tasks(args):
@@ -71,7 +87,8 @@ def main(argv=None):
     args = build_parser("minicpm").parse_args(argv)
     device = "cuda:%d" % int(__import__("os").environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(device)
-    cond = SyntheticConditioner("minicpm", device) if args.synthetic else MiniCPMConditioner(args.minicpm_path, device)
+    cond = SyntheticConditioner("minicpm", device) if args.synthetic else MiniCPMConditioner(args.minicpm_path, device,
+                                                                                              prefill_only=not args.full_generate)
     Harness(args, "minicpm", cond, device).run_tasks(tasks(args))
 
 

@@ -213,8 +213,8 @@ class MLP_plus(_LegacyMLP):
 
 
 class ProjFrontStage(nn.Module):
-    """The kernelised part of legacy Proj / Proj2 (model_internvl/proj.py:163-166): norm0 -> Conv2d(C->1,5x5) -> norm1.
-    The T5Stack that follows in the reference stays on `transformers` and is not part of this class."""
+    """The kernelised front stage of legacy Proj / Proj2 / Proj3 (model_internvl/proj.py:163-165): norm0 -> Conv2d(C->1,5x5) -> norm1,
+    on its own (the full classes, with the T5Stack on `transformers`, are Proj / Proj2 / Proj3 below)."""
 
     def __init__(self, in_channels=2, input_dim=896, layer_norm_eps=1e-6, device="cuda", dtype=torch.bfloat16):
         super().__init__()
@@ -232,3 +232,87 @@ class ProjFrontStage(nn.Module):
         x = ops.ln_affine(x.to(torch.bfloat16).contiguous(), self.norm0.weight, self.norm0.bias, self.eps)
         x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())
         return ops.ln_affine(x, self.norm1.weight, self.norm1.bias, self.eps)
+
+
+class _ProjT5(nn.Module):
+    """Legacy Proj / Proj2 / Proj3 (model_internvl/proj.py:149-211): LayerNorm -> Conv2d(C->1, 5x5) -> LayerNorm front stage and an
+    MLP / MLP2 head on the HIP path around a `transformers` T5Stack encoder (gated-gelu, relative attention bias), which stays on
+    PyTorch-ROCm as SURVEY.md section 8 row A3 allows.  Same constructor arguments and state-dict keys (norm0.*, conv.*, norm1.*,
+    t5stack.*, mlp.*) as the reference classes; no reference script imports them (checkpoint compatibility only)."""
+
+    mlp_cls = None      # MLP for Proj, MLP2 for Proj2 / Proj3
+    t5_first = False    # Proj3 runs the T5Stack on every layer's sequence BEFORE the layer-fusion stage (:203-210)
+
+    def __init__(self, in_channels=2, kernel_size=5, input_dim=896, output_dim0=768, output_dim1=4096, num_layers=4, num_heads=12,
+                 layer_norm_eps=1e-6, head_dim=64, device="cuda", dtype=torch.bfloat16):
+        super().__init__()
+        from transformers import T5Config
+        from transformers.models.t5.modeling_t5 import T5Stack
+        if kernel_size != 5:
+            raise ValueError("the HIP layer-fusion kernel implements the reference's 5x5 convolution")
+        config = T5Config(num_heads=num_heads, num_layers=num_layers, num_decoder_layers=0, layer_norm_epsilon=layer_norm_eps,
+                          is_encoder_decoder=False, is_decoder=False, d_ff=input_dim * 4, d_kv=head_dim, d_model=input_dim,
+                          dense_act_fn="gelu_new", feed_forward_proj="gated-gelu", use_cache=False)
+        self.eps = layer_norm_eps
+        self.norm0 = _LN(input_dim, device, dtype)
+        conv = nn.Module()
+        conv.weight = _param(1, in_channels, kernel_size, kernel_size, device=device, dtype=dtype)
+        conv.bias = _param(1, device=device, dtype=dtype)
+        self.conv = conv
+        self.norm1 = _LN(input_dim, device, dtype)
+        self.t5stack = T5Stack(config).to(device=device, dtype=dtype).eval().requires_grad_(False)
+        self.mlp = self.mlp_cls(input_dim, output_dim1, output_dim1, output_dim0, layer_norm_eps, device=device, dtype=dtype)
+
+    def _front(self, x):
+        B, C, S, H = x.shape
+        x = ops.ln_affine(x.to(torch.bfloat16).contiguous(), self.norm0.weight, self.norm0.bias, self.eps)          # :163 / :207
+        x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())       # :164 / :208
+        return ops.ln_affine(x, self.norm1.weight, self.norm1.bias, self.eps)                                       # :165 / :209
+
+    @torch.no_grad()
+    def forward(self, x):
+        B, C, S, H = x.shape
+        if self.t5_first:
+            x = self.t5stack(inputs_embeds=x.to(torch.bfloat16).contiguous().view(B * C, S, H)).last_hidden_state   # :206
+            x = self._front(x.view(B, C, S, H))
+        else:
+            x = self.t5stack(inputs_embeds=self._front(x)).last_hidden_state                                        # :166
+        return self.mlp(x.contiguous())
+
+
+class Proj(_ProjT5):
+    """model_internvl/proj.py:149-167"""
+    mlp_cls = MLP
+
+
+class Proj2(_ProjT5):
+    """model_internvl/proj.py:169-187"""
+    mlp_cls = MLP2
+
+
+class Proj3(_ProjT5):
+    """model_internvl/proj.py:190-211"""
+    mlp_cls = MLP2
+    t5_first = True
+
+
+class Transformer_proj(nn.Module):
+    """model_internvl/proj.py:133-147: nn.TransformerEncoder (stays on PyTorch-ROCm, like the T5Stack above) followed by two
+    biased linears on the HIP path; x1 = mean_S(linear1(x)), x2 = linear2(x).  Keys: transformer_encoder.*, linear1.*, linear2.*"""
+
+    def __init__(self, d_model, n_heads, out_dim1, out_dim2, num_layers=3, device="cuda", dtype=torch.bfloat16):
+        super().__init__()
+        layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=n_heads, dim_feedforward=2048, batch_first=True)
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=num_layers).to(device=device, dtype=dtype).eval()
+        self.transformer_encoder.requires_grad_(False)
+        self.linear1 = _Lin(d_model, out_dim1, True, device, dtype)
+        self.linear2 = _Lin(d_model, out_dim2, True, device, dtype)
+
+    @torch.no_grad()
+    def forward(self, x):
+        B, S, H = x.shape
+        x = self.transformer_encoder(x.to(torch.bfloat16)).contiguous()
+        x1_tok = ops.gemm(x, self.linear1.weight, self.linear1.bias, M=B * S, out_f32=True)
+        x1 = ops.seq_mean(x1_tok.view(B, S, -1))
+        x2 = ops.gemm(x, self.linear2.weight, self.linear2.bias, M=B * S)
+        return x1.to(torch.bfloat16), x2.view(B, S, -1)
