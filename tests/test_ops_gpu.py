@@ -184,6 +184,35 @@ def test_attention_forced_rescale_branch(ops):
     assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [4, 5, 6])
+@pytest.mark.parametrize("B,H,S,S0", [(1, 1, 64, 0), (2, 2, 136, 40), (1, 2, 1152, 128), (1, 3, 700, 100), (2, 1, 2000, 0)])
+def test_attention_kernel_forms(ops, opt, variant, B, H, S, S0):
+    """attn_variant 4 = the 4-wave kernel, 5 / 6 = the 8-wave ping-pong kernel (attention_pp.hip) with / without defer-max, on
+    ragged sequence lengths (S % 64 != 0, S % 256 != 0, fewer rows than one 256-row workgroup) and with the forced-rescale spike."""
+    opt("attn_variant", variant)
+    assert _attention_case(ops, B, H, S, S0, 200 + S) < 1e-2
+    assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
+
+
+def test_attention_ping_pong_equals_four_wave_kernel_closely(ops, opt):
+    """Same arithmetic per query row (tile order, defer-max rule, exp2 domain); only the wave -> row mapping differs, so the two
+    kernels agree to the last bits of bf16 on the model's shape (B = 1, 24 heads, S = 4608)."""
+    import math
+    B, H, S = 1, 24, 4608
+    Spad = ops.pad128(S)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    Q = torch.randn((B, H, Spad, 128), device=DEV, generator=gen).bfloat16()
+    K = torch.randn((B, H, Spad, 128), device=DEV, generator=gen).bfloat16()
+    VT = torch.randn((B, H, 128, Spad), device=DEV, generator=gen).bfloat16()
+    outs = []
+    for v in (4, 5):
+        opt("attn_variant", v)
+        O = torch.empty((B, S, H * 128), device=DEV, dtype=torch.bfloat16)
+        ops.attention(Q, K, VT, O, B, H, S, Spad, H * 128, S * H * 128, 1 / math.sqrt(128))
+        outs.append(O)
+    assert torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------------------------------------ norms / small linears
 def test_ln_modulate_two_streams(ops):
     B, S, S0, D = 2, 50, 18, 3072

@@ -1,0 +1,320 @@
+// Flash attention forward, 8-wave "ping-pong" organisation (round 2): same math, fragment layouts and LDS images as
+// attn_fwd_kernel (attention.hip) -- swapped QK^T with v_mfma_f32_32x32x16_bf16, key-order permutation that makes P^T the PV
+// B operand, V pre-transposed, XOR-swizzled K / V^T tiles filled by LDS-DMA, exp2-domain online softmax with defer-max -- but
+// the two waves that share a SIMD are made COMPLEMENTARY on purpose (MI355X_MICROARCH.md "Two waves per SIMD"):
+//
+//   * one workgroup = 8 waves = 256 query rows; waves w and w + 4 land on the same SIMD.  Group A = waves 0-3, group B = waves 4-7;
+//   * a wave's work per key tile is split into a MATRIX phase -- PV(t-1) then QK^T(t): 32 back-to-back MFMAs fed by LDS reads --
+//     and a VECTOR phase -- the online softmax of tile t: ~150 VALU instructions, no LDS, no MFMA;
+//   * the workgroup advances in global phases separated by s_barrier; group B runs one phase behind group A, so in every phase one
+//     wave of each SIMD is in its matrix phase and its partner in its vector phase: the matrix pipe of a SIMD is offered MFMAs all
+//     the time, the softmax rides under the partner's MFMAs, and only four waves read LDS at any moment;
+//   * K(t) is read in global phases 2t (A) and 2t+1 (B), V(t) in 2t+2 / 2t+3: two K and two V^T buffers (64 KiB); every wave issues
+//     its share of K(t+1) and V(t) at the start of phase 2t and waits for it (vmcnt(0)) before the barrier that ends phase 2t+1;
+//   * twice the query rows per workgroup also halves the K / V^T bytes streamed per FLOP.
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int KVB = 64;                  // keys per tile
+constexpr int KTILE = KVB * 128 * 2;     // 16 KiB  K  tile: [64 keys][128 d]
+constexpr int VTILE = 128 * KVB * 2;     // 16 KiB  V^T tile: [128 d][64 keys]
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int NTH = 512;
+
+// LDS-DMA through a buffer descriptor (MUBUF buffer_load ... lds), NOT global_load_lds: the global_ form is flat-family and makes
+// hipcc's wait-count pass give up counted lgkmcnt waits for the ds_reads that follow (every wait becomes lgkmcnt(0))
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
+}
+
+// Matrix phase of one wave: (start the LDS-DMA of this wave's share of K(t+1) and V(t)), O^T += V^T(t-1) P^T(t-1), S^T(t) = K(t) Q^T.
+// The four LDS regions are __restrict__ parameters of ONE function on purpose: after inlining that is what tells hipcc that the
+// fragment reads cannot touch the buffers the DMA is filling (without it every ds_read behind an LDS-DMA issue gets a conservative
+// s_waitcnt vmcnt(0)).
+struct LaneGeo {
+  int k_row_off, k_swz, v_row_off, v_swz, hi;
+};
+template <bool HAS_PV, bool HAS_QK>
+__device__ __forceinline__ void matrix_phase(const char* __restrict__ kb, const char* __restrict__ vb, char* __restrict__ kdst,
+                                             char* __restrict__ vdst, __amdgpu_buffer_rsrc_t k_rsrc, __amdgpu_buffer_rsrc_t v_rsrc,
+                                             uint32_t kg, uint32_t vg, bool issue_k, bool issue_v, const int (&k_src)[2],
+                                             const int (&v_src)[2], int wave,
+                                             const LaneGeo& L, const bf16x8_t (&qf)[8], const bf16x8_t (&pf)[2][2], f32x16_t (&sacc)[2],
+                                             f32x16_t (&oacc)[4]) {
+  if (issue_k) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(k_rsrc, kg + (uint32_t)k_src[j] * 2, kdst + (j * NTH + wave * 64) * 16);
+  }
+  if (issue_v) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(v_rsrc, vg + (uint32_t)v_src[j] * 2, vdst + (j * NTH + wave * 64) * 16);
+  }
+  // One fragment pipeline over the whole phase: steps 0-3 = the four (u, kt) groups of O^T += V^T P^T (fragment j = d-block), steps
+  // 4-7 = the four groups of S^T = K Q^T (fragment j: ds = 2g + (j >> 1), sub-tile u = j & 1).  Fragments are read LEAD = 2 steps
+  // (8 MFMAs = 256 matrix-pipe cycles) ahead of their use into a 3-deep register ring: while this wave is in its matrix phase its
+  // SIMD partner is in its vector phase and cannot fill an LDS-latency bubble with MFMAs of its own, so the latency has to be
+  // covered inside this stream.
+  constexpr int FIRST = HAS_PV ? 0 : 4, LAST = HAS_QK ? 8 : 4, LEAD = 2;
+  bf16x8_t fr[3][4];
+  auto load = [&](int step, int j) {
+    if (step < 4) {
+      const int u = step >> 1, kt = step & 1;
+      return *(const bf16x8_t*)(vb + j * 32 * 128 + L.v_row_off + (((4 * u + 2 * kt + L.hi) ^ L.v_swz) << 4));
+    }
+    const int ds = 2 * (step - 4) + (j >> 1), u = j & 1;
+    return *(const bf16x8_t*)(kb + u * 32 * 256 + L.k_row_off + (((ds * 2 + L.hi) ^ L.k_swz) << 4));
+  };
+  if constexpr (HAS_QK) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+  }
+#pragma unroll
+  for (int st = FIRST; st < FIRST + LEAD && st < LAST; ++st)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fr[st % 3][j] = load(st, j);
+#pragma unroll
+  for (int st = FIRST; st < LAST; ++st) {
+    if (st + LEAD < LAST) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fr[(st + LEAD) % 3][j] = load(st + LEAD, j);
+    }
+    // sched_barrier pins "reads of step st + LEAD, then MFMAs of step st": left to itself (or to sched_group_barrier hints) hipcc
+    // sinks every ds_read to just in front of its MFMA and waits lgkmcnt(0) for it -- the whole LDS latency exposed 32 times a phase
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (st < 4) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], pf[st >> 1][st & 1], oacc[j], 0, 0, 0);
+      else sacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], qf[2 * (st - 4) + (j >> 1)], sacc[j & 1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int THR, bool OUT8>
+__global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                      const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S, int Spad,
+                                                      int ldo, long long o_bs, float scale_log2, int nbatch, float oinv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K[2] 32 KiB | VT[2] 32 KiB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;    // 0 = group A (waves 0-3), 1 = group B (waves 4-7, one phase behind); waves w and w + 4 share a SIMD
+                                // (measured: pairing w / w+1 or w / w+2 instead runs 15-25 % slower)
+  const int hi = lane >> 5;
+  const int li = lane & 31;
+  const int nqt = gridDim.x / (H * nbatch);
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qt = bid % nqt, h = (bid / nqt) % H, b = bid / (nqt * H);
+  const int q0 = qt * 256 + wave * 32;
+  const long long bh = (long long)b * H + h;
+  const bf16_t* Qh = Q + bh * Spad * 128;
+  const bf16_t* Kh = K + bh * Spad * 128;
+  const bf16_t* Vh = VT + bh * 128 * Spad;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+li][ds*16 + hi*8 .. +8]; a 256-row tile may reach past Spad (a
+  // multiple of 128): those rows are clamped to a valid one and never stored
+  const int qrow = min(q0 + li, Spad - 1);
+  bf16x8_t qf[8];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8_t*)(Qh + (long long)qrow * 128 + ds * 16 + hi * 8);
+
+  // DMA source offsets (elements): 1024 chunks per 16 KiB tile, 2 per thread; swizzle on the source
+  int k_src[2], v_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = j * NTH + tid;
+    {
+      const int row = p >> 4, cphys = p & 15;
+      k_src[j] = row * 128 + ((cphys ^ (row & 15)) << 3);
+    }
+    {
+      const int row = p >> 3, cphys = p & 7;
+      v_src[j] = row * Spad + ((cphys ^ ((row >> 1) & 7)) << 3);
+    }
+  }
+  __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (uint32_t)Spad * 256u, 0x00020000);
+  __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (uint32_t)Spad * 256u, 0x00020000);
+  LaneGeo L;
+  {
+    const int kvm = (li & 0x13) | ((li & 4) << 1) | ((li & 8) >> 1);  // key order fed to the MFMA rows: bits 2 and 3 swapped
+    L.k_row_off = kvm * 256; L.k_swz = kvm & 15; L.v_row_off = li * 128; L.v_swz = (li >> 1) & 7; L.hi = hi;
+  }
+
+  f32x16_t oacc[4], sacc[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+  bf16x8_t pf[2][2] = {};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int nt = (S + KVB - 1) / KVB;
+  char* const kbuf = smem;
+  char* const vbuf = smem + 2 * KTILE;
+
+  // ---- vector phase: online softmax of tile t (scores in sacc) -> P(t) in pf, running max / sum, O rescale when a row max grew
+  auto softmax = [&](int t, auto last_c) {
+    const int kv0 = t * KVB;
+    if (decltype(last_c)::value && kv0 + KVB > S) {  // ragged last tile: mask keys >= S (lane (li, hi), sub-tile u, reg r <-> key kv0 + u*32 + 16*(r>>3) + 8*hi + (r&7))
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + u * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= S) sacc[u][r] = NEG_BIG;
+        }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[u][r]);
+    mx = xhalf_max(mx);
+    float m_new = fmaxf(m_run, mx * scale_log2);
+    if (THR > 0 && __all(m_new - m_run <= (float)THR)) m_new = m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - m_new);
+        sacc[u][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    if (!__all(m_new == m_run)) {  // PV(t-1) is complete (this wave's previous matrix phase): O is entirely at the old scale
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    m_run = m_new;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        union { bf16x8_t v; uint32_t w[4]; } cv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv.w[j] = pack_bf16x2(sacc[u][kt * 8 + 2 * j], sacc[u][kt * 8 + 2 * j + 1]);
+        pf[u][kt] = cv.v;
+      }
+  };
+  auto barrier = [&](bool wait_dma) {  // wait_dma is wave-uniform
+    if (wait_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  // matrix phase M(t): start K(t+1) / V(t); PV(t-1); QK^T(t)
+  auto M = [&](int t, auto has_pv, auto has_qk) {
+    matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value>(
+        kbuf + (t & 1) * KTILE, vbuf + ((t + 1) & 1) * VTILE, kbuf + ((t + 1) & 1) * KTILE, vbuf + (t & 1) * VTILE,
+        k_rsrc, v_rsrc, (uint32_t)(t + 1) * (KVB * 128 * 2), (uint32_t)t * (KVB * 2), t + 1 < nt, t < nt, k_src, v_src, wave, L, qf, pf, sacc,
+        oacc);
+  };
+
+  // prologue: K(0) visible to everyone; group B then falls one phase behind group A
+#pragma unroll
+  for (int j = 0; j < 2; ++j) dma16(k_rsrc, (uint32_t)k_src[j] * 2, kbuf + (j * NTH + wave * 64) * 16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) {
+    __builtin_amdgcn_s_setprio(1);  // the younger half loses VALU arbitration otherwise (guide T5, static form)
+    barrier(false);
+  }
+  // Every wave runs M(t) | S(t) | M(t+1) | ...; group A's M(t) is global phase 2t, group B's is 2t+1.  A wave's DMA is issued at the
+  // start of its M(t) and must have landed by the end of global phase 2t+1: A waits at the end of S(t), B at the end of M(t).
+  M(0, std::false_type{}, std::true_type{});
+  barrier(grp == 1);
+  if (nt == 1) softmax(0, std::true_type{});
+  else softmax(0, std::false_type{});
+  barrier(grp == 0);
+  for (int t = 1; t < nt - 1; ++t) {  // steady state: every key valid, every piece present
+    M(t, std::true_type{}, std::true_type{});
+    barrier(grp == 1);
+    softmax(t, std::false_type{});
+    barrier(grp == 0);
+  }
+  if (nt > 1) {
+    M(nt - 1, std::true_type{}, std::true_type{});
+    barrier(grp == 1);
+    softmax(nt - 1, std::true_type{});
+    barrier(grp == 0);
+  }
+  M(nt, std::true_type{}, std::false_type{});  // PV(nt-1); nothing left to stage
+  if (grp == 0) barrier(false);                // pairs with group B's last barrier
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l
+  l_run = xhalf_sum(l_run);
+  const float inv = 1.f / l_run;
+  const int q = q0 + li;
+  if constexpr (OUT8) {
+    uint8_t* orow8 = (uint8_t*)O + (long long)b * o_bs + (long long)q * ldo + h * 128;
+    const float sc = inv * oinv;
+    auto pk4 = [&](float a, float bq, float c, float d) {
+      int v = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f), __builtin_amdgcn_fmed3f(bq * sc, -448.f, 448.f), 0, false);
+      return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c * sc, -448.f, 448.f), __builtin_amdgcn_fmed3f(d * sc, -448.f, 448.f), v, true);
+    };
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const uint32_t a4 = pk4(oacc[db][4 * g], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]);
+        const uint32_t b4 = pk4(oacc[db][4 * g + 4], oacc[db][4 * g + 5], oacc[db][4 * g + 6], oacc[db][4 * g + 7]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a4, b4, false, false);
+        if (q < S) *(uint2*)(orow8 + db * 32 + 8 * (g + hi)) = make_uint2(s0[0], s0[1]);
+      }
+    return;
+  } else {
+    bf16_t* orow = O + (long long)b * o_bs + (long long)q * ldo + h * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const uint32_t a0 = pack_bf16x2(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv);
+        const uint32_t a1 = pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        const uint32_t b0 = pack_bf16x2(oacc[db][4 * g + 4] * inv, oacc[db][4 * g + 5] * inv);
+        const uint32_t b1 = pack_bf16x2(oacc[db][4 * g + 6] * inv, oacc[db][4 * g + 7] * inv);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        if (q < S) *(uint4*)(orow + db * 32 + 8 * (g + hi)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+  }
+}
+
+}  // namespace
+
+// Launcher of the ping-pong form; returns X2I_ERR_STATE when the shape is not served (the caller then uses attn_fwd_kernel).
+int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
+                            long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr) {
+  if (!out8 && ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7))) return X2I_ERR_STATE;  // 16-byte row stores only
+  const size_t shm = 2 * (KTILE + VTILE);
+  dim3 grid(((S + 255) / 256) * H * B);
+#define X2I_PP(THR_, O8_)                                                                                                   \
+  {                                                                                                                         \
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<THR_, O8_>, (int)shm);                              \
+    if (rc_) return rc_;                                                                                                    \
+    hipLaunchKernelGGL((attn_pp_kernel<THR_, O8_>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,       \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);                          \
+  }
+  if (out8) X2I_PP(8, true)
+  else if (thr == 0) X2I_PP(0, false)
+  else X2I_PP(8, false)
+#undef X2I_PP
+  return x2i_check_launch("attention");
+}

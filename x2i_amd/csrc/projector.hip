@@ -42,6 +42,12 @@ constexpr int MAXC = 64;
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
+// (non-template helper on purpose: with the LDS-DMA builtin called directly inside the kernel TEMPLATE, hipcc 7.2 silently dropped the
+// host-side instantiation of the kernel -- an undefined __device_stub__ symbol at load time, no diagnostic)
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rsrc, char* lds_piece, uint32_t voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_piece, 16, voff, 0, 0, 0);
+}
+
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
 }
@@ -57,8 +63,7 @@ __device__ __forceinline__ void conv_substep(const char* __restrict__ img, const
                                              __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&voff)[NJ_], int wave, uint32_t win_off,
                                              float (&acc)[NSTR][5][2]) {
 #pragma unroll
-  for (int j = 0; j < NJ_; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dma_dst + (j * 4 + wave) * 1024), 16, voff[j], 0, 0, 0);
+  for (int j = 0; j < NJ_; ++j) dma_piece(rsrc, dma_dst + (j * 4 + wave) * 1024, voff[j]);
   // taps and windows of layer l + 1 are read (into a second register set) BEFORE the dot products of layer l are issued;
   // sched_barrier pins that order -- left alone hipcc sinks every LDS read to just in front of its first use and the loop
   // runs at LDS latency
@@ -167,8 +172,7 @@ __global__ __launch_bounds__(256) void conv5x5_kernel(const bf16_t* __restrict__
     uint32_t v0[NJ];
     offsets(0, 0, v0);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (j * 4 + wave) * 1024), 16, v0[j], 0, 0, 0);
+    for (int j = 0; j < NJ; ++j) dma_piece(rsrc, smem + (j * 4 + wave) * 1024, v0[j]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // also publishes the packed taps
