@@ -126,33 +126,41 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // all tiles but the last stage their successor unconditionally (one basic block per K-step); the last one only computes
+  // all tiles but the last stage their successor unconditionally (one basic block per K-step); the last one only computes.
+  // Fragment pipeline (pinned with sched_barrier -- hipcc otherwise sinks every ds_read to just in front of its MFMAs and waits
+  // lgkmcnt(0) for it): the k-half-0 fragments of a tile are read right after the barrier that publishes it, under the issue of the
+  // next tile's eight DMA pieces; the k-half-1 fragments are read before the 16 MFMAs of k-half 0 start.
+  bf16x8_t af[2][4], wf[2][4];
+  auto load_frags = [&](const char* tile, int kk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[kk][i] = *(const bf16x8_t*)(tile + a_frag_base + i * 2048 + frag_off[kk]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[kk][j] = *(const bf16x8_t*)(tile + TILE_BYTES + b_frag_base + j * 2048 + frag_off[kk]);
+  };
+  load_frags(smem, 0);
   auto ktile = [&](int kt, auto stage_next) {
     char* cur = smem + (kt & 1) * 2 * TILE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
     if constexpr (decltype(stage_next)::value) {
-      char* nxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
       const uint32_t koff = (uint32_t)(kt + 1) * BK * 2;
       if (CONV) conv_offsets();
       stage_tile(a_rsrc, nxt, a_voff, CONV ? 0u : koff, wave);
       stage_tile(w_rsrc, nxt + TILE_BYTES, w_voff, koff, wave);
     }
-    const char* As = cur + a_frag_base;
-    const char* Bs = cur + TILE_BYTES + b_frag_base;
+    load_frags(cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(As + i * 2048 + frag_off[kk]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(Bs + j * 2048 + frag_off[kk]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed
     __syncthreads();                                  // ... everyone's has, and everyone is done reading `cur`
+    if constexpr (decltype(stage_next)::value) load_frags(nxt, 0);
   };
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
