@@ -1,9 +1,6 @@
 // 256x256x64 bf16 MFMA GEMM kernel, full-line LDS-DMA staging (8 waves, 144 KiB LDS, 1 workgroup per CU): the large DiT
 // linears and the implicit-GEMM convolutions with >= 256 output channels.  Launcher: gemm.hip.
 #include "gemm_device.h"
-#ifndef X2I_GEMM_SCHED
-#define X2I_GEMM_SCHED 0
-#endif
 
 namespace x2i_gemm {
 namespace {
@@ -178,17 +175,15 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[0][i] = *(const bf16x8_t*)(nxt + a_base + i * 2048);
       }
-#if X2I_GEMM_SCHED == 1
+      // pin "this phase's DMA issue and the next phase's fragment reads first, then the 16 MFMAs": hipcc otherwise sinks each
+      // ds_read to just in front of its first MFMA and waits lgkmcnt(0/1) for it (+1.3 % over the DiT shapes, +2.5 % at K = 3072)
       __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][j], af[mh][i], acc[mh * 4 + i][j], 0, 0, 0);
-#if X2I_GEMM_SCHED == 1
       __builtin_amdgcn_sched_barrier(0);
-#endif
     }
   };
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
