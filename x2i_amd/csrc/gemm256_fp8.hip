@@ -181,6 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(GemmP p) {
         load_a(nxt, 0, af[0][0]);
         load_a(nxt, 1, af[0][1]);
       }
+      __builtin_amdgcn_sched_barrier(0);  // DMA issue + next phase's A operands first, then the MFMAs (see gemm256.hip)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(GemmP p) {
                                                                                UNIT_SCALE, 0, UNIT_SCALE);
         if (ph == 3 && MORE) load_w(nxt, j, wf[j]);  // this column's W operand is dead for the current tile: replace it in place
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
