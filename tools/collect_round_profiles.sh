@@ -1,0 +1,34 @@
+#!/bin/bash
+# Everything kept under profiles/ for a round, in one GPU-box call:  tools/collect_round_profiles.sh r02x
+# (kernel-trace --stats runs and PMC passes are separate rocprofv3 invocations; counters never share a run with tracing domains
+# other than --kernel-trace)
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run_stats() {  # name, command...
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$name" -o s -- "$@" > "$OUT/stats_$name.log" 2>&1
+  cp "$OUT/stats_$name"/*/s_kernel_stats.csv "$OUT/${TAG}_${name}_kernel_stats.csv" 2>/dev/null || cp "$OUT/stats_$name"/s_kernel_stats.csv "$OUT/${TAG}_${name}_kernel_stats.csv" 2>/dev/null
+}
+cd "$R"
+python bench.py > "$OUT/${TAG}_bench_b4_1024.json.log" 2>&1
+python bench.py --dtype fp8 --no-cpu-baseline > "$OUT/${TAG}_bench_b4_1024_fp8.json.log" 2>&1
+python bench.py --config 3 --no-cpu-baseline > "$OUT/${TAG}_bench_config3.json.log" 2>&1
+python bench.py --config 5 --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/${TAG}_bench_config5.json.log" 2>&1
+for b in 1 2 8; do python bench.py --batch $b --no-cpu-baseline > "$OUT/${TAG}_bench_batch$b.json.log" 2>&1; done
+python tools/microbench.py > "$OUT/${TAG}_microbench.log" 2>&1
+python tools/fp8_bench.py > "$OUT/${TAG}_fp8_bench.log" 2>&1
+cd /tmp
+run_stats bench_b4_1024 python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline
+run_stats bench_b4_1024_fp8 python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dtype fp8
+run_stats roofline_probe python "$R/tools/roofline_probe.py"
+run_stats roofline_probe_fp8 python "$R/tools/roofline_probe.py" --fp8
+cp "$OUT/stats_roofline_probe.log" "$OUT/${TAG}_roofline_probe.json.log"
+cp "$OUT/stats_roofline_probe_fp8.log" "$OUT/${TAG}_roofline_probe_fp8.json.log"
+bash "$R/tools/pmc_collect.sh" "$OUT/pmc" all > "$OUT/pmc.log" 2>&1
+cp "$OUT/pmc/summary.json" "$OUT/${TAG}_pmc_gemm_attn.json"
+bash "$R/tools/clock_watch.sh" "$OUT/${TAG}_clock_power_during_bench.log" -- python "$R/bench.py" --no-cpu-baseline --steps 6 > /dev/null 2>&1
+ls -la "$OUT" | head -40

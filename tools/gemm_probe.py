@@ -16,6 +16,27 @@ if which in ("all", "gemm"):
         for _ in range(3):
             ops.gemm(A, W, b, out=out, act=act)
         torch.cuda.synchronize()
+if which in ("all", "fp8"):
+    for (M, N, K, gelu) in [(B * S, 4 * D, D, True), (B * S, D, 5 * D, False)]:
+        A8, sa = ops.quantize_rows_fp8(rnd(M, K))
+        W8, sw = ops.quantize_rows_fp8(rnd(N, K, scale=0.02))
+        b = rnd(N)
+        out = torch.empty((M, N), device="cuda", dtype=ops.FP8 if gelu else torch.bfloat16)
+        gate = torch.randn(1, N, device="cuda")
+        for _ in range(3):
+            if gelu:
+                ops.gemm_fp8(A8, W8, b, out=out, a_scale=sa, w_scale=sw, act=1, out_fp8=True)
+            else:
+                ops.gemm_fp8(A8, W8, b, out=out, w_scale=sw, res=out, gate=gate)
+        torch.cuda.synchronize()
+if which in ("all", "proj"):
+    for (C, Hh) in ((37, 2048), (29, 3584)):
+        x = rnd(B, C, 512, Hh, scale=3.0)
+        w, bb = torch.randn(C, 25, device="cuda").bfloat16().float(), torch.randn(1, device="cuda")
+        for _ in range(3):
+            ops.proj_conv5x5(x, w, bb)
+        torch.cuda.synchronize()
+        del x
 if which in ("all", "attn"):
     Spad = ops.pad128(S)
     Q, K_, VT = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)

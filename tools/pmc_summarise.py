@@ -13,8 +13,8 @@ def main(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "*", "p_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-            if not ("gemm" in name or "attn" in name):
+            name = re.sub(r"\(anonymous namespace\)::|x2i_gemm::", "", r["Kernel_Name"])
+            if not ("gemm" in name or "attn" in name or "conv5x5" in name):
                 continue
             key = "%s grid=%s" % (name.split("(")[0].replace("void ", ""), r["Grid_Size"])
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
