@@ -222,6 +222,13 @@ int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, in
 int x2i_rope_table_f32(const float* ids, int32_t S, int32_t d0, int32_t d1, int32_t d2, float theta, float* cos, float* sin,
                        x2i_stream_t stream);
 
+/* X[b][s][:] = bf16(X + gate[b][:] * T[b][s][:]): `hidden_states + gate.unsqueeze(1) * attn_output` (lightcontrol_flux.py:180-181,
+ * 193-194) as a separate pass.  The sampling path never needs it (the gate / residual ride in the projection's epilogue); it exists
+ * for the attention-distillation capture (train/train_qwenvl.py:206-214: forward hooks on every block's `attn`), where the
+ * projected attention outputs have to exist as tensors of their own.  Strides in elements; gate f32 [B][D] with batch stride gate_bs. */
+int x2i_gated_residual_bf16(void* X, int64_t x_bs, int32_t ldx, const void* T, int64_t t_bs, int32_t ldt, const float* gate,
+                            int64_t gate_bs, int32_t B, int32_t S, int32_t D, x2i_stream_t stream);
+
 /* FlowMatchEulerDiscreteScheduler.step: x = bf16(f32(x) + dt[0] * f32(eps)); dt is a DEVICE scalar so the
  * call can be captured in a hipGraph. */
 int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2i_stream_t stream);

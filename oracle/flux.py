@@ -26,13 +26,17 @@ DEFAULT_CFG = dict(
 )
 
 
-def double_block(sd, prefix, hidden, enc, temb, rotary, heads):
-    """FluxTransformerBlock.forward -- lightcontrol_flux.py:159-204."""
+def double_block(sd, prefix, hidden, enc, temb, rotary, heads, taps=None):
+    """FluxTransformerBlock.forward -- lightcontrol_flux.py:159-204.  `taps`: optional [img_list, txt_list, single_list]; the attention
+    module's outputs are appended as a forward hook on `block.attn` would see them (train/train_qwenvl.py:206-214)."""
     n_h, gate_msa, shift_mlp, scale_mlp, gate_mlp = P.ada_layer_norm_zero(sd, prefix + ".norm1", hidden, temb)  # :166
     n_e, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = P.ada_layer_norm_zero(
         sd, prefix + ".norm1_context", enc, temb
     )  # :168-170
     attn_img, attn_txt = P.flux_attention(sd, prefix + ".attn", n_h, heads, rotary, encoder_hidden=n_e)  # :173-177
+    if taps is not None:
+        taps[0].append(attn_img)
+        taps[1].append(attn_txt)
     hidden = hidden + gate_msa.unsqueeze(1) * attn_img  # :180-181
     n_h = P.layer_norm_plain(hidden) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]  # :183-184
     hidden = hidden + gate_mlp.unsqueeze(1) * P.feed_forward(sd, prefix + ".ff", n_h)  # :186-189
@@ -44,12 +48,14 @@ def double_block(sd, prefix, hidden, enc, temb, rotary, heads):
     return enc, hidden  # :204
 
 
-def single_block(sd, prefix, hidden, temb, rotary, heads):
+def single_block(sd, prefix, hidden, temb, rotary, heads, taps=None):
     """FluxSingleTransformerBlock.forward -- lightcontrol_flux.py:82-104."""
     residual = hidden
     n_h, gate = P.ada_layer_norm_zero_single(sd, prefix + ".norm", hidden, temb)  # :89
     mlp = torch.nn.functional.gelu(P.linear(sd, prefix + ".proj_mlp", n_h), approximate="tanh")  # :90
     attn = P.flux_attention(sd, prefix + ".attn", n_h, heads, rotary)  # :92-95
+    if taps is not None:
+        taps[2].append(attn)
     cat = torch.cat([attn, mlp], dim=2)  # :97
     hidden = residual + gate.unsqueeze(1) * P.linear(sd, prefix + ".proj_out", cat)  # :98-100
     if hidden.dtype == torch.float16:
@@ -107,6 +113,7 @@ def flux_forward(
     guidance=None,
     guided_hint=None,
     control_sds=(),
+    taps=None,
 ):
     """FluxTransformer2DModel.forward -- lightcontrol_flux.py:390-553.
 
@@ -128,7 +135,7 @@ def flux_forward(
     ids = torch.cat((txt_ids, img_ids), dim=0)  # :471
     rotary = P.flux_pos_embed(ids, tuple(cfg["axes_dims_rope"]))  # :472
     for i in range(cfg["num_layers"]):  # :474-507
-        enc, hidden = double_block(sd, f"transformer_blocks.{i}", hidden, enc, temb, rotary, heads)
+        enc, hidden = double_block(sd, f"transformer_blocks.{i}", hidden, enc, temb, rotary, heads, taps)
         if i < len(control_sds):
             control = controlnext_forward(control_sds[i], "", guided_hint, timestep)  # :505
             out = control["out"].flatten(2).transpose(1, 2).to(hidden.dtype)  # :506
@@ -136,7 +143,7 @@ def flux_forward(
     n_txt = enc.shape[1]
     hidden = torch.cat([enc, hidden], dim=1)  # :510
     for i in range(cfg["num_single_layers"]):  # :512-538
-        hidden = single_block(sd, f"single_transformer_blocks.{i}", hidden, temb, rotary, heads)
+        hidden = single_block(sd, f"single_transformer_blocks.{i}", hidden, temb, rotary, heads, taps)
     hidden = hidden[:, n_txt:, ...]  # :540
     hidden = P.ada_layer_norm_continuous(sd, "norm_out", hidden, temb)  # :542
     return P.linear(sd, "proj_out", hidden)  # :543

@@ -217,3 +217,46 @@ def test_legacy_transformer_proj_vs_reference_golden():
     m.load_state_dict(sd, strict=True)
     x1, x2 = m(t["x"].to(DEV))
     assert rel_l2(x2, t["x2"]) < 3e-2 and rel_l2(x1, t["x1"]) < 3e-2
+
+
+def test_attention_taps_for_distillation_match_oracle():
+    """Row N4 (forward part): forward hooks on every block.attn -- the reference's cast_hook_list (train/train_qwenvl.py:206-214) -- see
+    the (image, text) attention projections of the double blocks and the joint attention output of the single blocks; values against
+    the oracle's taps, the transformer output unchanged up to one bf16 rounding per block, nothing left behind when hooks are gone."""
+    from x2i_amd import distill
+    from x2i_amd.flux import FluxTransformer2DModel
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32)
+    sd = OF.random_flux_state_dict(cfg, seed=13, std=0.05)
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
+    g = torch.Generator().manual_seed(2)
+    B, St, h2, w2 = 2, 24, 6, 8
+    hid = torch.randn((B, h2 * w2, 64), generator=g).bfloat16()
+    enc, pooled = torch.randn((B, St, 64), generator=g).bfloat16(), torch.randn((B, 32), generator=g).bfloat16()
+    ts = torch.tensor([0.5, 0.25])
+    ids, tids = OS.prepare_latent_image_ids(h2, w2), torch.zeros(St, 3)
+    kw = dict(hidden_states=hid.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV), timestep=ts.to(DEV),
+              img_ids=ids.to(DEV), txt_ids=tids.to(DEV), return_dict=False)
+    plain = m(**kw)[0].clone()
+    lists = []
+    handles = distill.cast_hook_list(m, lists)
+    tapped = m(**kw)[0].clone()
+    for h in handles:
+        h.remove()
+    assert torch.equal(m(**kw)[0], plain)  # hooks removed: the fused sampling path again, bit for bit
+    assert rel_l2(tapped, plain) < 1e-2
+    otaps = [[], [], []]
+    OF.flux_forward({k: v.bfloat16().float() for k, v in sd.items()}, cfg, hid.float(), enc.float(), pooled.float(), ts, ids, tids, taps=otaps)
+    assert [len(x) for x in lists] == [2, 2, 2]
+    for k in range(3):
+        got, want = torch.stack(lists[k], 1), torch.stack(otaps[k], 1)
+        assert got.shape == want.shape and rel_l2(got, want) < 2e-2, k
+    assert lists[0][0].shape == (B, h2 * w2, 256) and lists[1][0].shape == (B, St, 256) and lists[2][0].shape == (B, St + h2 * w2, 256)
+    # the distillation loss of a model against itself is zero; against perturbed conditioning it is positive and finite
+    loss0, _, _ = distill.teacher_student_loss(m, kw, kw)
+    kw2 = dict(kw, encoder_hidden_states=(enc * 1.5).bfloat16().to(DEV))
+    loss1, tl, sl = distill.teacher_student_loss(m, kw, kw2)
+    assert abs(float(loss0)) < 1e-6 and float(loss1) > 1e-4 and torch.isfinite(loss1)
+    ref_loss = distill.kd_attention_loss([torch.stack(x, 1).float().cpu() for x in tl], [torch.stack(x, 1).float().cpu() for x in sl])
+    assert abs(float(loss1) - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)))

@@ -72,6 +72,7 @@ SIGNATURES = {
     "x2i_skinny_linear": [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "x2i_timestep_sinusoid": [_vp, _vp, _i32, _i32, _i32, _vp],
     "x2i_rope_table_f32": [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "x2i_gated_residual_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
     "x2i_euler_step_bf16": [_vp, _vp, _i64, _vp, _vp],
     "x2i_proj_conv5x5_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_proj_layer_mean_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _vp],

@@ -201,6 +201,11 @@ int x2i_rope_table_f32(const float* ids, int32_t S, int32_t d0, int32_t d1, int3
   return x2i_launch_rope_table(ids, S, d0, d1, d2, theta, cos, sin, (hipStream_t)stream);
 }
 
+int x2i_gated_residual_bf16(void* X, int64_t x_bs, int32_t ldx, const void* T, int64_t t_bs, int32_t ldt, const float* gate,
+                            int64_t gate_bs, int32_t B, int32_t S, int32_t D, x2i_stream_t stream) {
+  return x2i_launch_gated_residual(X, x_bs, ldx, T, t_bs, ldt, gate, gate_bs, B, S, D, (hipStream_t)stream);
+}
+
 int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2i_stream_t stream) {
   return x2i_launch_euler_step(x, eps, n, dt, (hipStream_t)stream);
 }

@@ -285,6 +285,26 @@ __global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ 
   }
 }
 
+// x[b][s][:] = bf16(x + gate[b][:] * t[b][s][:])  -- `hidden + gate.unsqueeze(1) * attn_output` (lightcontrol_flux.py:180-181,193-194) as
+// its own pass, used only when the per-block attention outputs have to be materialised for forward hooks (x2i_gated_residual_bf16)
+__global__ __launch_bounds__(256) void gated_residual_kernel(bf16_t* __restrict__ X, long long x_bs, int ldx, const bf16_t* __restrict__ T,
+                                                             long long t_bs, int ldt, const float* __restrict__ gate, long long g_bs, int S,
+                                                             int D8, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D8);
+    const long long row = i / D8;
+    const int b = (int)(row / S), s = (int)(row - (long long)b * S);
+    bf16_t* x = X + (long long)b * x_bs + (long long)s * ldx + c * 8;
+    float a[8], t[8];
+    unpack8(*(const bf16x8_t*)x, a);
+    unpack8(*(const bf16x8_t*)(T + (long long)b * t_bs + (long long)s * ldt + c * 8), t);
+    const float* g = gate + (long long)b * g_bs + c * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = fmaf(g[j], t[j], a[j]);
+    *(bf16x8_t*)x = pack8(a);
+  }
+}
+
 __global__ void euler_tail_kernel(bf16_t* x, const bf16_t* eps, long long start, long long n, const float* dt) {
   const long long i = start + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = f32_to_bf16(bf16_to_f32(x[i]) + dt[0] * bf16_to_f32(eps[i]));
@@ -400,6 +420,18 @@ int x2i_launch_rope_table(const float* ids, int S, int d0, int d1, int d2, float
   const long long n = (long long)S * (d0 + d1 + d2);
   hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, S, d0, d1, d2, (double)theta, cosp, sinp);
   return x2i_check_launch("rope_table");
+}
+
+int x2i_launch_gated_residual(void* X, long long x_bs, int ldx, const void* T, long long t_bs, int ldt, const float* gate, long long g_bs,
+                              int B, int S, int D, hipStream_t stream) {
+  if (!X || !T || !gate || B <= 0 || S <= 0 || D <= 0) return x2i_set_error(X2I_ERR_ARG, "gated_residual: bad argument");
+  if (D % 8 || ldx % 8 || ldt % 8 || x_bs % 8 || t_bs % 8 || g_bs % 4 || !al16(X) || !al16(T) || !al16(gate))
+    return x2i_set_error(X2I_ERR_ALIGN, "gated_residual: rows must be 16-byte aligned, D %% 8 == 0");
+  const long long total = (long long)B * S * (D / 8);
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(gated_residual_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, (bf16_t*)X, x_bs, ldx,
+                     (const bf16_t*)T, t_bs, ldt, gate, g_bs, S, D / 8, total);
+  return x2i_check_launch("gated_residual");
 }
 
 int x2i_launch_euler_step(void* x, const void* eps, long long n, const float* dt, hipStream_t stream) {

@@ -145,7 +145,9 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     const long long per_row = (long long)tn * a->batch;
     const long long full_rounds = tiles256 / 256, rem = tiles256 % 256;
     int tm_main = tm_all;
-    if (force == 0 && !conv && full_rounds >= 1 && rem > 0 && rem <= 160 && opt.gemm_split_tail) {
+    // (re-measured in round 2, tools/tail_probe.py: peeling pays up to a 3/8-full last round at any depth, and for a half-full one
+    // only behind >= 8 full rounds; a fuller last round is faster left in the one launch.  Either way the results are bit-identical.)
+    if (force == 0 && !conv && full_rounds >= 1 && rem > 0 && (rem <= 96 || (rem <= 128 && full_rounds >= 8)) && opt.gemm_split_tail) {
       const long long tm_fit = (full_rounds * 256) / per_row;
       if (tm_fit >= 1 && tm_fit < tm_all) tm_main = (int)tm_fit;
     }

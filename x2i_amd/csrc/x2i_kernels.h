@@ -33,6 +33,8 @@ int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const 
                              int N, int K, int act_in, int act_out, int accumulate, hipStream_t stream);
 int x2i_launch_timestep_sinusoid(const float* t, float* out, int B, int dim, int round_bf16, hipStream_t stream);
 int x2i_launch_rope_table(const float* ids, int S, int d0, int d1, int d2, float theta, float* cosp, float* sinp, hipStream_t stream);
+int x2i_launch_gated_residual(void* X, long long x_bs, int ldx, const void* T, long long t_bs, int ldt, const float* gate, long long g_bs,
+                              int B, int S, int D, hipStream_t stream);
 int x2i_launch_euler_step(void* x, const void* eps, long long n, const float* dt, hipStream_t stream);
 int x2i_launch_proj_conv5x5(const void* x, const float* w, const float* bias, void* y, int B, int C, int S, int H,
                             hipStream_t stream);

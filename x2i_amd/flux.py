@@ -38,6 +38,16 @@ class _P(nn.Module):
             self.register_parameter(k, nn.Parameter(v, requires_grad=False))
 
 
+class _AttnTap(nn.Module):
+    """The `attn` sub-module of a block: holds the reference's parameter names (to_q / to_k / ... are views into fused storage) and
+    is CALLED with the block's attention outputs when forward hooks are registered on it -- the reference's distillation code hooks
+    `block.attn` (train/train_qwenvl.py:206-214: double blocks return (image, text) projections, single blocks the joint sequence).
+    Identity otherwise; the sampling path never calls it (the projections' outputs are never materialised there)."""
+
+    def forward(self, *outs):
+        return outs if len(outs) > 1 else outs[0]
+
+
 class _Seq(nn.Module):
     """ModuleList-like container whose children are named by integers but may be sparse (e.g. net.0 / net.2)."""
 
@@ -137,7 +147,7 @@ class FluxTransformer2DModel(nn.Module):
             blk.add_module("norm1_context", mod_lin(off + 6 * D, 6 * D))
             store(p + ".qkv.w", 3 * D, D), store(p + ".qkv.b", 3 * D)
             store(p + ".cqkv.w", 3 * D, D), store(p + ".cqkv.b", 3 * D)
-            attn = nn.Module()
+            attn = _AttnTap()
             for j, nm in enumerate(("to_q", "to_k", "to_v")):
                 attn.add_module(nm, lin_from(p + ".qkv.w", p + ".qkv.b", j * D, (j + 1) * D))
             for j, nm in enumerate(("add_q_proj", "add_k_proj", "add_v_proj")):
@@ -164,7 +174,7 @@ class FluxTransformer2DModel(nn.Module):
             blk = nn.Module()
             blk.add_module("norm", mod_lin(base + i * 3 * D, 3 * D))
             store(p + ".in.w", 7 * D, D), store(p + ".in.b", 7 * D)
-            attn = nn.Module()
+            attn = _AttnTap()
             for j, nm in enumerate(("to_q", "to_k", "to_v")):
                 attn.add_module(nm, lin_from(p + ".in.w", p + ".in.b", j * D, (j + 1) * D))
             for nm in ("norm_q", "norm_k"):
@@ -358,6 +368,11 @@ class FluxTransformer2DModel(nn.Module):
 
         fuse_qkv = self.fuse_qkv and D % 64 == 0
         fp8 = self._fp8
+        # forward hooks on block.attn (attention-distillation capture): materialise the attention outputs of every block
+        taps = any(len(b.attn._forward_hooks) for b in self.transformer_blocks) or \
+            any(len(b.attn._forward_hooks) for b in self.single_transformer_blocks)
+        if taps and fp8 is not None:
+            raise RuntimeError("attention taps (forward hooks on block.attn) are served by the bf16 configuration only")
         qkv_txt = QKV  # rows [0, B*St)
         qkv_img_off = B * St * 3 * D
         # ---- double-stream blocks (lightcontrol_flux.py:159-204)
@@ -382,12 +397,24 @@ class FluxTransformer2DModel(nn.Module):
                               f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
             ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
             # hidden += gate_msa * to_out(attn_img) ; enc += c_gate_msa * to_add_out(attn_txt)
-            ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
-                     a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
-                     res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
-            ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=X, M=St, batch=B, a_batch_stride=S * D, lda=D,
-                     c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
-                     gate_batch_stride=Ntot)
+            if not taps:
+                ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                         a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
+                         res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
+                ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=X, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                         c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
+                         gate_batch_stride=Ntot)
+            else:
+                # the module's outputs as the reference's Attention returns them (image, text), fresh tensors per block for the hooks
+                t_img = torch.empty((B, Si, D), device=self.device, dtype=torch.bfloat16)
+                t_txt = torch.empty((B, St, D), device=self.device, dtype=torch.bfloat16)
+                ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=t_img, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                         a_offset=St * D, c_batch_stride=Si * D, ldc=D)
+                ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=t_txt, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                         c_batch_stride=St * D, ldc=D)
+                self.transformer_blocks[i].attn(t_img, t_txt)
+                ops.gated_residual_(X, t_img, mod(oi + 2 * D), B, Si, D, S * D, D, Si * D, D, Ntot, x_offset=St * D)
+                ops.gated_residual_(X, t_txt, mod(oc + 2 * D), B, St, D, S * D, D, St * D, D, Ntot)
             # feed-forward of both streams
             ffh_img_off = B * St * 4 * D
             if fp8 is None:
@@ -446,6 +473,8 @@ class FluxTransformer2DModel(nn.Module):
                               Q, K, VT, Spad)
             if fp8 is None:
                 ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+                if taps:  # single blocks' Attention (pre_only) returns the un-projected joint sequence [B, S, D]
+                    self.single_transformer_blocks[i].attn(CAT.view(B, S, 5 * D)[:, :, :D].clone())
                 ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D,
                          lda=5 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(o + 2 * D),
                          gate_batch_stride=Ntot)

@@ -408,3 +408,11 @@ def attention_e4m3out(Q, K, VT, out8, B, H, S, Spad, ldo, o_batch_stride, scale,
     check(lib.x2i_attention_e4m3out(_p(Q), _p(K), _p(VT), C.c_void_p(out8.data_ptr() + o_offset), B, H, S, Spad, ldo, o_batch_stride,
                                     scale, out_inv_scale, _stream()), "attention_e4m3out")
     return out8
+
+
+def gated_residual_(X, T, gate, B, S, D, x_bs, ldx, t_bs, ldt, gate_bs, x_offset=0, t_offset=0):
+    """X <- bf16(X + gate[b] * T) in place (include/x2i.h: x2i_gated_residual_bf16); offsets / strides in elements."""
+    lib = _lib.load()
+    check(lib.x2i_gated_residual_bf16(C.c_void_p(X.data_ptr() + 2 * x_offset), x_bs, ldx, C.c_void_p(T.data_ptr() + 2 * t_offset), t_bs, ldt,
+                                      _p(gate), gate_bs, B, S, D, _stream()), "gated_residual")
+    return X
