@@ -56,7 +56,7 @@ def main():
     Q, K_ = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128)
     VT = rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device=DEV, dtype=torch.bfloat16)
-    for var, nm in (("4", "4-wave thr8"), ("1", "nw8 lockstep thr8"), ("2", "nw4 thr0"), ("5", "ping-pong thr8"), ("6", "ping-pong thr0"), ("4", "4-wave thr8")):
+    for var, nm in (("4", "4-wave thr8"), ("1", "nw8 lockstep thr8"), ("2", "nw4 thr0"), ("5", "ping-pong thr8"), ("7", "ping-pong, DMA in vector phase"), ("5", "ping-pong thr8"), ("7", "ping-pong, DMA in vector phase"), ("4", "4-wave thr8")):
         _lib.set_option("attn_variant", int(var))
         t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention[{nm}] B={B} H={H} S={S}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")

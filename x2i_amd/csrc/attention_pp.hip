@@ -95,7 +95,10 @@ __device__ __forceinline__ void matrix_phase(const char* __restrict__ kb, const 
   }
 }
 
-template <int THR, bool OUT8>
+// SCH = 0: every wave starts its share of K(t+1) / V(t) at the head of its MATRIX phase M(t) (two K and two V^T buffers).
+// SCH = 1: the DMA issue rides in the VECTOR phase instead -- S(t) starts K(t+2) / V(t+1) into three-deep rings (96 KiB) -- so that
+//          the matrix phase, the longer of the two, carries nothing but fragment reads and MFMAs.
+template <int THR, bool OUT8, int SCH>
 __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S, int Spad,
                                                       int ldo, long long o_bs, float scale_log2, int nbatch, float oinv) {
@@ -161,8 +164,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
   bf16x8_t pf[2][2] = {};
   float m_run = NEG_BIG, l_run = 0.f;
   const int nt = (S + KVB - 1) / KVB;
+  constexpr int NB = SCH ? 3 : 2;
   char* const kbuf = smem;
-  char* const vbuf = smem + 2 * KTILE;
+  char* const vbuf = smem + NB * KTILE;
 
   // ---- vector phase: online softmax of tile t (scores in sacc) -> P(t) in pf, running max / sum, O rescale when a row max grew
   auto softmax = [&](int t, auto last_c) {
@@ -219,17 +223,62 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
   };
-  // matrix phase M(t): start K(t+1) / V(t); PV(t-1); QK^T(t)
+  // matrix phase M(t): (SCH 0: start K(t+1) / V(t);) PV(t-1); QK^T(t)
   auto M = [&](int t, auto has_pv, auto has_qk) {
-    matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value>(
-        kbuf + (t & 1) * KTILE, vbuf + ((t + 1) & 1) * VTILE, kbuf + ((t + 1) & 1) * KTILE, vbuf + (t & 1) * VTILE,
-        k_rsrc, v_rsrc, (uint32_t)(t + 1) * (KVB * 128 * 2), (uint32_t)t * (KVB * 2), t + 1 < nt, t < nt, k_src, v_src, wave, L, qf, pf, sacc,
-        oacc);
+    if constexpr (SCH == 0) {
+      matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value>(
+          kbuf + (t & 1) * KTILE, vbuf + ((t + 1) & 1) * VTILE, kbuf + ((t + 1) & 1) * KTILE, vbuf + (t & 1) * VTILE,
+          k_rsrc, v_rsrc, (uint32_t)(t + 1) * (KVB * 128 * 2), (uint32_t)t * (KVB * 2), t + 1 < nt, t < nt, k_src, v_src, wave, L, qf, pf,
+          sacc, oacc);
+    } else {
+      matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value>(
+          kbuf + (t % 3) * KTILE, vbuf + ((t + 2) % 3) * VTILE, nullptr, nullptr, k_rsrc, v_rsrc, 0u, 0u, false, false, k_src, v_src, wave, L,
+          qf, pf, sacc, oacc);
+    }
+  };
+  // SCH 1: the vector phase S(t) starts this wave's share of K(t+2) and V(t+1); returns how many DMA pieces it issued
+  auto stage_ahead = [&](int t) {
+    int n = 0;
+    if constexpr (SCH == 1) {
+      if (t + 2 < nt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          dma16(k_rsrc, (uint32_t)(t + 2) * (KVB * 128 * 2) + (uint32_t)k_src[j] * 2, kbuf + ((t + 2) % 3) * KTILE + (j * NTH + wave * 64) * 16);
+        n += 2;
+      }
+      if (t + 1 < nt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          dma16(v_rsrc, (uint32_t)(t + 1) * (KVB * 2) + (uint32_t)v_src[j] * 2, vbuf + ((t + 1) % 3) * VTILE + (j * NTH + wave * 64) * 16);
+        n += 2;
+      }
+    }
+    return n;
+  };
+  // group A's wait at the end of S(t): everything but the `keep` pieces just issued must have landed (SCH 0: keep = 0)
+  auto barrier_keep = [&](bool wait_dma, int keep) {
+    if (wait_dma) {
+      if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (keep >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
   };
 
   // prologue: K(0) visible to everyone; group B then falls one phase behind group A
 #pragma unroll
   for (int j = 0; j < 2; ++j) dma16(k_rsrc, (uint32_t)k_src[j] * 2, kbuf + (j * NTH + wave * 64) * 16);
+  if constexpr (SCH == 1) {  // K(1) and V(0) as well: the rings run two tiles (K) / one tile (V) ahead of the matrix phases
+    if (nt > 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(k_rsrc, (uint32_t)(KVB * 128 * 2) + (uint32_t)k_src[j] * 2, kbuf + KTILE + (j * NTH + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(v_rsrc, (uint32_t)v_src[j] * 2, vbuf + (j * NTH + wave * 64) * 16);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -239,22 +288,26 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
   }
   // Every wave runs M(t) | S(t) | M(t+1) | ...; group A's M(t) is global phase 2t, group B's is 2t+1.  A wave's DMA is issued at the
   // start of its M(t) and must have landed by the end of global phase 2t+1: A waits at the end of S(t), B at the end of M(t).
+  int keep;
   M(0, std::false_type{}, std::true_type{});
   barrier(grp == 1);
+  keep = stage_ahead(0);
   if (nt == 1) softmax(0, std::true_type{});
   else softmax(0, std::false_type{});
-  barrier(grp == 0);
+  barrier_keep(grp == 0, keep);
   for (int t = 1; t < nt - 1; ++t) {  // steady state: every key valid, every piece present
     M(t, std::true_type{}, std::true_type{});
     barrier(grp == 1);
+    keep = stage_ahead(t);
     softmax(t, std::false_type{});
-    barrier(grp == 0);
+    barrier_keep(grp == 0, keep);
   }
   if (nt > 1) {
     M(nt - 1, std::true_type{}, std::true_type{});
     barrier(grp == 1);
+    keep = stage_ahead(nt - 1);
     softmax(nt - 1, std::true_type{});
-    barrier(grp == 0);
+    barrier_keep(grp == 0, keep);
   }
   M(nt, std::true_type{}, std::false_type{});  // PV(nt-1); nothing left to stage
   if (grp == 0) barrier(false);                // pairs with group B's last barrier
@@ -303,13 +356,21 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                             long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr) {
   if (!out8 && ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7))) return X2I_ERR_STATE;  // 16-byte row stores only
-  const size_t shm = 2 * (KTILE + VTILE);
+  const int sch = x2i_options().attn_variant == 7 ? 1 : 0;
+  const size_t shm = (sch ? 3 : 2) * (KTILE + VTILE);
   dim3 grid(((S + 255) / 256) * H * B);
+  if (sch && !out8) {
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 1>, (int)shm);
+    if (rc_) return rc_;
+    hipLaunchKernelGGL((attn_pp_kernel<8, false, 1>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
+                       (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
+    return x2i_check_launch("attention");
+  }
 #define X2I_PP(THR_, O8_)                                                                                                   \
   {                                                                                                                         \
-    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<THR_, O8_>, (int)shm);                              \
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<THR_, O8_, 0>, (int)shm);                           \
     if (rc_) return rc_;                                                                                                    \
-    hipLaunchKernelGGL((attn_pp_kernel<THR_, O8_>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,       \
+    hipLaunchKernelGGL((attn_pp_kernel<THR_, O8_, 0>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,    \
                        (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);                          \
   }
   if (out8) X2I_PP(8, true)
