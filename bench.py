@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="bf16 (default, the headline arithmetic = the reference's) or fp8: the MLP GEMMs (72 %% of the GEMM FLOPs) on "
                          "e4m3 MFMA (FluxTransformer2DModel.enable_fp8), reported as a separate line with its own tolerance")
+    ap.add_argument("--fp8-mode", default="mlp", choices=["mlp", "all"],
+                    help="with --dtype fp8: 'mlp' = the MLP GEMMs only; 'all' = also the image-stream / single-block QKV and attention "
+                         "output projections (97 %% of the GEMM FLOPs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -244,7 +247,7 @@ def main():
         model = FluxTransformer2DModel(device=dev).init_random_(seed=1234 + rank)
         pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
     if args.dtype == "fp8":
-        model.enable_fp8("mlp")
+        model.enable_fp8(args.fp8_mode)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     mllm_hidden = (torch.randn((B, C, St, Hm), device=dev, generator=g) * 3.0).bfloat16()
     noise = torch.randn((B, (args.size // 16) ** 2, 64), device=dev, generator=g).bfloat16()
@@ -305,9 +308,11 @@ def main():
         if args.dtype == "fp8":
             line["dtype"] = "fp8"
             line["dtype_detail"] = ("e4m3 (OCP) operands with fp32 accumulation for ff.net.0/ff.net.2 (image stream) and the single blocks' "
-                                    "proj_mlp/proj_out = 72% of the GEMM FLOPs; everything else bf16 as in the headline run; stated tolerance "
-                                    "vs the fp32 oracle in tests/test_fp8_gpu.py")
-            line["metric"] += " [fp8 MLP GEMMs]"
+                                    "proj_mlp/proj_out = 72% of the GEMM FLOPs" +
+                                    ("; plus image-stream / single-block to_q|k|v and to_out / to_add_out = 97%" if args.fp8_mode == "all" else "") +
+                                    "; everything else bf16 as in the headline run; stated tolerance vs the fp32 oracle in "
+                                    "tests/test_fp8_gpu.py")
+            line["metric"] += " [fp8 MLP GEMMs]" if args.fp8_mode == "mlp" else " [fp8 MLP + attention-projection GEMMs]"
             line["roofline"] = gemm_roofline_fp8(B)
         else:
             line["roofline"] = gemm_roofline(B)

@@ -191,6 +191,10 @@ typedef struct x2i_qkv_desc {
   float eps;
 } x2i_qkv_desc;
 int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_stream_t stream);
+/* The same fused projection on e4m3 operands (x2i_fp8_desc as for x2i_gemm_fp8, out_fp8 = 0): A is the e4m3 LayerNorm output with
+ * its row scales, W the quantised to_q|to_k|to_v weight.  The accumulators are dequantised before the shared RMSNorm / RoPE
+ * epilogue, so Q / K / V^T are bf16 as above.  Needs H*128 % 256 == 0 and the x2i_gemm_fp8 alignment rules. */
+int x2i_gemm_qkv_fp8(const x2i_gemm_args* args, const x2i_fp8_desc* fp8, const x2i_qkv_desc* qkv, x2i_stream_t stream);
 
 /* LayerNorm(elementwise_affine=False, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero / ZeroSingle /
  * Continuous and `norm2(x) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]`, lightcontrol_flux.py:166-170,

@@ -136,7 +136,51 @@ def test_attention_e4m3_output_equals_quantised_bf16_output():
     assert (b8 != a.to(FP8).float()).float().mean() < 0.03
 
 
-def _tiny(fp8):
+@pytest.mark.parametrize("B,H,St,Si", [(2, 2, 256, 1024), (1, 4, 0, 1500), (2, 2, 200, 700)])
+def test_gemm_qkv_fp8_equals_gemm_fp8_then_qkv_split(B, H, St, Si):
+    """x2i_gemm_qkv_fp8 (dequantise, then the bf16 kernel's fused RMSNorm / RoPE / head-split epilogue) against the two-step form
+    x2i_gemm_fp8 -> x2i_qkv_split_bf16 on the same e4m3 operands and scales: batched image rows behind a text offset, the
+    flattened single-block geometry, and ragged (unaligned) token counts."""
+    from x2i_amd import ops
+    D, S, Kd = H * 128, St + Si, 256
+    Spad = ops.pad128(S)
+    W8, sw = ops.quantize_rows_fp8(bf(seeded((3 * D, Kd), 40, 0.08)).to(DEV))
+    bias = bf(seeded((3 * D,), 41, 0.5)).to(DEV)
+    X8, sx = ops.quantize_rows_fp8(bf(seeded((B * S, Kd), 44)).to(DEV))
+    nq, nk = (bf(1 + 0.2 * seeded((128,), 45 + i)).to(DEV) for i in range(2))
+    ang = seeded((S, 64), 50, 3.0)
+    cos, sin = torch.cos(ang).repeat_interleave(2, 1).contiguous().to(DEV), torch.sin(ang).repeat_interleave(2, 1).contiguous().to(DEV)
+
+    def bufs():
+        z = lambda *sh: torch.zeros(sh, device=DEV, dtype=torch.bfloat16)
+        return z(B, H, Spad, 128), z(B, H, Spad, 128), z(B, H, 128, Spad)
+    Q0, K0, V0 = bufs()
+    Q1, K1, V1 = bufs()
+    if St > 0:
+        # image rows of a [B, S, Kd] activation; row scales laid out [B, Si] as the LayerNorm kernel writes them
+        sxi = sx.view(B, S)[:, St:].contiguous()
+        QKV = torch.zeros((B * S, 3 * D), device=DEV, dtype=torch.bfloat16)
+        off_img = B * St * 3 * D
+        ops.gemm_fp8(X8, W8, bias, out=QKV, M=Si, batch=B, a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd, a_scale=sxi,
+                     a_scale_batch_stride=Si, w_scale=sw, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=off_img)
+        ops.qkv_split(QKV, QKV.view(-1)[off_img:], 3 * D, 3 * D, B, S, St, H, nq, nk, nq, nk, cos, sin, Q0, K0, V0, Spad)
+        ops.gemm_qkv_fp8(X8, W8, bias, Q1, K1, V1, nq, nk, cos, sin, M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B,
+                         a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd, a_scale=sxi, a_scale_batch_stride=Si, w_scale=sw)
+        sl = slice(St, S)
+    else:
+        QKV = torch.empty((B * S, 3 * D), device=DEV, dtype=torch.bfloat16)
+        ops.gemm_fp8(X8, W8, bias, out=QKV, M=B * S, a_scale=sx, w_scale=sw)
+        ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, nq, nk, cos, sin, Q0, K0, V0, Spad)
+        ops.gemm_qkv_fp8(X8, W8, bias, Q1, K1, V1, nq, nk, cos, sin, M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S,
+                         a_scale=sx, w_scale=sw)
+        sl = slice(0, S)
+    torch.cuda.synchronize()
+    assert torch.equal(V1[..., sl], V0[..., sl]) and torch.equal(Q1[:, :, sl], Q0[:, :, sl]) and torch.equal(K1[:, :, sl], K0[:, :, sl])
+    assert float(Q1[:, :, :St].float().abs().max() if St else 0.0) == 0.0  # rows outside the launch are untouched
+    assert float(Q1[:, :, sl].float().abs().mean()) > 0.1
+
+
+def _tiny(fp8, mode="mlp"):
     from oracle import flux as OF
     from x2i_amd.flux import FluxTransformer2DModel
     cfg = dict(OF.DEFAULT_CFG)
@@ -145,17 +189,18 @@ def _tiny(fp8):
     m = FluxTransformer2DModel(**cfg, device=DEV)
     m.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
     if fp8:
-        m.enable_fp8("mlp")
+        m.enable_fp8(mode)
     return m, sd, cfg
 
 
-def test_fp8_model_vs_bf16_model_and_fp32_oracle_and_graph_replay():
+@pytest.mark.parametrize("mode", ["mlp", "all"])
+def test_fp8_model_vs_bf16_model_and_fp32_oracle_and_graph_replay(mode):
     """Stated tolerance of the fp8 configuration: transformer output rel-L2 <= 6e-2 vs the fp32 oracle (bf16: <= 2e-2), 4-step latents
     <= 8e-2; per-sample results stay batch independent and hipGraph replay is bit-identical to eager."""
     from oracle import flux as OF
     from oracle import sampler as OS
     from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
-    m8, sd, cfg = _tiny(True)
+    m8, sd, cfg = _tiny(True, mode)
     m16, _, _ = _tiny(False)
     g = torch.Generator().manual_seed(0)
     B, St, h2, w2 = 3, 24, 6, 8
@@ -168,7 +213,7 @@ def test_fp8_model_vs_bf16_model_and_fp32_oracle_and_graph_replay():
     o8, o16 = m8(**kw)[0], m16(**kw)[0]
     ref = OF.flux_forward({k: v.bfloat16().float() for k, v in sd.items()}, cfg, hid.float(), enc.float(), pooled.float(), ts, ids, tids)
     e8, e16 = rel_l2(o8, ref), rel_l2(o16, ref)
-    print(f"tiny 2+2 blocks: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
+    print(f"tiny 2+2 blocks [{mode}]: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
     assert e16 < 2e-2 and e8 < 6e-2 and not torch.equal(o8, o16)
     kw1 = dict(kw, hidden_states=kw["hidden_states"][1:2], encoder_hidden_states=kw["encoder_hidden_states"][1:2],
                pooled_projections=kw["pooled_projections"][1:2], timestep=kw["timestep"][1:2])
@@ -185,7 +230,8 @@ def test_fp8_model_vs_bf16_model_and_fp32_oracle_and_graph_replay():
     assert torch.equal(m8(**kw)[0], o16)  # switching back restores the bf16 path bit for bit
 
 
-def test_fp8_full_width_blocks_vs_oracle():
+@pytest.mark.parametrize("mode", ["mlp", "all"])
+def test_fp8_full_width_blocks_vs_oracle(mode):
     """D = 3072, one double + one single block on 512 + 1024 tokens: the real GEMM shapes of the fp8 configuration."""
     from oracle import flux as OF
     from oracle import sampler as OS
@@ -201,10 +247,10 @@ def test_fp8_full_width_blocks_vs_oracle():
     kw = dict(hidden_states=hidden.to(DEV), encoder_hidden_states=enc.to(DEV), pooled_projections=pooled.to(DEV), timestep=ts.to(DEV),
               img_ids=img_ids.to(DEV), txt_ids=txt_ids.to(DEV), return_dict=False)
     o16 = m(**kw)[0].clone()
-    m.enable_fp8("mlp")
+    m.enable_fp8(mode)
     o8 = m(**kw)[0]
     ref = OF.flux_forward({k: v.bfloat16().float() for k, v in sd.items()}, cfg, hidden.bfloat16().float(), enc.bfloat16().float(),
                           pooled.bfloat16().float(), ts, img_ids, txt_ids)
     e8, e16 = rel_l2(o8, ref), rel_l2(o16, ref)
-    print(f"full-width 1+1 blocks: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
+    print(f"full-width 1+1 blocks [{mode}]: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
     assert e16 < 2e-2 and e8 < 6e-2

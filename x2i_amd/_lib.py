@@ -59,6 +59,7 @@ SIGNATURES = {
     "x2i_conv2d_nhwc_bf16": [C.POINTER(GemmArgs), C.POINTER(ConvDesc), _vp],
     "x2i_gemm_qkv_bf16": [C.POINTER(GemmArgs), C.POINTER(QkvDesc), _vp],
     "x2i_gemm_fp8": [C.POINTER(GemmArgs), C.POINTER(Fp8Desc), _vp],
+    "x2i_gemm_qkv_fp8": [C.POINTER(GemmArgs), C.POINTER(Fp8Desc), C.POINTER(QkvDesc), _vp],
     "x2i_quantize_rows_fp8": [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _f32, _vp],
     "x2i_ln_modulate_fp8": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64,
                             _f32, _vp],

@@ -122,6 +122,10 @@ int x2i_gemm_fp8(const x2i_gemm_args* args, const x2i_fp8_desc* fp8, x2i_stream_
   return x2i_launch_gemm_fp8(args, fp8, (hipStream_t)stream);
 }
 
+int x2i_gemm_qkv_fp8(const x2i_gemm_args* args, const x2i_fp8_desc* fp8, const x2i_qkv_desc* qkv, x2i_stream_t stream) {
+  return x2i_launch_gemm_qkv_fp8(args, fp8, qkv, (hipStream_t)stream);
+}
+
 int x2i_quantize_rows_fp8(const void* x, int64_t rows, int32_t cols, int64_t ldx, void* y, int64_t ldy, float* scale,
                           float static_inv_scale, x2i_stream_t stream) {
   return x2i_launch_quantize_rows_fp8(x, rows, cols, ldx, y, ldy, scale, static_inv_scale, (hipStream_t)stream);

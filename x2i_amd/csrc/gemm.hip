@@ -46,6 +46,7 @@ constexpr double NAIVE_MAX_FLOP = 5.0e10;
 }  // namespace
 
 static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream);
+static int check_qkv_desc(const x2i_gemm_args* a, const x2i_qkv_desc* qd, const char* who);
 
 int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream) { return launch_gemm_impl(a, nullptr, nullptr, stream); }
 int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream) {
@@ -53,17 +54,7 @@ int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStr
 }
 int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStream_t stream) {
   if (!a || !qd) return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: null pointer");
-  if (!qd->norm_q || !qd->norm_k || !qd->cos || !qd->sin || !qd->Q || !qd->K || !qd->VT)
-    return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: null pointer in descriptor");
-  if (qd->H <= 0 || a->N != 3 * qd->H * 128) return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv: N=%d must be 3*H*128 (H=%d)", a->N, qd->H);
-  if (qd->Spad % 128 || qd->rows_per_sample <= 0 || qd->tok_off < 0 || qd->tok_off + qd->rows_per_sample > qd->Spad)
-    return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv: bad token geometry (tok_off=%d rows_per_sample=%d Spad=%d)", qd->tok_off,
-                         qd->rows_per_sample, qd->Spad);
-  if (a->act || a->res || a->gate || a->C2 || a->out_f32 || a->bias2)
-    return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: only the plain bias epilogue can be fused");
-  if ((((uintptr_t)qd->Q | (uintptr_t)qd->K | (uintptr_t)qd->VT | (uintptr_t)qd->norm_q | (uintptr_t)qd->norm_k | (uintptr_t)qd->cos |
-        (uintptr_t)qd->sin) & 15) != 0)
-    return x2i_set_error(X2I_ERR_ALIGN, "gemm_qkv: descriptor pointers must be 16-byte aligned");
+  if (const int rc = check_qkv_desc(a, qd, "gemm_qkv")) return rc;
   return launch_gemm_impl(a, nullptr, qd, stream);
 }
 
@@ -209,8 +200,35 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
 // ---------------------------------------------------------------------------------------------------------------------
 // fp8 (e4m3) operands: x2i_gemm_fp8.  One kernel family (256^2 tiles, gemm256_fp8.hip); shapes it does not serve are refused
 // with a message -- the host keeps those GEMMs on the bf16 path (there is no silent slow fallback).
+static int check_qkv_desc(const x2i_gemm_args* a, const x2i_qkv_desc* qd, const char* who) {
+  if (!qd->norm_q || !qd->norm_k || !qd->cos || !qd->sin || !qd->Q || !qd->K || !qd->VT)
+    return x2i_set_error(X2I_ERR_ARG, "%s: null pointer in descriptor", who);
+  if (qd->H <= 0 || a->N != 3 * qd->H * 128) return x2i_set_error(X2I_ERR_SHAPE, "%s: N=%d must be 3*H*128 (H=%d)", who, a->N, qd->H);
+  if (qd->Spad % 128 || qd->rows_per_sample <= 0 || qd->tok_off < 0 || qd->tok_off + qd->rows_per_sample > qd->Spad)
+    return x2i_set_error(X2I_ERR_SHAPE, "%s: bad token geometry (tok_off=%d rows_per_sample=%d Spad=%d)", who, qd->tok_off,
+                         qd->rows_per_sample, qd->Spad);
+  if (a->act || a->res || a->gate || a->C2 || a->out_f32 || a->bias2)
+    return x2i_set_error(X2I_ERR_ARG, "%s: only the plain bias epilogue can be fused", who);
+  if ((((uintptr_t)qd->Q | (uintptr_t)qd->K | (uintptr_t)qd->VT | (uintptr_t)qd->norm_q | (uintptr_t)qd->norm_k | (uintptr_t)qd->cos |
+        (uintptr_t)qd->sin) & 15) != 0)
+    return x2i_set_error(X2I_ERR_ALIGN, "%s: descriptor pointers must be 16-byte aligned", who);
+  return X2I_OK;
+}
+
+static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, const x2i_qkv_desc* qd, hipStream_t stream);
 int x2i_launch_gemm_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, hipStream_t stream) {
-  if (!a || !f || !a->A || !a->W || !a->C) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: null pointer");
+  return launch_gemm_fp8_impl(a, f, nullptr, stream);
+}
+int x2i_launch_gemm_qkv_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, const x2i_qkv_desc* qd, hipStream_t stream) {
+  if (!a || !f || !qd) return x2i_set_error(X2I_ERR_ARG, "gemm_qkv_fp8: null pointer");
+  if (const int rc = check_qkv_desc(a, qd, "gemm_qkv_fp8")) return rc;
+  if (f->out_fp8) return x2i_set_error(X2I_ERR_ARG, "gemm_qkv_fp8: Q / K / V^T are written as bf16");
+  if ((qd->H * 128) % BN2) return x2i_set_error(X2I_ERR_SHAPE, "gemm_qkv_fp8: H*128 must be a multiple of 256 (H=%d)", qd->H);
+  return launch_gemm_fp8_impl(a, f, qd, stream);
+}
+
+static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, const x2i_qkv_desc* qd, hipStream_t stream) {
+  if (!a || !f || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: null pointer");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm_fp8: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: gate without residual");
   if (a->C2 || a->out_f32 || a->w_batch_stride) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: C2 / f32 output / per-batch W are not supported");
@@ -220,7 +238,7 @@ int x2i_launch_gemm_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, hipStream
     return x2i_set_error(X2I_ERR_SHAPE, "gemm_fp8: operand larger than 2 GB per batch item");
   const bool out8 = f->out_fp8 != 0, res = a->res != nullptr;
   const int nal = out8 ? 15 : 7;
-  if ((a->N & nal) || (a->ldc & nal) || (a->c_batch_stride & nal) || (((uintptr_t)a->C) & 15) || (res && ((a->ldr & 7) || (a->res_batch_stride & 7))))
+  if ((a->N & nal) || (!qd && ((a->ldc & nal) || (a->c_batch_stride & nal) || (((uintptr_t)a->C) & 15))) || (res && ((a->ldr & 7) || (a->res_batch_stride & 7))))
     return x2i_set_error(X2I_ERR_ALIGN, "gemm_fp8: N, ldc and c_batch_stride must be multiples of %d, C 16-byte aligned", nal + 1);
   if (out8 && (res || a->gate)) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: e4m3 output has no residual form");
   kern_t kern = pick_gemm256_fp8(a->act, res, out8);
@@ -238,6 +256,12 @@ int x2i_launch_gemm_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, hipStream
   p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
+  if (qd) {
+    p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps;
+    p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
+    p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT;
+    p.ldc = a->N; p.c_bs = 0;  // C is never written
+  }
   p.f_sa = f->a_scale; p.f_sa_bs = f->a_scale_batch_stride; p.f_sw = f->w_scale; p.f_alpha = f->alpha; p.f_oinv = f->out_inv_scale;
   p.f_out8 = out8 ? 1 : 0;
   const int tm = (a->M + BM2 - 1) / BM2, tn = (a->N + BN2 - 1) / BN2;

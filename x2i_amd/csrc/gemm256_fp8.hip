@@ -219,6 +219,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(GemmP p) {
     });
   }
   __syncthreads();  // every wave is done reading the operand images before they are reused as staging space
+  if constexpr (ACT == X2I_ACT_NONE && !RES && !OUT8) {
+    if (p.q_on) {  // fused per-head RMSNorm + RoPE + head-major / transposed stores (x2i_gemm_qkv_fp8), same code as the bf16 kernel
+      epilogue_qkv<8, 4, 512>(p, acc, z, m0, n0, wm, wn, lane, tid, smem);
+      return;
+    }
+  }
   if constexpr (OUT8) {
     epilogue_store_fp8<ACT>(p, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
   } else {

@@ -193,33 +193,44 @@ class FluxTransformer2DModel(nn.Module):
         # X2I_QKV_FUSE=0 (read once, here) keeps the two-step form GEMM -> x2i_qkv_split for A/B measurements; bit-identical results
         self.fuse_qkv = os.environ.get("X2I_QKV_FUSE", "1") != "0"
         self._fp8 = None  # see enable_fp8()
+        self._fp8_mode = None
 
     # ------------------------------------------------------------------ fp8 (e4m3) configuration, opt-in
     @torch.no_grad()
     def enable_fp8(self, mode="mlp"):
-        """Switch the large image-/joint-stream MLP linears to the e4m3 MFMA path (BASELINE north_star "MFMA bf16/fp8"; bf16 stays
-        the default).  mode "mlp": double blocks' ff.net.0 / ff.net.2 on the image rows and the single blocks' proj_mlp / proj_out
-        (72 % of the GEMM FLOPs); QKV / attention-output projections, every text-stream linear and all small linears stay bf16.
+        """Switch the large image-/joint-stream linears to the e4m3 MFMA path (BASELINE north_star "MFMA bf16/fp8 for the QKV/out-proj
+        and MLP GEMMs"; bf16 stays the default).
+          mode "mlp": double blocks' ff.net.0 / ff.net.2 on the image rows and the single blocks' proj_mlp / proj_out (72 % of the
+                      GEMM FLOPs); QKV / attention-output projections stay bf16.
+          mode "all": additionally the image-stream to_q|k|v (fused RMSNorm/RoPE epilogue, x2i_gemm_qkv_fp8), to_out / to_add_out
+                      and the single blocks' to_q|k|v (97 % of the GEMM FLOPs).  Text-stream QKV / feed-forward and all small
+                      linears stay bf16 in both modes.
         Weights are quantised ONCE here (per-output-channel scales, x2i_quantize_rows_fp8) from the bf16 parameters currently
         loaded -- call again after load_state_dict().  Activations: the preceding LayerNorm+modulate emits e4m3 rows with
-        per-row scales; GELU outputs and the single blocks' attention output are written as e4m3 with a static scale of 1
-        (saturating at 448).  mode None / "off" returns to bf16."""
+        per-row scales; GELU outputs and attention outputs are written as e4m3 with a static scale of 1 (saturating at 448).
+        mode None / "off" returns to bf16."""
         if mode in (None, "off", False):
             self._fp8 = None
+            self._fp8_mode = None
             self._ws = {}
             return self
-        if mode != "mlp":
-            raise ValueError("enable_fp8: mode must be 'mlp' or None")
+        if mode not in ("mlp", "all"):
+            raise ValueError("enable_fp8: mode must be 'mlp', 'all' or None")
         if self.inner_dim % 128:
             raise ValueError("enable_fp8: inner_dim must be a multiple of 128 (K-tile of the e4m3 MFMA kernel)")
+        if mode == "all" and (not self.fuse_qkv or self._H % 2):
+            raise ValueError("enable_fp8('all'): needs the fused QKV epilogue and an even head count (256-column tiles)")
         D, f, q = self.inner_dim, self._fused, {}
         for i in range(self.config.num_layers):
-            for nm in (f"d{i}.ff.0", f"d{i}.ff.2"):
+            for nm in (f"d{i}.ff.0", f"d{i}.ff.2") + ((f"d{i}.qkv", f"d{i}.to_out", f"d{i}.to_add_out") if mode == "all" else ()):
                 q[nm] = ops.quantize_rows_fp8(f[nm + ".w"])
         for i in range(self.config.num_single_layers):
+            if mode == "all":
+                q[f"s{i}.qkv"] = ops.quantize_rows_fp8(f[f"s{i}.in.w"][:3 * D])
             q[f"s{i}.mlp"] = ops.quantize_rows_fp8(f[f"s{i}.in.w"][3 * D:])
             q[f"s{i}.proj_out"] = ops.quantize_rows_fp8(f[f"s{i}.proj_out.w"])
         self._fp8 = q
+        self._fp8_mode = mode
         self._ws = {}
         return self
 
@@ -243,7 +254,7 @@ class FluxTransformer2DModel(nn.Module):
             p.data = self._fused[name][sl]
         self._ws = {}
         if getattr(self, "_fp8", None) is not None:
-            self.enable_fp8("mlp")  # re-quantise on the new device
+            self.enable_fp8(self._fp8_mode)  # re-quantise on the new device
         return self
 
     @torch.no_grad()
@@ -287,6 +298,8 @@ class FluxTransformer2DModel(nn.Module):
             f8 = dict(device=dev, dtype=ops.FP8)
             ws.update(NRM8=torch.empty((B, S, D), **f8), RS=torch.empty((B * S,), device=dev, dtype=torch.float32),
                       H8=torch.empty((B * Si, 4 * D), **f8), CAT8=torch.empty((B * S, 5 * D), **f8))
+            if self._fp8_mode == "all":
+                ws.update(ATT8=torch.empty((B, S, D), **f8))
         self._ws = {key: ws}  # keep one shape resident
         return ws
 
@@ -368,6 +381,7 @@ class FluxTransformer2DModel(nn.Module):
 
         fuse_qkv = self.fuse_qkv and D % 64 == 0
         fp8 = self._fp8
+        fp8_all = fp8 is not None and self._fp8_mode == "all"
         # forward hooks on block.attn (attention-distillation capture): materialise the attention outputs of every block
         taps = any(len(b.attn._forward_hooks) for b in self.transformer_blocks) or \
             any(len(b.attn._forward_hooks) for b in self.single_transformer_blocks)
@@ -380,8 +394,23 @@ class FluxTransformer2DModel(nn.Module):
             p = f"d{i}"
             oi = i * 12 * D
             oc = oi + 6 * D
-            ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
-            if fuse_qkv:
+            if fp8_all:
+                # text rows: bf16 norm for the bf16 add_q|k|v projection; image rows: e4m3 rows + per-row scales
+                if St > 0:
+                    ops.ln_modulate(X, NRM, B, St, D, St, mod(oc), mod(oc + D), mod(oc), mod(oc + D), Ntot, x_bs=S * D, y_bs=S * D)
+                ops.ln_modulate_fp8(X, None, ws["NRM8"], ws["RS"], B, Si, D, 0, None, None, mod(oi), mod(oi + D), Ntot,
+                                    x_bs=S * D, x_offset=St * D, y8_bs=S * D, y8_offset=St * D)
+                wq, sq = fp8[p + ".qkv"]
+                ops.gemm_qkv_fp8(ws["NRM8"], wq, f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=Si, H=H,
+                                 Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                                 a_scale=ws["RS"], a_scale_batch_stride=Si, w_scale=sq)
+                ops.gemm_qkv(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], Q, K, VT, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
+                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D)
+            else:
+                ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
+            if fp8_all:
+                pass
+            elif fuse_qkv:
                 # q/k RMSNorm + RoPE + head split + V transpose ride in the QKV GEMM's epilogue (no [B*S, 3D] round trip)
                 ops.gemm_qkv(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
                              M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
@@ -395,9 +424,21 @@ class FluxTransformer2DModel(nn.Module):
                          c_batch_stride=St * 3 * D, ldc=3 * D)
                 ops.qkv_split(qkv_txt, QKV.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"],
                               f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
-            ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
+            if fp8_all:
+                ops.attention_e4m3out(Q, K, VT, ws["ATT8"], B, H, S, Spad, D, S * D, scale)
+                (wo, so), (wa, sa) = fp8[p + ".to_out"], fp8[p + ".to_add_out"]
+                ops.gemm_fp8(ws["ATT8"], wo, f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                             w_scale=so, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
+                             res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
+                ops.gemm_fp8(ws["ATT8"], wa, f[p + ".to_add_out.b"], out=X, M=St, batch=B, a_batch_stride=S * D, lda=D, w_scale=sa,
+                             c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
+                             gate_batch_stride=Ntot)
+            else:
+                ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
             # hidden += gate_msa * to_out(attn_img) ; enc += c_gate_msa * to_add_out(attn_txt)
-            if not taps:
+            if fp8_all:
+                pass
+            elif not taps:
                 ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
                          a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
                          res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
@@ -455,9 +496,13 @@ class FluxTransformer2DModel(nn.Module):
             if fp8 is None:
                 ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
             else:
-                ops.ln_modulate_fp8(X, NRM, ws["NRM8"], ws["RS"], B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
+                ops.ln_modulate_fp8(X, None if fp8_all else NRM, ws["NRM8"], ws["RS"], B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
             w, bias = f[p + ".in.w"], f[p + ".in.b"]
-            if fuse_qkv:
+            if fp8_all:
+                wq, sq = fp8[p + ".qkv"]
+                ops.gemm_qkv_fp8(ws["NRM8"], wq, bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
+                                 Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=ws["RS"], w_scale=sq)
+            elif fuse_qkv:
                 ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
                              Spad=Spad, tok_off=0, rows_per_sample=S)
             else:

@@ -385,6 +385,36 @@ def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_
     return out
 
 
+def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1,
+                 a_batch_stride=0, lda=None, a_offset=0, a_scale=None, a_scale_batch_stride=0, w_scale=None, alpha=1.0, eps=1e-6):
+    """gemm_qkv on e4m3 operands (include/x2i.h: x2i_gemm_qkv_fp8): dequantised accumulators, then the same fused epilogue."""
+    lib = _lib.load()
+    _req(A8, FP8, "A8")
+    _req(W8, FP8, "W8")
+    a = GemmArgs()
+    a.A = A8.data_ptr() + a_offset
+    a.a_batch_stride = a_batch_stride
+    a.lda = A8.shape[-1] if lda is None else lda
+    a.W, a.ldw = W8.data_ptr(), W8.stride(-2)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C = None
+    a.c_batch_stride, a.ldc = 0, 3 * H * 128
+    a.C2, a.act2, a.gate, a.gate_batch_stride, a.res, a.res_batch_stride, a.ldr = None, 0, None, 0, None, 0, 0
+    a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
+    a.M, a.N, a.K, a.batch = M, 3 * H * 128, W8.shape[-1], batch
+    a.act, a.out_f32 = ACT_NONE, 0
+    f = Fp8Desc()
+    f.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    f.a_scale_batch_stride = a_scale_batch_stride
+    f.w_scale = w_scale.data_ptr() if w_scale is not None else None
+    f.alpha, f.out_fp8, f.out_inv_scale = float(alpha), 0, 1.0
+    q = QkvDesc()
+    q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
+    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps = H, Spad, tok_off, rows_per_sample, eps
+    check(lib.x2i_gemm_qkv_fp8(C.byref(a), C.byref(f), C.byref(q), _stream()), "gemm_qkv_fp8")
+
+
 def ln_modulate_fp8(X, Y, Y8, row_scale, B, S, D, S0, shift0, scale0, shift1, scale1, mod_bs, eps=1e-6, x_bs=None, ldx=None,
                     y_bs=None, ldy=None, x_offset=0, y_offset=0, y8_bs=None, ldy8=None, y8_offset=0):
     """ln_modulate with an extra e4m3 output + per-row scales (Y may be None)."""
