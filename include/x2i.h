@@ -239,6 +239,8 @@ int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2
 
 /* Projector layer fusion (utils/proj.py:62-72).  x: bf16 [B,C,S,H] -> y: bf16 [B,S,H]
  *   conv5x5:   Conv2d(C->1, k=5, pad=2) over the (S,H) plane (:68-69); w f32 [C,5,5], bias f32 [1]
+ *              The f32 taps are rounded to bf16 inside the kernel (packed bf16 tap pairs feed v_dot2c_f32_bf16; the reference's
+ *              conv runs in bf16 under autocast, so its weights are bf16 values already); accumulation and bias are fp32.
  *   layer_mean: (cha_scale * x).mean(1) (:66-67) or plain mean (:70-71) when scale == NULL; scale f32 [C] */
 int x2i_proj_conv5x5_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t C, int32_t S,
                           int32_t H, x2i_stream_t stream);
