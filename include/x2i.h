@@ -50,7 +50,7 @@ const char* x2i_last_error(void);
 /* A/B and tuning switches.  Defaults are the product configuration; each option is initialised ONCE (first use) from the
  * environment variable X2I_<NAME> and afterwards only changes through x2i_set_option -- nothing on the launch path reads
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
- * "conv256" (1), "attn_variant" (0), "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
+ * "conv256" (1), "attn_variant" (0), "conv5_variant" (0), "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
  * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
  * return X2I_ERR_ARG.  Every setting selects between
  * kernels with identical results (bit-identical where the tests say so); the measurement-only kernels ("wrong results by
@@ -246,6 +246,13 @@ int x2i_proj_conv5x5_bf16(const void* x, const float* w, const float* bias, void
                           int32_t H, x2i_stream_t stream);
 int x2i_proj_layer_mean_bf16(const void* x, const float* scale, void* y, int32_t B, int32_t C, int64_t plane,
                              x2i_stream_t stream);
+/* conv5x5 on the matrix cores (the form x2i_amd uses; same result up to fp32 summation order): the taps are first expanded, once
+ * per weight, into banded-Toeplitz MFMA fragments -- table: bf16 [C][5][64][8] (C * 5 KiB, 16-byte aligned, caller-owned) -- and the
+ * convolution then runs as v_mfma_f32_16x16x32_bf16 over 32-column windows of 16 input rows (csrc/proj_conv_mfma.hip).  H % 8 == 0,
+ * y 8-byte aligned; any C. */
+int x2i_proj_conv5x5_pack(const float* w, void* table, int32_t C, x2i_stream_t stream);
+int x2i_proj_conv5x5_packed_bf16(const void* x, const void* table, const float* bias, void* y, int32_t B, int32_t C, int32_t S,
+                                 int32_t H, x2i_stream_t stream);
 /* torch.mean(x1, 1): x f32 [B,S,N] -> y f32 [B,N] (utils/proj.py:32) */
 int x2i_seq_mean_f32(const float* x, float* y, int32_t B, int32_t S, int32_t N, x2i_stream_t stream);
 

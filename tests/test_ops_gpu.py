@@ -276,6 +276,44 @@ def test_proj_conv5x5(ops, B, C, S, H):
     assert rel_l2(out, ref) < 5e-3
 
 
+@pytest.mark.parametrize("B,C,S,H", [(1, 3, 6, 64), (2, 29, 40, 896), (1, 37, 20, 2048), (2, 1, 12, 256), (1, 4, 13, 264), (1, 37, 512, 2048)])
+def test_proj_conv5x5_matrix_core_form(ops, opt, B, C, S, H):
+    """x2i_proj_conv5x5_pack + x2i_proj_conv5x5_packed_bf16 (banded-Toeplitz MFMA form, the one proj.py uses) against
+    F.conv2d in fp32 on the same bf16 inputs and bf16-rounded taps (tight: only the summation order differs), against the
+    unrounded taps (the VALU form's tolerance), and against the VALU form itself.  Shapes: single row block, ragged row blocks
+    (S % 12 != 0), ragged column blocks (H % 256 != 0, H % 16 != 0), odd / even / single layer counts, the full Qwen2.5-VL-3B
+    plane."""
+    x = bf(seeded((B, C, S, H), 32, 3.0))
+    w, b = seeded((1, C, 5, 5), 33) / (C * 25) ** 0.5, seeded((1,), 34)
+    wg = g(w.reshape(C, 25).contiguous())
+    table = ops.proj_conv5x5_pack(wg)
+    assert table.shape == (C, 5, 64, 8)
+    # Toeplitz fragments: lane (n, g), element j holds tap 8 g + j - n - 6 of the kernel row
+    t = table.float().cpu().view(C, 5, 4, 16, 8)
+    wb = bf(w).float().view(C, 5, 5)
+    for gi, n, j in ((0, 0, 6), (1, 5, 3), (1, 0, 2), (2, 15, 7), (3, 15, 1), (0, 3, 0), (3, 0, 0)):
+        dh = 8 * gi + j - n - 6
+        want = wb[:, :, dh] if 0 <= dh <= 4 else torch.zeros(C, 5)
+        assert torch.equal(t[:, :, gi, n, j], want)
+    out = ops.proj_conv5x5_packed(g(x), table, g(b))
+    ref_b = F.conv2d(x.float(), bf(w).float(), b, padding=2).squeeze(1)
+    assert rel_l2(out, ref_b) < 3e-3  # bf16 output rounding
+    assert rel_l2(out, F.conv2d(x.float(), w, b, padding=2).squeeze(1)) < 5e-3
+    valu = ops.proj_conv5x5(g(x), wg, g(b))
+    assert rel_l2(out, valu.float().cpu()) < 3e-3
+    # staging variants (layers per stage x ring depth) are the same arithmetic in the same order
+    for v in (1, 2, 3):
+        opt("conv5_variant", v)
+        assert torch.equal(ops.proj_conv5x5_packed(g(x), table, g(b)), out), v
+    opt("conv5_variant", 0)
+    # no bias pointer, and a table / layer-count mismatch is refused
+    out0 = ops.proj_conv5x5_packed(g(x), table, None)
+    assert rel_l2(out0, ref_b - b) < 3e-3
+    if C > 1:
+        with pytest.raises(ValueError):
+            ops.proj_conv5x5_packed(g(x[:, :-1].contiguous()), table, g(b))
+
+
 def test_proj_layer_mean_and_seq_mean(ops):
     x = bf(seeded((2, 25, 8, 896), 35, 3.0))
     sc = seeded((25,), 36)

@@ -1,44 +1,38 @@
-#!/usr/bin/env python3
-"""ControlNeXt / VAE convolution shapes through the implicit-GEMM path (run on the GPU box): achieved TFLOP/s per shape."""
-import os
+"""Projector conv5x5: VALU form vs matrix-core (Toeplitz MFMA) form, HIP-event timing.  python tools/conv_bench.py [B]"""
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ".")
 from x2i_amd import ops  # noqa: E402
-from tools.microbench import timeit, rnd  # noqa: E402
 
-B = 4
-SHAPES = [  # h, w, cin, cout, k, stride, pad, residual, name
-    (512, 512, 128, 128, 3, 1, 1, True, "res0.conv2"),
-    (512, 512, 128, 128, 3, 2, 1, False, "down0"),
-    (256, 256, 128, 256, 3, 1, 1, False, "res1.conv1"),
-    (256, 256, 128, 256, 1, 1, 0, False, "res1.shortcut"),
-    (256, 256, 256, 256, 3, 1, 1, True, "res1.conv2"),
-    (256, 256, 256, 256, 3, 2, 1, False, "down1"),
-    (128, 128, 256, 256, 3, 1, 1, False, "mid"),
-    (128, 128, 256, 3072, 2, 2, 0, False, "out 2x2s2"),
-    (512, 512, 256, 256, 3, 1, 1, False, "vae up2 res"),
-    (1024, 1024, 128, 128, 3, 1, 1, False, "vae up3 res"),
-]
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
 
 
 def main():
-    global B
-    B = int(os.environ.get("X2I_B", "4"))
-    extra = [(128, 128, 128, 128, 3, 1, 1, True, "res0.conv2@128"), (128, 128, 128, 128, 3, 1, 1, False, "res0 nores@128"),
-             (512, 512, 128, 128, 3, 1, 1, False, "res0 nores")]
-    for (h, w, cin, cout, k, s, pad, res, name) in extra + SHAPES + extra:
-        x = rnd(B, h, w, cin)
-        wt = rnd(cout, k * k * cin, scale=0.02)
-        b = rnd(cout)
-        oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-        r = rnd(B, oh, ow, cout) if res else None
-        out = torch.empty((B, oh, ow, cout), device="cuda", dtype=torch.bfloat16)
-        t = timeit(lambda: ops.conv2d_nhwc(x, wt, b, h, w, cin, cout, k, k, s, pad, res=r, out=out))
-        fl = 2.0 * B * oh * ow * cout * k * k * cin
-        print(f"conv {name:14s} {h}x{w} {cin}->{cout} k{k}s{s}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TFLOP/s  ({fl/1e9:.0f} GFLOP)")
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    for (C, H) in ((37, 2048), (29, 3584)):
+        x = torch.randn(B, C, 512, H, device="cuda").bfloat16()
+        w, bb = torch.randn(C, 25, device="cuda"), torch.randn(1, device="cuda")
+        table = ops.proj_conv5x5_pack(w)
+        t = timeit(lambda: ops.proj_conv5x5(x, w, bb))
+        print(f"proj_conv5x5[VALU] B={B} C={C} H={H}: {t*1e6:8.1f} us  {x.numel()*2/t/1e9:8.1f} GB/s (input)")
+        for v, name in ((0, "automatic"), (3, "two row blocks per wave"), (2, "register-pipelined"), (1, "plain 2-layer stages")):
+            with ops.option("conv5_variant", v):
+                t = timeit(lambda: ops.proj_conv5x5_packed(x, table, bb))
+            print(f"proj_conv5x5[MFMA, {name}] B={B} C={C} H={H}: {t*1e6:8.1f} us  {x.numel()*2/t/1e9:8.1f} GB/s (input)")
+        del x
 
 
 if __name__ == "__main__":

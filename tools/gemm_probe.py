@@ -33,8 +33,10 @@ if which in ("all", "proj"):
     for (C, Hh) in ((37, 2048), (29, 3584)):
         x = rnd(B, C, 512, Hh, scale=3.0)
         w, bb = torch.randn(C, 25, device="cuda").bfloat16().float(), torch.randn(1, device="cuda")
+        table = ops.proj_conv5x5_pack(w)
         for _ in range(3):
             ops.proj_conv5x5(x, w, bb)
+            ops.proj_conv5x5_packed(x, table, bb)
         torch.cuda.synchronize()
         del x
 if which in ("all", "attn"):

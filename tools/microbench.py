@@ -95,7 +95,10 @@ def main():
         x = rnd(B, C, 512, Hh)
         w, bb = torch.randn(C, 25, device=DEV), torch.randn(1, device=DEV)
         t = timeit(lambda: ops.proj_conv5x5(x, w, bb))
-        print(f"proj_conv5x5 C={C} H={Hh}: {t*1e3:8.3f} ms  {x.numel()*2/t/1e9:8.1f} GB/s (input)")
+        print(f"proj_conv5x5[VALU] C={C} H={Hh}: {t*1e3:8.3f} ms  {x.numel()*2/t/1e9:8.1f} GB/s (input)")
+        table = ops.proj_conv5x5_pack(w)
+        t = timeit(lambda: ops.proj_conv5x5_packed(x, table, bb))
+        print(f"proj_conv5x5[MFMA] C={C} H={Hh}: {t*1e3:8.3f} ms  {x.numel()*2/t/1e9:8.1f} GB/s (input)")
         del x
 
 

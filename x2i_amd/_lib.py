@@ -76,6 +76,8 @@ SIGNATURES = {
     "x2i_gated_residual_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
     "x2i_euler_step_bf16": [_vp, _vp, _i64, _vp, _vp],
     "x2i_proj_conv5x5_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "x2i_proj_conv5x5_pack": [_vp, _vp, _i32, _vp],
+    "x2i_proj_conv5x5_packed_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_proj_layer_mean_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _vp],
     "x2i_seq_mean_f32": [_vp, _vp, _i32, _i32, _i32, _vp],
     "x2i_softmax_rows_bf16": [_vp, _i64, _i32, _f32, _vp],

@@ -43,6 +43,7 @@ X2IOptions make_options() {
   o.gemm_split_tail = env_int("X2I_GEMM_NOSPLIT", 0) ? 0 : 1;
   o.conv256 = env_int("X2I_CONV256", 1);
   o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
+  o.conv5_variant = env_int("X2I_CONV5_VARIANT", 0);
   o.fp8 = env_int("X2I_FP8", 0);
   o.last_gemm_tile = -1;
   o.gemm_lform = env_int("X2I_GEMM_LFORM", 1);
@@ -78,7 +79,7 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
   X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate)
 #endif
@@ -217,6 +218,15 @@ int x2i_euler_step_bf16(void* x, const void* eps, int64_t n, const float* dt, x2
 int x2i_proj_conv5x5_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t C, int32_t S, int32_t H,
                           x2i_stream_t stream) {
   return x2i_launch_proj_conv5x5(x, w, bias, y, B, C, S, H, (hipStream_t)stream);
+}
+
+int x2i_proj_conv5x5_pack(const float* w, void* table, int32_t C, x2i_stream_t stream) {
+  return x2i_launch_proj_conv5x5_pack(w, table, C, (hipStream_t)stream);
+}
+
+int x2i_proj_conv5x5_packed_bf16(const void* x, const void* table, const float* bias, void* y, int32_t B, int32_t C, int32_t S,
+                                 int32_t H, x2i_stream_t stream) {
+  return x2i_launch_proj_conv5x5_packed(x, table, bias, y, B, C, S, H, (hipStream_t)stream);
 }
 
 int x2i_proj_layer_mean_bf16(const void* x, const float* scale, void* y, int32_t B, int32_t C, int64_t plane, x2i_stream_t stream) {

@@ -39,6 +39,9 @@ int x2i_launch_gated_residual(void* X, long long x_bs, int ldx, const void* T, l
 int x2i_launch_euler_step(void* x, const void* eps, long long n, const float* dt, hipStream_t stream);
 int x2i_launch_proj_conv5x5(const void* x, const float* w, const float* bias, void* y, int B, int C, int S, int H,
                             hipStream_t stream);
+int x2i_launch_proj_conv5x5_pack(const float* w, void* table, int C, hipStream_t stream);
+int x2i_launch_proj_conv5x5_packed(const void* x, const void* table, const float* bias, void* y, int B, int C, int S, int H,
+                                   hipStream_t stream);
 int x2i_launch_layer_mean(const void* x, const float* scale, void* y, int B, int C, long long plane, hipStream_t stream);
 int x2i_launch_seq_mean(const float* x, float* y, int B, int S, int N, hipStream_t stream);
 int x2i_launch_softmax_rows(void* x, long long rows, int cols, float scale, hipStream_t stream);

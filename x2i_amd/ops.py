@@ -206,6 +206,29 @@ def proj_conv5x5(x, w, bias, out=None):
     return out
 
 
+def proj_conv5x5_pack(w):
+    """f32 taps [C,25] -> banded-Toeplitz MFMA fragments, bf16 [C,5,64,8] (include/x2i.h: x2i_proj_conv5x5_pack)."""
+    lib = _lib.load()
+    _req(w, torch.float32, "w")
+    Cc = w.shape[0]
+    table = torch.empty((Cc, 5, 64, 8), device=w.device, dtype=torch.bfloat16)
+    check(lib.x2i_proj_conv5x5_pack(_p(w), _p(table), Cc, _stream()), "proj_conv5x5_pack")
+    return table
+
+
+def proj_conv5x5_packed(x, table, bias, out=None):
+    """Conv2d(C->1, 5, pad 2) over the (S,H) plane on the matrix cores (x2i_proj_conv5x5_packed_bf16)."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    _req(table, torch.bfloat16, "table")
+    B, Cc, S, H = x.shape
+    if tuple(table.shape) != (Cc, 5, 64, 8):
+        raise ValueError(f"proj_conv5x5_packed: table {tuple(table.shape)} does not match C={Cc}")
+    out = torch.empty((B, S, H), device=x.device, dtype=torch.bfloat16) if out is None else out
+    check(lib.x2i_proj_conv5x5_packed_bf16(_p(x), _p(table), _p(bias), _p(out), B, Cc, S, H, _stream()), "proj_conv5x5_packed")
+    return out
+
+
 def proj_layer_mean(x, scale, out=None):
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")

@@ -23,6 +23,19 @@ def _param(*shape, device, dtype):
     return nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
 
 
+def _conv5x5(mod, x):
+    """Conv2d(C->1, 5, pad 2) of `mod.conv` over the (S,H) plane on the matrix cores.  The banded-Toeplitz fragment table is packed
+    once per weight value (cache keyed on the parameter's version counter / storage / device, like the packed VAE weights)."""
+    w, b = mod.conv.weight, mod.conv.bias
+    key = (w._version, w.data_ptr(), b._version, b.data_ptr(), str(w.device))
+    cache = mod.__dict__.get("_conv5x5_cache")
+    if cache is None or cache[0] != key:
+        C = w.shape[1]
+        cache = (key, ops.proj_conv5x5_pack(w.detach().float().reshape(C, 25).contiguous()), b.detach().float().contiguous())
+        mod.__dict__["_conv5x5_cache"] = cache
+    return ops.proj_conv5x5_packed(x, cache[1], cache[2])
+
+
 class _LN(nn.Module):
     def __init__(self, dim, device, dtype):
         super().__init__()
@@ -105,7 +118,7 @@ class Proj7Exp(nn.Module):
         if self.use_scale:
             x = ops.proj_layer_mean(x, self.cha_scale.float().reshape(-1).contiguous())  # :66-67
         elif self.use_cnn:
-            x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())  # :68-69
+            x = _conv5x5(self, x)  # :68-69
         else:
             x = ops.proj_layer_mean(x, None)  # :70-71
         return self.mlp(x)  # :72
@@ -230,7 +243,7 @@ class ProjFrontStage(nn.Module):
     def forward(self, x):
         B, C, S, H = x.shape
         x = ops.ln_affine(x.to(torch.bfloat16).contiguous(), self.norm0.weight, self.norm0.bias, self.eps)
-        x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())
+        x = _conv5x5(self, x)
         return ops.ln_affine(x, self.norm1.weight, self.norm1.bias, self.eps)
 
 
@@ -266,7 +279,7 @@ class _ProjT5(nn.Module):
     def _front(self, x):
         B, C, S, H = x.shape
         x = ops.ln_affine(x.to(torch.bfloat16).contiguous(), self.norm0.weight, self.norm0.bias, self.eps)          # :163 / :207
-        x = ops.proj_conv5x5(x, self.conv.weight.float().reshape(C, 25).contiguous(), self.conv.bias.float())       # :164 / :208
+        x = _conv5x5(self, x)       # :164 / :208
         return ops.ln_affine(x, self.norm1.weight, self.norm1.bias, self.eps)                                       # :165 / :209
 
     @torch.no_grad()
