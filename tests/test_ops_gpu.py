@@ -184,7 +184,7 @@ def test_attention_forced_rescale_branch(ops):
     assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8])
 @pytest.mark.parametrize("B,H,S,S0", [(1, 1, 64, 0), (2, 2, 136, 40), (1, 2, 1152, 128), (1, 3, 700, 100), (2, 1, 2000, 0)])
 def test_attention_kernel_forms(ops, opt, variant, B, H, S, S0):
     """attn_variant 4 = the 4-wave kernel, 5 / 6 = the 8-wave ping-pong kernel (attention_pp.hip) with / without defer-max, on

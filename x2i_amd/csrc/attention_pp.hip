@@ -37,13 +37,45 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte
 struct LaneGeo {
   int k_row_off, k_swz, v_row_off, v_swz, hi;
 };
-template <bool HAS_PV, bool HAS_QK>
+// fragment address of pipeline step `step` (0-3: V^T rows for O^T += V^T P^T, 4-7: K rows for S^T = K Q^T), fragment j
+__device__ __forceinline__ bf16x8_t load_frag(const char* kb, const char* vb, const LaneGeo& L, int step, int j) {
+  if (step < 4) {
+    const int u = step >> 1, kt = step & 1;
+    return *(const bf16x8_t*)(vb + j * 32 * 128 + L.v_row_off + (((4 * u + 2 * kt + L.hi) ^ L.v_swz) << 4));
+  }
+  const int ds = 2 * (step - 4) + (j >> 1), u = j & 1;
+  return *(const bf16x8_t*)(kb + u * 32 * 256 + L.k_row_off + (((ds * 2 + L.hi) ^ L.k_swz) << 4));
+}
+
+// SCH 2, end of the vector phase S(t): start this wave's share of K(t+3) / V(t+2), then read the first fragments of the
+// NEXT matrix phase (three steps of PV(t): V^T(t), visible to everyone since two barriers ago) into the idle fragment ring -- M(t+1) then starts
+// with its operands in registers instead of paying one LDS round trip per phase with the matrix pipe idle (its SIMD partner is in its
+// vector phase and cannot fill the bubble).  One function with __restrict__ regions: see matrix_phase.
+__device__ __forceinline__ void stage_and_prefetch(const char* __restrict__ vb_next, char* __restrict__ kdst, char* __restrict__ vdst,
+                                                   __amdgpu_buffer_rsrc_t k_rsrc, __amdgpu_buffer_rsrc_t v_rsrc, uint32_t kg, uint32_t vg,
+                                                   bool issue_k, bool issue_v, const int (&k_src)[2], const int (&v_src)[2], int wave,
+                                                   const LaneGeo& L, bf16x8_t (&fr)[3][4]) {
+  if (issue_k) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(k_rsrc, kg + (uint32_t)k_src[j] * 2, kdst + (j * NTH + wave * 64) * 16);
+  }
+  if (issue_v) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(v_rsrc, vg + (uint32_t)v_src[j] * 2, vdst + (j * NTH + wave * 64) * 16);
+  }
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fr[st][j] = load_frag(nullptr, vb_next, L, st, j);
+}
+
+template <bool HAS_PV, bool HAS_QK, bool PRE = false>
 __device__ __forceinline__ void matrix_phase(const char* __restrict__ kb, const char* __restrict__ vb, char* __restrict__ kdst,
                                              char* __restrict__ vdst, __amdgpu_buffer_rsrc_t k_rsrc, __amdgpu_buffer_rsrc_t v_rsrc,
                                              uint32_t kg, uint32_t vg, bool issue_k, bool issue_v, const int (&k_src)[2],
                                              const int (&v_src)[2], int wave,
                                              const LaneGeo& L, const bf16x8_t (&qf)[8], const bf16x8_t (&pf)[2][2], f32x16_t (&sacc)[2],
-                                             f32x16_t (&oacc)[4]) {
+                                             f32x16_t (&oacc)[4], bf16x8_t (&fr)[3][4]) {
   if (issue_k) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) dma16(k_rsrc, kg + (uint32_t)k_src[j] * 2, kdst + (j * NTH + wave * 64) * 16);
@@ -58,40 +90,54 @@ __device__ __forceinline__ void matrix_phase(const char* __restrict__ kb, const 
   // SIMD partner is in its vector phase and cannot fill an LDS-latency bubble with MFMAs of its own, so the latency has to be
   // covered inside this stream.
   constexpr int FIRST = HAS_PV ? 0 : 4, LAST = HAS_QK ? 8 : 4, LEAD = 2;
-  bf16x8_t fr[3][4];
-  auto load = [&](int step, int j) {
-    if (step < 4) {
-      const int u = step >> 1, kt = step & 1;
-      return *(const bf16x8_t*)(vb + j * 32 * 128 + L.v_row_off + (((4 * u + 2 * kt + L.hi) ^ L.v_swz) << 4));
-    }
-    const int ds = 2 * (step - 4) + (j >> 1), u = j & 1;
-    return *(const bf16x8_t*)(kb + u * 32 * 256 + L.k_row_off + (((ds * 2 + L.hi) ^ L.k_swz) << 4));
-  };
+  static_assert(!PRE || HAS_PV, "prefetched fragments are those of steps 0 and 1");
+  auto load = [&](int step, int j) { return load_frag(kb, vb, L, step, j); };
   if constexpr (HAS_QK) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
   }
+  if constexpr (!PRE) {
 #pragma unroll
-  for (int st = FIRST; st < FIRST + LEAD && st < LAST; ++st)
+    for (int st = FIRST; st < FIRST + LEAD && st < LAST; ++st)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fr[st % 3][j] = load(st, j);
+      for (int j = 0; j < 4; ++j) fr[st % 3][j] = load(st, j);
+  }
+  if constexpr (PRE) {
+    // the ring arrives full (steps 0-2, read during the vector phase): use a step, then refill its slot with step st + 3 -- no read is
+    // issued in front of the first MFMA, so the wait hipcc puts there (lgkmcnt(0)) finds everything landed
 #pragma unroll
-  for (int st = FIRST; st < LAST; ++st) {
-    if (st + LEAD < LAST) {
+    for (int st = 0; st < LAST; ++st) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fr[(st + LEAD) % 3][j] = load(st + LEAD, j);
+      for (int j = 0; j < 4; ++j) {
+        if (st < 4) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], pf[st >> 1][st & 1], oacc[j], 0, 0, 0);
+        else sacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], qf[2 * (st - 4) + (j >> 1)], sacc[j & 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 3 < LAST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fr[st % 3][j] = load(st + 3, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // sched_barrier pins "reads of step st + LEAD, then MFMAs of step st": left to itself (or to sched_group_barrier hints) hipcc
-    // sinks every ds_read to just in front of its MFMA and waits lgkmcnt(0) for it -- the whole LDS latency exposed 32 times a phase
-    __builtin_amdgcn_sched_barrier(0);
+  } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (st < 4) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], pf[st >> 1][st & 1], oacc[j], 0, 0, 0);
-      else sacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], qf[2 * (st - 4) + (j >> 1)], sacc[j & 1], 0, 0, 0);
+    for (int st = FIRST; st < LAST; ++st) {
+      if (st + LEAD < LAST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fr[(st + LEAD) % 3][j] = load(st + LEAD, j);
+      }
+      // sched_barrier pins "reads of step st + LEAD, then MFMAs of step st": left to itself (or to sched_group_barrier hints) hipcc
+      // sinks every ds_read to just in front of its MFMA and waits lgkmcnt(0) for it -- the whole LDS latency exposed 32 times a phase
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (st < 4) oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], pf[st >> 1][st & 1], oacc[j], 0, 0, 0);
+        else sacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st % 3][j], qf[2 * (st - 4) + (j >> 1)], sacc[j & 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -164,7 +210,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
   bf16x8_t pf[2][2] = {};
   float m_run = NEG_BIG, l_run = 0.f;
   const int nt = (S + KVB - 1) / KVB;
-  constexpr int NB = SCH ? 3 : 2;
+  constexpr int NB = SCH == 2 ? 4 : SCH == 1 ? 3 : 2;
+  bf16x8_t fr[3][4];  // fragment ring of the matrix phase (SCH 2: steps 0-1 of the next phase are read at the end of the vector phase)
   char* const kbuf = smem;
   char* const vbuf = smem + NB * KTILE;
 
@@ -229,11 +276,15 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
       matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value>(
           kbuf + (t & 1) * KTILE, vbuf + ((t + 1) & 1) * VTILE, kbuf + ((t + 1) & 1) * KTILE, vbuf + (t & 1) * VTILE,
           k_rsrc, v_rsrc, (uint32_t)(t + 1) * (KVB * 128 * 2), (uint32_t)t * (KVB * 2), t + 1 < nt, t < nt, k_src, v_src, wave, L, qf, pf,
-          sacc, oacc);
-    } else {
+          sacc, oacc, fr);
+    } else if constexpr (SCH == 1) {
       matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value>(
           kbuf + (t % 3) * KTILE, vbuf + ((t + 2) % 3) * VTILE, nullptr, nullptr, k_rsrc, v_rsrc, 0u, 0u, false, false, k_src, v_src, wave, L,
-          qf, pf, sacc, oacc);
+          qf, pf, sacc, oacc, fr);
+    } else {
+      matrix_phase<decltype(has_pv)::value, decltype(has_qk)::value, decltype(has_pv)::value>(
+          kbuf + (t & 3) * KTILE, vbuf + ((t + 3) & 3) * VTILE, nullptr, nullptr, k_rsrc, v_rsrc, 0u, 0u, false, false, k_src, v_src, wave, L,
+          qf, pf, sacc, oacc, fr);
     }
   };
   // SCH 1: the vector phase S(t) starts this wave's share of K(t+2) and V(t+1); returns how many DMA pieces it issued
@@ -255,6 +306,17 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
     }
     return n;
   };
+  // SCH 2: end of S(t) -- K(t+3) / V(t+2) into the four-deep rings and the first fragments of M(t+1) (V^T(t)) into `fr`
+  auto stage_tail = [&](int t) {
+    int n = 0;
+    if constexpr (SCH == 2) {
+      const bool ik = t + 3 < nt, iv = t + 2 < nt;
+      stage_and_prefetch(vbuf + (t & 3) * VTILE, kbuf + ((t + 3) & 3) * KTILE, vbuf + ((t + 2) & 3) * VTILE, k_rsrc, v_rsrc,
+                         (uint32_t)(t + 3) * (KVB * 128 * 2), (uint32_t)(t + 2) * (KVB * 2), ik, iv, k_src, v_src, wave, L, fr);
+      n = (ik ? 2 : 0) + (iv ? 2 : 0);
+    }
+    return n;
+  };
   // group A's wait at the end of S(t): everything but the `keep` pieces just issued must have landed (SCH 0: keep = 0)
   auto barrier_keep = [&](bool wait_dma, int keep) {
     if (wait_dma) {
@@ -271,13 +333,20 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
   // prologue: K(0) visible to everyone; group B then falls one phase behind group A
 #pragma unroll
   for (int j = 0; j < 2; ++j) dma16(k_rsrc, (uint32_t)k_src[j] * 2, kbuf + (j * NTH + wave * 64) * 16);
-  if constexpr (SCH == 1) {  // K(1) and V(0) as well: the rings run two tiles (K) / one tile (V) ahead of the matrix phases
-    if (nt > 1) {
+  if constexpr (SCH >= 1) {  // K(1) and V(0) as well (SCH 2: also K(2), V(1)): the rings run ahead of the matrix phases
 #pragma unroll
-      for (int j = 0; j < 2; ++j) dma16(k_rsrc, (uint32_t)(KVB * 128 * 2) + (uint32_t)k_src[j] * 2, kbuf + KTILE + (j * NTH + wave * 64) * 16);
-    }
+    for (int a = 1; a <= SCH; ++a)
+      if (a < nt) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(v_rsrc, (uint32_t)v_src[j] * 2, vbuf + (j * NTH + wave * 64) * 16);
+        for (int j = 0; j < 2; ++j)
+          dma16(k_rsrc, (uint32_t)a * (KVB * 128 * 2) + (uint32_t)k_src[j] * 2, kbuf + a * KTILE + (j * NTH + wave * 64) * 16);
+      }
+#pragma unroll
+    for (int a = 0; a < SCH; ++a)
+      if (a < nt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(v_rsrc, (uint32_t)a * (KVB * 2) + (uint32_t)v_src[j] * 2, vbuf + a * VTILE + (j * NTH + wave * 64) * 16);
+      }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -294,12 +363,14 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
   keep = stage_ahead(0);
   if (nt == 1) softmax(0, std::true_type{});
   else softmax(0, std::false_type{});
+  keep += stage_tail(0);
   barrier_keep(grp == 0, keep);
   for (int t = 1; t < nt - 1; ++t) {  // steady state: every key valid, every piece present
     M(t, std::true_type{}, std::true_type{});
     barrier(grp == 1);
     keep = stage_ahead(t);
     softmax(t, std::false_type{});
+    keep += stage_tail(t);
     barrier_keep(grp == 0, keep);
   }
   if (nt > 1) {
@@ -307,6 +378,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
     barrier(grp == 1);
     keep = stage_ahead(nt - 1);
     softmax(nt - 1, std::true_type{});
+    keep += stage_tail(nt - 1);
     barrier_keep(grp == 0, keep);
   }
   M(nt, std::true_type{}, std::false_type{});  // PV(nt-1); nothing left to stage
@@ -356,13 +428,23 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                             long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr) {
   if (!out8 && ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7))) return X2I_ERR_STATE;  // 16-byte row stores only
-  const int sch = x2i_options().attn_variant == 7 ? 1 : 0;
-  const size_t shm = (sch ? 3 : 2) * (KTILE + VTILE);
+  const int var = x2i_options().attn_variant;
+  // schedule: 2 (four-deep rings, fragment prefetch in the vector phase; +2 % measured) for the bf16 / defer-max launches unless an
+  // A/B variant asks otherwise (5 = schedule 0, 7 = schedule 1); the e4m3-output and THR = 0 instantiations stay on schedule 0
+  const int sch = var == 7 ? 1 : (var == 8 || (var != 5 && var != 6 && !out8 && thr != 0)) ? 2 : 0;
+  const size_t shm = (sch == 2 ? 4 : sch ? 3 : 2) * (KTILE + VTILE);
   dim3 grid(((S + 255) / 256) * H * B);
-  if (sch && !out8) {
+  if (sch == 1 && !out8) {
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 1>, (int)shm);
     if (rc_) return rc_;
     hipLaunchKernelGGL((attn_pp_kernel<8, false, 1>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
+                       (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
+    return x2i_check_launch("attention");
+  }
+  if (sch == 2 && !out8) {
+    const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 2>, (int)shm);
+    if (rc_) return rc_;
+    hipLaunchKernelGGL((attn_pp_kernel<8, false, 2>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
                        (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
     return x2i_check_launch("attention");
   }
