@@ -264,6 +264,51 @@ int x2i_softmax_rows_bf16(void* x, int64_t rows, int32_t cols, float scale, x2i_
 int x2i_cast_f32_to_bf16(const float* x, void* y, int64_t n, x2i_stream_t stream);
 int x2i_cast_bf16_to_f32(const void* x, float* y, int64_t n, x2i_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * N4 -- backward pass of the attention-distillation step (train/train_qwenvl.py:556-654: `loss.backward()` with only the
+ * projector trainable).  The transformer is frozen, so its backward is an ACTIVATION-gradient chain: every matrix product is
+ * x2i_gemm_bf16 on a transposed operand (x2i_transpose_bf16), and the entry points below are the row kernels around them
+ * (csrc/train.hip).  Column sums (d scale / d shift / d gate / d weight / d bias) are two-stage: a kernel writes per-wave partial
+ * rows into a caller-provided f32 scratch, x2i_reduce_rows_f32 finishes -- no atomics, results independent of scheduling.
+ * All tensors bf16 unless typed float; rows must be 16-byte aligned, column counts multiples of 8 (<= 4096 for the row kernels). */
+/* out[z][c][r] = in[z][r][c] */
+int x2i_transpose_bf16(const void* in, int64_t in_batch_stride, int64_t ld_in, void* out, int64_t out_batch_stride, int64_t ld_out,
+                       int32_t batch, int32_t R, int32_t C, x2i_stream_t stream);
+/* x [nz][Rt][ld]: P = softmax(scale * x) over the Cv valid columns of the Rv valid rows, in place; padding up to (Rt, Ct) becomes 0 */
+int x2i_softmax_pad_bf16(void* x, int64_t ld, int32_t nz, int32_t Rt, int32_t Rv, int32_t Ct, int32_t Cv, float scale, x2i_stream_t stream);
+/* dP <- scale * P * (dP - rowsum(P * dP)), same padding rules */
+int x2i_softmax_bwd_bf16(const void* P, void* dP, int64_t ld, int32_t nz, int32_t Rt, int32_t Rv, int32_t Ct, int32_t Cv, float scale,
+                         x2i_stream_t stream);
+/* backward of y = LayerNorm_noaffine(x) * mult + shift over S rows per sample: dXout = (dXin ? dXin : 0) + dx;
+ * mult_is_scale: mult = 1 + mult_ptr[b][col] (AdaLN scale, f32, batch stride mult_bs) else mult = mult_ptr[col] (affine weight as f32).
+ * partial: f32 [B][ceil(S / rows_per_wave)][2][D]: [0] = sum dy * xhat (-> d scale / d weight), [1] = sum dy (-> d shift / d bias) */
+int x2i_ln_mod_bwd_bf16(const void* X, int64_t x_bs, int32_t ldx, const void* dY, int64_t dy_bs, int32_t ldy, const float* mult, int64_t mult_bs,
+                        int32_t mult_is_scale, const void* dXin, void* dXout, int64_t dx_bs, int32_t lddx, int32_t B, int32_t S, int32_t D,
+                        int32_t rows_per_wave, float* partial, float eps, x2i_stream_t stream);
+/* backward of x + gate[b][:] * t: dT = gate * dX (+ G, a gradient injected at t; may be NULL); partial f32 [B][ceil(S/R)][D] = sum dX * T
+ * (-> d gate).  gate == NULL: dT = dX (+ G), no partials. */
+int x2i_gate_bwd_bf16(const void* dX, int64_t dx_bs, int32_t lddx, const void* T, int64_t t_bs, int32_t ldt, const float* gate, int64_t gate_bs,
+                      const void* G, int64_t g_bs, int32_t ldg, void* dT, int64_t dt_bs, int32_t lddt, int32_t B, int32_t S, int32_t D,
+                      int32_t rows_per_wave, float* partial, x2i_stream_t stream);
+/* out[z][i] = (accumulate ? out[z][i] : 0) + alpha * sum_{p < np} in[z * in_z_stride + p * in_p_stride + i] */
+int x2i_reduce_rows_f32(const float* in, int64_t in_z_stride, int32_t np, int64_t in_p_stride, float* out, int64_t out_z_stride, int32_t nz,
+                        int32_t len, int32_t accumulate, float alpha, x2i_stream_t stream);
+/* dA <- dA * act'(pre) (X2I_ACT_GELU_TANH / GELU_ERF / SILU); bf16 matrices with row strides, or contiguous f32 (is_f32) */
+int x2i_act_bwd(void* dA, int64_t ldd, const void* pre, int64_t ldp, int64_t rows, int32_t cols, int32_t act, int32_t is_f32, x2i_stream_t stream);
+/* backward of x2i_qkv_split_bf16: dQ / dK / dV bf16 [B,H,Spad,128] (dV row-major per head) -> d(q|k|v) rows, from the saved pre-norm rows */
+int x2i_qkv_split_bwd_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t ld1, void* d0, void* d1, int32_t ldd0, int32_t ldd1, int32_t B,
+                           int32_t S, int32_t S0, int32_t H, const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cosp,
+                           const float* sinp, const void* dQ, const void* dK, const void* dV, int32_t Spad, float eps, x2i_stream_t stream);
+/* dx[b][:] = sum_n dy[b][n] * W[n][:] (B <= 8): partial f32 [ceil(N / chunk)][B][K], finished by x2i_reduce_rows_f32 */
+int x2i_skinny_linear_bwd(const float* dy, int64_t dy_bs, const void* W, int32_t ldw, float* partial, int32_t B, int32_t N, int32_t K,
+                          int32_t chunk, x2i_stream_t stream);
+/* distillation loss rows (:58-61, :613-634): row_loss[r] = KL(softmax(normalize(student_r)/T) vs softmax(normalize(teacher_r)/T)) as
+ * F.kl_div(q.log(), p) sums it; grad (may be NULL) = loss_scale * d row_loss / d student */
+int x2i_kd_loss_bf16(const void* teacher, int64_t ldt, const void* student, int64_t lds, void* grad, int64_t ldg, float* row_loss, int64_t rows,
+                     int32_t D, float temperature, float loss_scale, x2i_stream_t stream);
+/* g[0..n) <- 0 when *term is NaN / Inf (the reference skips non-finite per-block loss terms, :617-620); no host synchronisation */
+int x2i_zero_if_nonfinite_bf16(void* g, int64_t n, const float* term, x2i_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,18 @@ SIGNATURES = {
     "x2i_euler_step_bf16": [_vp, _vp, _i64, _vp, _vp],
     "x2i_proj_conv5x5_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_proj_conv5x5_pack": [_vp, _vp, _i32, _vp],
+    "x2i_transpose_bf16": [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "x2i_softmax_pad_bf16": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "x2i_softmax_bwd_bf16": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "x2i_ln_mod_bwd_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _vp],
+    "x2i_gate_bwd_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "x2i_reduce_rows_f32": [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp],
+    "x2i_act_bwd": [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "x2i_qkv_split_bwd_bf16": [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i32, _f32, _vp],
+    "x2i_skinny_linear_bwd": [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "x2i_kd_loss_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp],
+    "x2i_zero_if_nonfinite_bf16": [_vp, _i64, _vp, _vp],
     "x2i_proj_conv5x5_packed_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_proj_layer_mean_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _vp],
     "x2i_seq_mean_f32": [_vp, _vp, _i32, _i32, _i32, _vp],

@@ -248,4 +248,53 @@ int x2i_cast_bf16_to_f32(const void* x, float* y, int64_t n, x2i_stream_t stream
   return x2i_launch_cast_bf16_f32(x, y, n, (hipStream_t)stream);
 }
 
+/* ---- N4: backward kernels of the attention-distillation step (train.hip) */
+int x2i_transpose_bf16(const void* in, int64_t in_batch_stride, int64_t ld_in, void* out, int64_t out_batch_stride, int64_t ld_out,
+                       int32_t batch, int32_t R, int32_t C, x2i_stream_t stream) {
+  return x2i_launch_transpose(in, in_batch_stride, ld_in, out, out_batch_stride, ld_out, batch, R, C, (hipStream_t)stream);
+}
+int x2i_softmax_pad_bf16(void* x, int64_t ld, int32_t nz, int32_t Rt, int32_t Rv, int32_t Ct, int32_t Cv, float scale, x2i_stream_t stream) {
+  return x2i_launch_softmax_pad(x, ld, nz, Rt, Rv, Ct, Cv, scale, (hipStream_t)stream);
+}
+int x2i_softmax_bwd_bf16(const void* P, void* dP, int64_t ld, int32_t nz, int32_t Rt, int32_t Rv, int32_t Ct, int32_t Cv, float scale,
+                         x2i_stream_t stream) {
+  return x2i_launch_softmax_bwd(P, dP, ld, nz, Rt, Rv, Ct, Cv, scale, (hipStream_t)stream);
+}
+int x2i_ln_mod_bwd_bf16(const void* X, int64_t x_bs, int32_t ldx, const void* dY, int64_t dy_bs, int32_t ldy, const float* mult, int64_t mult_bs,
+                        int32_t mult_is_scale, const void* dXin, void* dXout, int64_t dx_bs, int32_t lddx, int32_t B, int32_t S, int32_t D,
+                        int32_t rows_per_wave, float* partial, float eps, x2i_stream_t stream) {
+  return x2i_launch_ln_mod_bwd(X, x_bs, ldx, dY, dy_bs, ldy, mult, mult_bs, mult_is_scale, dXin, dXout, dx_bs, lddx, B, S, D, rows_per_wave, partial,
+                               eps, (hipStream_t)stream);
+}
+int x2i_gate_bwd_bf16(const void* dX, int64_t dx_bs, int32_t lddx, const void* T, int64_t t_bs, int32_t ldt, const float* gate, int64_t gate_bs,
+                      const void* G, int64_t g_bs, int32_t ldg, void* dT, int64_t dt_bs, int32_t lddt, int32_t B, int32_t S, int32_t D,
+                      int32_t rows_per_wave, float* partial, x2i_stream_t stream) {
+  return x2i_launch_gate_bwd(dX, dx_bs, lddx, T, t_bs, ldt, gate, gate_bs, G, g_bs, ldg, dT, dt_bs, lddt, B, S, D, rows_per_wave, partial,
+                             (hipStream_t)stream);
+}
+int x2i_reduce_rows_f32(const float* in, int64_t in_z_stride, int32_t np, int64_t in_p_stride, float* out, int64_t out_z_stride, int32_t nz,
+                        int32_t len, int32_t accumulate, float alpha, x2i_stream_t stream) {
+  return x2i_launch_reduce_rows(in, in_z_stride, np, in_p_stride, out, out_z_stride, nz, len, accumulate, alpha, (hipStream_t)stream);
+}
+int x2i_act_bwd(void* dA, int64_t ldd, const void* pre, int64_t ldp, int64_t rows, int32_t cols, int32_t act, int32_t is_f32, x2i_stream_t stream) {
+  return x2i_launch_act_bwd(dA, ldd, pre, ldp, rows, cols, act, is_f32, (hipStream_t)stream);
+}
+int x2i_qkv_split_bwd_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t ld1, void* d0, void* d1, int32_t ldd0, int32_t ldd1, int32_t B,
+                           int32_t S, int32_t S0, int32_t H, const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cosp,
+                           const float* sinp, const void* dQ, const void* dK, const void* dV, int32_t Spad, float eps, x2i_stream_t stream) {
+  return x2i_launch_qkv_split_bwd(qkv0, qkv1, ld0, ld1, d0, d1, ldd0, ldd1, B, S, S0, H, nq0, nk0, nq1, nk1, cosp, sinp, dQ, dK, dV, Spad, eps,
+                                  (hipStream_t)stream);
+}
+int x2i_skinny_linear_bwd(const float* dy, int64_t dy_bs, const void* W, int32_t ldw, float* partial, int32_t B, int32_t N, int32_t K,
+                          int32_t chunk, x2i_stream_t stream) {
+  return x2i_launch_skinny_bwd(dy, dy_bs, W, ldw, partial, B, N, K, chunk, (hipStream_t)stream);
+}
+int x2i_kd_loss_bf16(const void* teacher, int64_t ldt, const void* student, int64_t lds, void* grad, int64_t ldg, float* row_loss, int64_t rows,
+                     int32_t D, float temperature, float loss_scale, x2i_stream_t stream) {
+  return x2i_launch_kd_loss(teacher, ldt, student, lds, grad, ldg, row_loss, rows, D, temperature, loss_scale, (hipStream_t)stream);
+}
+int x2i_zero_if_nonfinite_bf16(void* g, int64_t n, const float* term, x2i_stream_t stream) {
+  return x2i_launch_zero_if_nonfinite(g, n, term, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -47,3 +47,27 @@ int x2i_launch_seq_mean(const float* x, float* y, int B, int S, int N, hipStream
 int x2i_launch_softmax_rows(void* x, long long rows, int cols, float scale, hipStream_t stream);
 int x2i_launch_cast_f32_bf16(const float* x, void* y, long long n, hipStream_t stream);
 int x2i_launch_cast_bf16_f32(const void* x, float* y, long long n, hipStream_t stream);
+
+/* ---- backward kernels of the attention-distillation step (train.hip) */
+int x2i_launch_transpose(const void* in, long long in_bs, long long ld_in, void* out, long long out_bs, long long ld_out, int batch, int R, int C,
+                         hipStream_t stream);
+int x2i_launch_softmax_pad(void* x, long long ld, int nz, int Rt, int Rv, int Ct, int Cv, float scale, hipStream_t stream);
+int x2i_launch_softmax_bwd(const void* P, void* dP, long long ld, int nz, int Rt, int Rv, int Ct, int Cv, float scale, hipStream_t stream);
+int x2i_launch_ln_mod_bwd(const void* X, long long x_bs, int ldx, const void* dY, long long dy_bs, int ldy, const float* m, long long m_bs,
+                          int mult_is_scale, const void* dXin, void* dXout, long long dx_bs, int lddx, int B, int S, int D, int R,
+                          float* partial, float eps, hipStream_t stream);
+int x2i_launch_gate_bwd(const void* dX, long long dx_bs, int lddx, const void* T, long long t_bs, int ldt, const float* gate, long long g_bs,
+                        const void* G, long long gg_bs, int ldg, void* dT, long long dt_bs, int lddt, int B, int S, int D, int R,
+                        float* partial, hipStream_t stream);
+int x2i_launch_reduce_rows(const float* in, long long in_zs, int np, long long in_ps, float* out, long long out_zs, int nz, int len,
+                           int accumulate, float alpha, hipStream_t stream);
+int x2i_launch_act_bwd(void* dA, long long ldd, const void* pre, long long ldp, long long rows, int cols, int act, int is_f32,
+                       hipStream_t stream);
+int x2i_launch_qkv_split_bwd(const void* qkv0, const void* qkv1, int ld0, int ld1, void* d0, void* d1, int ldd0, int ldd1, int B, int S, int S0,
+                             int H, const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cosp, const float* sinp,
+                             const void* dQ, const void* dK, const void* dV, int Spad, float eps, hipStream_t stream);
+int x2i_launch_skinny_bwd(const float* dy, long long dy_bs, const void* W, int ldw, float* partial, int B, int N, int K, int chunk,
+                          hipStream_t stream);
+int x2i_launch_kd_loss(const void* teacher, long long ldt, const void* student, long long lds, void* grad, long long ldg, float* row_loss,
+                       long long rows, int D, float temperature, float loss_scale, hipStream_t stream);
+int x2i_launch_zero_if_nonfinite(void* g, long long n, const float* term, hipStream_t stream);

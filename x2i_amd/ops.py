@@ -469,3 +469,115 @@ def gated_residual_(X, T, gate, B, S, D, x_bs, ldx, t_bs, ldt, gate_bs, x_offset
     check(lib.x2i_gated_residual_bf16(C.c_void_p(X.data_ptr() + 2 * x_offset), x_bs, ldx, C.c_void_p(T.data_ptr() + 2 * t_offset), t_bs, ldt,
                                       _p(gate), gate_bs, B, S, D, _stream()), "gated_residual")
     return X
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4: backward kernels of the attention-distillation step (include/x2i.h, csrc/train.hip)
+def transpose(x, out=None, *, batch=1, R=None, C=None, in_bs=0, ld_in=None, out_bs=0, ld_out=None, in_offset=0, out_offset=0):
+    """out[z][c][r] = in[z][r][c] (bf16).  Defaults: x is a contiguous [..., R, C] tensor, leading dims are the batch."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    if R is None:
+        R, C = x.shape[-2], x.shape[-1]
+        batch = x.numel() // (R * C)
+        in_bs, ld_in = R * C, C
+    ld_in = C if ld_in is None else ld_in
+    if out is None:
+        out = torch.empty((batch, C, R) if batch > 1 else (C, R), device=x.device, dtype=torch.bfloat16)
+        out_bs, ld_out = C * R, R
+    ld_out = R if ld_out is None else ld_out
+    check(lib.x2i_transpose_bf16(_off(x, in_offset), in_bs, ld_in, _off(out, out_offset),
+                                 out_bs, ld_out, batch, R, C, _stream()), "transpose")
+    return out
+
+
+def _off(t, elems):
+    return C.c_void_p(t.data_ptr() + elems * t.element_size())
+
+
+def softmax_pad_(x, nz, Rt, Rv, Ct, Cv, scale, ld=None):
+    check(_lib.load().x2i_softmax_pad_bf16(_p(x), Ct if ld is None else ld, nz, Rt, Rv, Ct, Cv, float(scale), _stream()), "softmax_pad")
+    return x
+
+
+def softmax_bwd_(P, dP, nz, Rt, Rv, Ct, Cv, scale, ld=None):
+    check(_lib.load().x2i_softmax_bwd_bf16(_p(P), _p(dP), Ct if ld is None else ld, nz, Rt, Rv, Ct, Cv, float(scale), _stream()), "softmax_bwd")
+    return dP
+
+
+def reduce_rows(partial, out, *, np_, len_, nz=1, in_zs=0, in_ps=None, out_zs=0, accumulate=False, alpha=1.0, in_offset=0, out_offset=0):
+    check(_lib.load().x2i_reduce_rows_f32(_off(partial, in_offset), in_zs, np_, len_ if in_ps is None else in_ps, _off(out, out_offset), out_zs, nz,
+                                          len_, 1 if accumulate else 0, float(alpha), _stream()), "reduce_rows")
+    return out
+
+
+def ln_mod_bwd(X, dY, mult, dXin, dXout, partial, *, B, S, D, R, mult_is_scale=True, mult_bs=0, x_bs=None, ldx=None, dy_bs=None, ldy=None,
+               dx_bs=None, lddx=None, x_offset=0, dy_offset=0, dx_offset=0, eps=1e-6):
+    """Backward of LayerNorm(no affine) * mult + shift on S rows per sample; partial f32 [B, ceil(S/R), 2, D]."""
+    ldx = D if ldx is None else ldx
+    ldy = D if ldy is None else ldy
+    lddx = D if lddx is None else lddx
+    x_bs = S * ldx if x_bs is None else x_bs
+    dy_bs = S * ldy if dy_bs is None else dy_bs
+    dx_bs = S * lddx if dx_bs is None else dx_bs
+    check(_lib.load().x2i_ln_mod_bwd_bf16(_off(X, x_offset), x_bs, ldx, _off(dY, dy_offset), dy_bs, ldy, _p(mult), mult_bs,
+                                          1 if mult_is_scale else 0, _off(dXin, dx_offset) if dXin is not None else C.c_void_p(0),
+                                          _off(dXout, dx_offset), dx_bs, lddx, B, S, D, R, _p(partial), float(eps), _stream()), "ln_mod_bwd")
+
+
+def gate_bwd(dX, T, gate, G, dT, partial, *, B, S, D, R, gate_bs=0, dx_bs=None, lddx=None, t_bs=None, ldt=None, g_bs=None, ldg=None,
+             dt_bs=None, lddt=None, dx_offset=0, t_offset=0, g_offset=0, dt_offset=0):
+    """dT = gate * dX (+ G); partial f32 [B, ceil(S/R), D] = sum_rows dX * T."""
+    lddx = D if lddx is None else lddx
+    ldt = D if ldt is None else ldt
+    ldg = D if ldg is None else ldg
+    lddt = D if lddt is None else lddt
+    dx_bs = S * lddx if dx_bs is None else dx_bs
+    t_bs = S * ldt if t_bs is None else t_bs
+    g_bs = S * ldg if g_bs is None else g_bs
+    dt_bs = S * lddt if dt_bs is None else dt_bs
+    check(_lib.load().x2i_gate_bwd_bf16(_off(dX, dx_offset), dx_bs, lddx, _off(T, t_offset) if T is not None else C.c_void_p(0), t_bs, ldt,
+                                        _p(gate), gate_bs, _off(G, g_offset) if G is not None else C.c_void_p(0), g_bs, ldg,
+                                        _off(dT, dt_offset), dt_bs, lddt, B, S, D, R, _p(partial), _stream()), "gate_bwd")
+
+
+def act_bwd_(dA, pre, act, *, rows=None, cols=None, ldd=None, ldp=None, d_offset=0, p_offset=0):
+    """dA <- dA * act'(pre); bf16 strided matrices, or contiguous f32 tensors."""
+    f32 = dA.dtype == torch.float32
+    cols = dA.shape[-1] if cols is None else cols
+    rows = dA.numel() // dA.shape[-1] if rows is None else rows
+    ldd = cols if ldd is None else ldd
+    ldp = cols if ldp is None else ldp
+    check(_lib.load().x2i_act_bwd(_off(dA, d_offset), ldd, _off(pre, p_offset), ldp, rows, cols, act, 1 if f32 else 0, _stream()), "act_bwd")
+    return dA
+
+
+def qkv_split_bwd(qkv0, qkv1, ld0, ld1, d0, d1, ldd0, ldd1, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, dQ, dK, dV, Spad, eps=1e-6):
+    check(_lib.load().x2i_qkv_split_bwd_bf16(_p(qkv0), _p(qkv1), ld0, ld1, _p(d0), _p(d1), ldd0, ldd1, B, S, S0, H, _p(nq0), _p(nk0), _p(nq1),
+                                             _p(nk1), _p(cos), _p(sin), _p(dQ), _p(dK), _p(dV), Spad, float(eps), _stream()), "qkv_split_bwd")
+
+
+def skinny_linear_bwd(dy, W, *, chunk=1024):
+    """dx [B, K] f32 = dy [B, N] f32 @ W [N, K] bf16 (B <= 8): two-stage, deterministic."""
+    lib = _lib.load()
+    _req(dy, torch.float32, "dy")
+    _req(W, torch.bfloat16, "W")
+    B, N = dy.shape
+    K = W.shape[1]
+    nchunk = (N + chunk - 1) // chunk
+    partial = torch.empty((nchunk, B, K), device=dy.device, dtype=torch.float32)
+    check(lib.x2i_skinny_linear_bwd(_p(dy), dy.stride(0), _p(W), W.stride(0), _p(partial), B, N, K, chunk, _stream()), "skinny_linear_bwd")
+    out = torch.empty((B, K), device=dy.device, dtype=torch.float32)
+    reduce_rows(partial, out, np_=nchunk, len_=B * K)
+    return out
+
+
+def kd_loss_rows(teacher, student, grad, row_loss, *, rows, D, temperature, loss_scale, ldt=None, lds=None, ldg=None):
+    check(_lib.load().x2i_kd_loss_bf16(_p(teacher), D if ldt is None else ldt, _p(student), D if lds is None else lds, _p(grad),
+                                       D if ldg is None else ldg, _p(row_loss), rows, D, float(temperature), float(loss_scale), _stream()),
+          "kd_loss")
+
+
+def zero_if_nonfinite_(g, term):
+    check(_lib.load().x2i_zero_if_nonfinite_bf16(_p(g), g.numel(), _p(term), _stream()), "zero_if_nonfinite")
+    return g

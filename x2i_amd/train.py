@@ -1,0 +1,372 @@
+"""Attention-distillation training step on the HIP path (reference train/train_qwenvl.py:556-654).
+
+The reference trains ONLY the projector: `loss.backward()` runs back through the frozen student transformer into
+`prompt_embeds_zh` / `add_text_embeds` (train/train_qwenvl.py:577-590,626).  So the transformer's backward is an activation-gradient
+chain -- no weight gradients -- and that is what `DistillBackward` implements:
+
+  forward_train()   the transformer forward with every activation the chain needs kept (block inputs, pre-norm q|k|v rows, attention
+                    projections, pre-GELU rows, feed-forward outputs); at every `block.attn` tap the distillation loss of that tap
+                    (x2i_kd_loss_bf16) is evaluated against the teacher's tensor and its gradient stored -- the taps themselves are
+                    not kept;
+  backward()        57 blocks in reverse: gated-residual, GELU, LayerNorm+modulate, q/k RMSNorm + RoPE and attention backward, every
+                    matrix product a launch of the forward MFMA GEMM on a transposed operand.  Attention backward recomputes
+                    P = softmax(QK^T) per sample with explicit [H, S, S] matrices (5 GEMMs + 2 row kernels + 3 transposes) -- correct and
+                    deterministic, HBM-bound rather than flash-style (the fused form is the next optimisation);
+                    returns d loss / d encoder_hidden_states and d loss / d pooled_projections.
+
+`ProjectorTrainer` (below) is the other half: the projector's forward with saves, its backward (weight gradients), gradient
+clipping and AdamW, and `distill_step` strings the reference's step together.  Everything numeric runs in the C-ABI library; torch
+is storage and launch order.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_SILU
+
+
+def _gcd_rows(*ns):
+    g = 32
+    for n in ns:
+        if n:
+            g = math.gcd(g, n)
+    return max(g, 1)
+
+
+class DistillBackward:
+    """Activation-gradient chain of a frozen x2i_amd FluxTransformer2DModel (see the module docstring)."""
+
+    def __init__(self, model):
+        self.m = model
+        self.WT = {}
+        self.saved = None
+
+    # ------------------------------------------------------------------ frozen weights, transposed once
+    @torch.no_grad()
+    def _wt(self, key, rows=None):
+        """W^T of fused weight `key` (optionally of its row slice): the B operand of dX = dY W as the GEMM wants it ([K_in, N_out])."""
+        k = (key, rows)
+        t = self.WT.get(k)
+        if t is None:
+            w = self.m._fused[key]
+            if rows is not None:
+                w = w[rows[0]:rows[1]]
+            t = ops.transpose(w.contiguous())
+            self.WT[k] = t
+        return t
+
+    # ------------------------------------------------------------------ forward with saves
+    @torch.no_grad()
+    def forward_train(self, state, hidden_states, timestep, teacher=None, tap_grads=None, temperature=3.0):
+        """One transformer evaluation (prepared conditioning `state` as in FluxTransformer2DModel.denoise) that keeps what backward()
+        needs.  Exactly one of
+          teacher   = three stacked tensors / lists [(B, 19, Si, D), (B, 19, St, D), (B, 38, S, D)] as the reference's batch holds them
+                      (KD_teacher_tensor0/1/2, train/train_qwenvl.py:570-572): the loss is evaluated tap by tap, or
+          tap_grads = three lists of explicit gradients with the taps' shapes (tests, other losses)
+        may be given.  Returns (noise_pred, loss) with loss a device f32 scalar (0 when tap_grads is used)."""
+        m = self.m
+        cfg, f, ws = m.config, m._fused, state["ws"]
+        B, St, Si = state["B"], state["St"], state["Si"]
+        S, Spad = ws["S"], ws["Spad"]
+        D, H = m.inner_dim, m._H
+        if S % 8:
+            raise ValueError("forward_train: the joint sequence length must be a multiple of 8")
+        dev = m.device
+        X, NRM, QKV, Q, K, VT, ATT, CAT, MOD = (ws[k] for k in ("X", "NRM", "QKV", "Q", "K", "VT", "ATT", "CAT", "MOD"))
+        Ntot = m._mod_rows
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        hs = hidden_states.to(device=dev, dtype=torch.bfloat16).contiguous()
+        X[:, :St].copy_(state["ctx"])
+        ops.gemm(hs, f["x_embedder.w"], f["x_embedder.b"], out=X, M=Si, batch=B, a_batch_stride=Si * cfg.in_channels, lda=cfg.in_channels,
+                 c_batch_stride=S * D, ldc=D, c_offset=St * D)
+        t1000 = (timestep.to(device=dev, dtype=hidden_states.dtype) * 1000).float().contiguous()
+        tp = ops.timestep_sinusoid(t1000, 256, round_bf16=state["round_bf16"])
+        h1 = ops.skinny_linear(tp, f["tte.timestep_embedder.1.w"], f["tte.timestep_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
+        temb = torch.empty((B, D), device=dev, dtype=torch.float32)
+        temb.copy_(state["cond"])
+        ops.skinny_linear(h1, f["tte.timestep_embedder.2.w"], f["tte.timestep_embedder.2.b"], out=temb, accumulate=True)
+        ops.skinny_linear(temb, f["mod.w"], f["mod.b"], out=MOD, act_in=ACT_SILU)
+        cos, sin = state["cos"], state["sin"]
+        scale = 1.0 / math.sqrt(128.0)
+
+        def mod(off):
+            return MOD[:, off:]
+
+        loss_terms = []
+        row_loss = torch.empty((B * S,), device=dev, dtype=torch.float32)
+
+        def tap(kind, i, tensor, rows, ld, offset_rows=0):
+            """gradient injected at a tap: explicit, or d(loss term) / d(tap) from the teacher's tensor; `tensor` rows = [B][rows][D] with
+            row stride ld inside a [B, S or rows, *] buffer"""
+            if tap_grads is not None:
+                return tap_grads[kind][i].to(**bf).contiguous()
+            if teacher is None:
+                return None
+            t_all = teacher[kind]
+            t = (t_all[i] if isinstance(t_all, (list, tuple)) else t_all[:, i]).to(**bf).contiguous()  # [B, rows, D]
+            g = torch.empty((B, rows, D), **bf)
+            term = torch.zeros((1,), device=dev, dtype=torch.float32)
+            # F.kl_div(..., reduction='batchmean') divides the summed rows by B (:616); one launch per sample keeps the strides simple
+            for b in range(B):
+                ops.kd_loss_rows(t[b], tensor[b, offset_rows:offset_rows + rows], g[b], row_loss[b * rows:], rows=rows, D=D,
+                                 temperature=temperature, loss_scale=1.0 / B, ldt=D, lds=ld, ldg=D)
+            ops.reduce_rows(row_loss, term, np_=B * rows, len_=1, in_ps=1, alpha=1.0 / B)
+            ops.zero_if_nonfinite_(g, term)
+            loss_terms.append(term)
+            return g
+
+        saved = dict(state=state, B=B, St=St, Si=Si, S=S, Spad=Spad, temb=temb, MOD=MOD.clone(), double=[], single=[])
+        qkv_img_off = B * St * 3 * D
+        for i in range(cfg.num_layers):
+            p = f"d{i}"
+            oi = i * 12 * D
+            oc = oi + 6 * D
+            sv = dict(Xin=X.clone())
+            ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
+            qkv = torch.empty((B * S, 3 * D), **bf)
+            ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=qkv, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                     c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
+            ops.gemm(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], out=qkv, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=St * 3 * D,
+                     ldc=3 * D)
+            ops.qkv_split(qkv, qkv.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
+                          f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
+            ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
+            OP = torch.empty((B, S, D), **bf)
+            ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=OP, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
+            ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=OP, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                     c_batch_stride=S * D, ldc=D)
+            sv["Gimg"] = tap(0, i, OP, Si, D, offset_rows=St)   # reference lists[0]: image-stream attention output
+            sv["Gtxt"] = tap(1, i, OP, St, D, offset_rows=0)    # lists[1]: text-stream attention output
+            ops.gated_residual_(X, OP, mod(oi + 2 * D), B, Si, D, S * D, D, S * D, D, Ntot, x_offset=St * D, t_offset=St * D)
+            ops.gated_residual_(X, OP, mod(oc + 2 * D), B, St, D, S * D, D, S * D, D, Ntot)
+            sv.update(QKV=qkv, OP=OP, Xmid=X.clone())
+            ops.ln_modulate(X, NRM, B, S, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oi + 3 * D), mod(oi + 4 * D), Ntot)
+            PRE = torch.empty((B * S, 4 * D), **bf)   # text rows [B*St] first, image rows behind (as CAT in denoise)
+            Hh = torch.empty((B * S, 4 * D), **bf)
+            ff_img = B * St * 4 * D
+            ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                     a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img)
+            ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=St, batch=B,
+                     a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D, ldc=4 * D)
+            FF = torch.empty((B, S, D), **bf)
+            ops.gemm(Hh, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=FF, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, a_offset=ff_img,
+                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
+            ops.gemm(Hh, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=FF, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D,
+                     c_batch_stride=S * D, ldc=D)
+            ops.gated_residual_(X, FF, mod(oi + 5 * D), B, Si, D, S * D, D, S * D, D, Ntot, x_offset=St * D, t_offset=St * D)
+            ops.gated_residual_(X, FF, mod(oc + 5 * D), B, St, D, S * D, D, S * D, D, Ntot)
+            sv.update(PRE=PRE, FF=FF)
+            del Hh
+            saved["double"].append(sv)
+        base = cfg.num_layers * 12 * D
+        for i in range(cfg.num_single_layers):
+            p = f"s{i}"
+            o = base + i * 3 * D
+            sv = dict(Xin=X.clone())
+            ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
+            w, bias = f[p + ".in.w"], f[p + ".in.b"]
+            IN = torch.empty((B * S, 7 * D), **bf)   # [q|k|v pre-norm | proj_mlp pre-GELU]
+            ops.gemm(NRM, w, bias, out=IN, M=B * S)
+            ops.qkv_split(None, IN, 7 * D, 7 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
+            ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+            sv["G"] = tap(2, i, CAT.view(B, S, 5 * D), S, 5 * D)   # lists[2]: the un-projected joint attention output
+            # GELU(proj_mlp) into CAT[:, D:]: one elementwise pass through the GEMM epilogue is not available here, so the kernel that
+            # owns the activation (x2i_gemm_bf16 with act) recomputes that slice from NRM -- the saved pre-activation stays exact
+            ops.gemm(NRM, w[3 * D:], bias[3 * D:], out=CAT, M=B * S, N=4 * D, ldc=5 * D, c_offset=D, act=ACT_GELU_TANH)
+            PO = torch.empty((B, S, D), **bf)
+            ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=PO, M=S, batch=B, a_batch_stride=S * 5 * D, lda=5 * D,
+                     c_batch_stride=S * D, ldc=D)
+            ops.gated_residual_(X, PO, mod(o + 2 * D), B, S, D, S * D, D, S * D, D, Ntot)
+            sv.update(IN=IN, PO=PO)
+            saved["single"].append(sv)
+        o = base + cfg.num_single_layers * 3 * D
+        NRMF = ws["NRMF"]
+        ops.ln_modulate(X, NRMF, B, Si, D, 0, None, None, mod(o + D), mod(o), Ntot, x_bs=S * D, ldx=D, y_bs=Si * D, ldy=D, x_offset=St * D)
+        out = torch.empty((B, Si, m.out_channels * cfg.patch_size ** 2), **bf)
+        ops.gemm(NRMF, f["proj_out.w"], f["proj_out.b"], out=out, M=B * Si)
+        self.saved = saved
+        loss = torch.zeros((1,), device=dev, dtype=torch.float32)
+        for t in loss_terms:   # non-finite terms are skipped (:617-620): their gradients were zeroed on the device, here the value
+            loss += torch.where(torch.isfinite(t), t, torch.zeros_like(t))
+        return out, loss
+
+    # ------------------------------------------------------------------ backward pieces
+    @torch.no_grad()
+    def _attention_bwd(self, qkv0, qkv1, ld, S0, norms, dATT, ld_datt, dQKV0, dQKV1):
+        """d(q|k|v rows) from d(attention output) [B, S, *] (row stride ld_datt): recompute Q / K / V^T, then per sample the explicit
+        P = softmax(scale Q K^T), dP = dO V^T, dS, dQ = dS K, dK = dS^T Q, dV = P^T dO -- all x2i_gemm_bf16 launches."""
+        sv = self.saved
+        m = self.m
+        B, S, Spad = sv["B"], sv["S"], sv["Spad"]
+        H = m._H
+        ws = sv["state"]["ws"]
+        Q, K, VT = ws["Q"], ws["K"], ws["VT"]
+        cos, sin = sv["state"]["cos"], sv["state"]["sin"]
+        dev = m.device
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        nq0, nk0, nq1, nk1 = norms
+        ops.qkv_split(qkv0, qkv1, ld, ld, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, Q, K, VT, Spad)
+        scale = 1.0 / math.sqrt(128.0)
+        big = self.__dict__.get("_attn_ws")
+        if big is None or big["key"] != (H, Spad):
+            big = dict(key=(H, Spad), P=torch.empty((H, Spad, Spad), **bf), dP=torch.empty((H, Spad, Spad), **bf),
+                       T=torch.empty((H, Spad, Spad), **bf), V=torch.empty((H, Spad, 128), **bf), KT=torch.empty((H, 128, Spad), **bf),
+                       QT=torch.empty((H, 128, Spad), **bf), dOT=torch.zeros((H, 128, Spad), **bf))
+            self._attn_ws = big
+        P, dP, T, V, KT, QT, dOT = (big[k] for k in ("P", "dP", "T", "V", "KT", "QT", "dOT"))
+        dQ = torch.empty((B, H, Spad, 128), **bf)
+        dK = torch.empty((B, H, Spad, 128), **bf)
+        dV = torch.empty((B, H, Spad, 128), **bf)
+        L2 = Spad * Spad
+        for b in range(B):
+            ops.gemm(Q[b], K[b], out=P, M=Spad, N=Spad, K=128, batch=H, a_batch_stride=Spad * 128, lda=128, w_batch_stride=Spad * 128,
+                     c_batch_stride=L2, ldc=Spad)
+            ops.softmax_pad_(P, H, Spad, S, Spad, S, scale)
+            ops.transpose(VT[b], V, batch=H, R=128, C=Spad, in_bs=128 * Spad, ld_in=Spad, out_bs=Spad * 128, ld_out=128)
+            ops.gemm(dATT, V, out=dP, M=S, N=Spad, K=128, batch=H, a_batch_stride=128, lda=ld_datt, a_offset=b * S * ld_datt,
+                     w_batch_stride=Spad * 128, c_batch_stride=L2, ldc=Spad)
+            ops.softmax_bwd_(P, dP, H, Spad, S, Spad, S, scale)   # dP now holds dS (scale folded in)
+            ops.transpose(K[b], KT, batch=H, R=Spad, C=128, in_bs=Spad * 128, ld_in=128, out_bs=128 * Spad, ld_out=Spad)
+            ops.gemm(dP, KT, out=dQ[b], M=S, N=128, K=Spad, batch=H, a_batch_stride=L2, lda=Spad, w_batch_stride=128 * Spad,
+                     c_batch_stride=Spad * 128, ldc=128)
+            ops.transpose(dP, T, batch=H, R=Spad, C=Spad, in_bs=L2, ld_in=Spad, out_bs=L2, ld_out=Spad)
+            ops.transpose(Q[b], QT, batch=H, R=Spad, C=128, in_bs=Spad * 128, ld_in=128, out_bs=128 * Spad, ld_out=Spad)
+            ops.gemm(T, QT, out=dK[b], M=S, N=128, K=Spad, batch=H, a_batch_stride=L2, lda=Spad, w_batch_stride=128 * Spad,
+                     c_batch_stride=Spad * 128, ldc=128)
+            ops.transpose(P, T, batch=H, R=Spad, C=Spad, in_bs=L2, ld_in=Spad, out_bs=L2, ld_out=Spad)
+            ops.transpose(dATT, dOT, batch=H, R=S, C=128, in_bs=128, ld_in=ld_datt, out_bs=128 * Spad, ld_out=Spad,
+                          in_offset=b * S * ld_datt)
+            ops.gemm(T, dOT, out=dV[b], M=S, N=128, K=Spad, batch=H, a_batch_stride=L2, lda=Spad, w_batch_stride=128 * Spad,
+                     c_batch_stride=Spad * 128, ldc=128)
+        ops.qkv_split_bwd(qkv0, qkv1, ld, ld, dQKV0, dQKV1, ld, ld, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, dQ, dK, dV, Spad)
+
+    @torch.no_grad()
+    def backward(self):
+        """Runs the chain on the activations kept by forward_train(); returns (d_encoder_hidden_states [B, St, joint_dim] bf16,
+        d_pooled_projections [B, pooled_dim] f32)."""
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("backward: call forward_train() first")
+        m = self.m
+        cfg, f = m.config, m._fused
+        B, St, Si, S = sv["B"], sv["St"], sv["Si"], sv["S"]
+        D, H = m.inner_dim, m._H
+        dev = m.device
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        MOD = sv["MOD"]
+        Ntot = m._mod_rows
+        R = _gcd_rows(St, Si)
+        dX = torch.zeros((B, S, D), **bf)                      # gradient of the residual stream
+        dT = torch.empty((B, S, D), **bf)
+        dN = torch.empty((B, S, D), **bf)
+        dMOD = torch.zeros((B, Ntot), device=dev, dtype=torch.float32)
+        part = torch.empty((B * ((S + R - 1) // R) * 2 * D,), device=dev, dtype=torch.float32)
+
+        def mod(off):
+            return MOD[:, off:]
+
+        def colsum(npart, stat, nstat, out_off):
+            """dMOD[:, out_off : out_off + D] += sum over the npart wave partials of statistic `stat` (of nstat)"""
+            ops.reduce_rows(part, dMOD, np_=npart, len_=D, nz=B, in_zs=npart * nstat * D, in_ps=nstat * D, out_zs=Ntot, accumulate=True,
+                            in_offset=stat * D, out_offset=out_off)
+
+        def gate_bwd(T, G, gate_off, r0, n):
+            """rows [r0, r0 + n) of every sample: dT = gate * dX (+ G), d gate accumulated"""
+            ops.gate_bwd(dX, T, mod(gate_off), G, dT, part, B=B, S=n, D=D, R=R, gate_bs=Ntot, dx_bs=S * D, t_bs=S * D,
+                         g_bs=n * D, dt_bs=S * D, dx_offset=r0 * D, t_offset=r0 * D, dt_offset=r0 * D)
+            colsum((n + R - 1) // R, 0, 1, gate_off)
+
+        def ln_bwd(Xsaved, scale_off, shift_off, r0, n):
+            """rows [r0, r0 + n): dX += LayerNorm-modulate backward of dN; d scale / d shift accumulated"""
+            ops.ln_mod_bwd(Xsaved, dN, mod(scale_off), dX, dX, part, B=B, S=n, D=D, R=R, mult_bs=Ntot, x_bs=S * D, dy_bs=S * D, dx_bs=S * D,
+                           x_offset=r0 * D, dy_offset=r0 * D, dx_offset=r0 * D)
+            np_ = (n + R - 1) // R
+            colsum(np_, 0, 2, scale_off)
+            colsum(np_, 1, 2, shift_off)
+
+        base = cfg.num_layers * 12 * D
+        # ---- single-stream blocks, last to first
+        for i in reversed(range(cfg.num_single_layers)):
+            p = f"s{i}"
+            o = base + i * 3 * D
+            s_ = sv["single"][i]
+            gate_bwd(s_["PO"], None, o + 2 * D, 0, S)                                     # dT = d proj_out output
+            dCAT = torch.empty((B * S, 5 * D), **bf)
+            ops.gemm(dT, self._wt(p + ".proj_out.w"), out=dCAT, M=B * S)                    # [d attention | d GELU(proj_mlp)]
+            if s_["G"] is not None:
+                ops.gate_bwd(dCAT, None, None, s_["G"], dCAT, None, B=B, S=S, D=D, R=R, dx_bs=S * 5 * D, lddx=5 * D, g_bs=S * D, dt_bs=S * 5 * D,
+                             lddt=5 * D)                                                    # d attention += tap gradient
+            dIN = torch.empty((B * S, 7 * D), **bf)
+            # d proj_mlp pre-activation -> columns [3D, 7D) of dIN
+            dIN.view(B * S, 7 * D)[:, 3 * D:].copy_(dCAT.view(B * S, 5 * D)[:, D:])
+            ops.act_bwd_(dIN, s_["IN"], ACT_GELU_TANH, rows=B * S, cols=4 * D, ldd=7 * D, ldp=7 * D, d_offset=3 * D, p_offset=3 * D)
+            self._attention_bwd(None, s_["IN"], 7 * D, 0, (None, None, f[p + ".norm_q"], f[p + ".norm_k"]), dCAT, 5 * D, None, dIN)
+            ops.gemm(dIN, self._wt(p + ".in.w"), out=dN, M=B * S)
+            ln_bwd(s_["Xin"], o + D, o, 0, S)
+            del dCAT, dIN
+        # ---- double-stream blocks
+        for i in reversed(range(cfg.num_layers)):
+            p = f"d{i}"
+            oi = i * 12 * D
+            oc = oi + 6 * D
+            d_ = sv["double"][i]
+            # feed-forward: x = x_mid + gate_mlp * FF
+            gate_bwd(d_["FF"], None, oi + 5 * D, St, Si)
+            gate_bwd(d_["FF"], None, oc + 5 * D, 0, St)
+            dH = torch.empty((B * S, 4 * D), **bf)
+            ff_img = B * St * 4 * D
+            ops.gemm(dT, self._wt(p + ".ff.2.w"), out=dH, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                     c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img)
+            ops.gemm(dT, self._wt(p + ".ff_context.2.w"), out=dH, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D,
+                     ldc=4 * D)
+            ops.act_bwd_(dH, d_["PRE"], ACT_GELU_TANH)
+            ops.gemm(dH, self._wt(p + ".ff.0.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, a_offset=ff_img,
+                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
+            ops.gemm(dH, self._wt(p + ".ff_context.0.w"), out=dN, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D,
+                     ldc=D)
+            del dH
+            ln_bwd(d_["Xmid"], oi + 4 * D, oi + 3 * D, St, Si)
+            ln_bwd(d_["Xmid"], oc + 4 * D, oc + 3 * D, 0, St)
+            # attention: x_mid = x_in + gate_msa * OP, OP = to_out(attention) -- the taps sit on OP
+            gate_bwd(d_["OP"], d_["Gimg"], oi + 2 * D, St, Si)
+            gate_bwd(d_["OP"], d_["Gtxt"], oc + 2 * D, 0, St)
+            dATT = torch.empty((B, S, D), **bf)
+            ops.gemm(dT, self._wt(p + ".to_out.w"), out=dATT, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
+            ops.gemm(dT, self._wt(p + ".to_add_out.w"), out=dATT, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=S * D, ldc=D)
+            dQKV = torch.empty((B * S, 3 * D), **bf)
+            img = B * St * 3 * D
+            self._attention_bwd(d_["QKV"], d_["QKV"].view(-1)[img:], 3 * D, St,
+                                (f[p + ".norm_added_q"], f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"]), dATT, D, dQKV,
+                                dQKV.view(-1)[img:])
+            ops.gemm(dQKV, self._wt(p + ".qkv.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 3 * D, lda=3 * D, a_offset=img,
+                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
+            ops.gemm(dQKV, self._wt(p + ".cqkv.w"), out=dN, M=St, batch=B, a_batch_stride=St * 3 * D, lda=3 * D, c_batch_stride=S * D, ldc=D)
+            del dATT, dQKV
+            ln_bwd(d_["Xin"], oi + D, oi, St, Si)
+            ln_bwd(d_["Xin"], oc + D, oc, 0, St)
+        # ---- embedders: text rows of dX -> context_embedder -> encoder_hidden_states
+        joint = f["context_embedder.w"].shape[1]
+        d_enc = torch.empty((B, St, joint), **bf)
+        ops.gemm(dX, self._wt("context_embedder.w"), out=d_enc, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=St * joint, ldc=joint)
+        # ---- modulation table -> temb -> text_embedder -> pooled_projections  (MOD = Linear(SiLU(temb)))
+        d_act = ops.skinny_linear_bwd(dMOD, f["mod.w"])                       # d SiLU(temb)
+        ops.act_bwd_(d_act, sv["temb"], ACT_SILU)                             # d temb = d cond
+        pooled = sv["state"].get("pooled")
+        if pooled is None:
+            raise RuntimeError("backward: prepare the conditioning with DistillBackward.prepare_conditioning (it keeps the pooled input)")
+        pre1 = ops.skinny_linear(pooled, f["tte.text_embedder.1.w"], f["tte.text_embedder.1.b"])
+        d_h1 = ops.skinny_linear_bwd(d_act, f["tte.text_embedder.2.w"])
+        ops.act_bwd_(d_h1, pre1, ACT_SILU)
+        d_pooled = ops.skinny_linear_bwd(d_h1, f["tte.text_embedder.1.w"])
+        self.dMOD = dMOD
+        return d_enc, d_pooled
+
+    @torch.no_grad()
+    def prepare_conditioning(self, encoder_hidden_states, pooled_projections, txt_ids, img_ids, guidance=None):
+        """FluxTransformer2DModel.prepare_conditioning + the pooled input kept for the backward of the text embedder."""
+        st = self.m.prepare_conditioning(encoder_hidden_states, pooled_projections, txt_ids, img_ids, guidance)
+        st["pooled"] = pooled_projections.to(device=self.m.device, dtype=torch.bfloat16).contiguous()
+        return st
