@@ -309,6 +309,20 @@ int x2i_kd_loss_bf16(const void* teacher, int64_t ldt, const void* student, int6
 /* g[0..n) <- 0 when *term is NaN / Inf (the reference skips non-finite per-block loss terms, :617-620); no host synchronisation */
 int x2i_zero_if_nonfinite_bf16(void* g, int64_t n, const float* term, x2i_stream_t stream);
 
+/* -- the trainable side (projector): weight gradients of the layer fusion, gradient clipping, AdamW.  Linear-layer weight gradients are
+ * x2i_gemm_bf16 launches on transposed operands (dW = dY^T X). */
+/* conv5x5 (utils/proj.py:50,68-69) weight gradient: partial f32 [C][B][ceil(S/16)][25], dw[c] = sum over [B][chunk] (x2i_reduce_rows_f32) */
+int x2i_proj_conv5x5_wgrad(const void* x, const void* dy, float* partial, int32_t B, int32_t C, int32_t S, int32_t H, x2i_stream_t stream);
+/* partial f32 [C][B][nchunk] = sum_i dy[b][i] * x[b][c][i] over chunks of the plane (cha_scale gradient, utils/proj.py:66-67) */
+int x2i_plane_dot_bf16(const void* x, const void* dy, float* partial, int32_t B, int32_t C, int64_t plane, int32_t nchunk, x2i_stream_t stream);
+/* partial[blk] = sum x (squares = 0) or sum x^2 (squares = 1) over a grid-strided slice of n elements (f32 or bf16) */
+int x2i_sum_partials(const void* x, int32_t is_bf16, int64_t n, int32_t squares, float* partial, int32_t nblocks, x2i_stream_t stream);
+/* out[0] = min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_, train/train_qwenvl.py:628), out[1] = the norm */
+int x2i_clip_coef_f32(const float* sumsq, float max_norm, float* out, x2i_stream_t stream);
+/* AdamW step (torch.optim.AdamW semantics, :447-459) on bf16 parameters, f32 gradients (scaled by *grad_coef when non-NULL) and f32 moments */
+int x2i_adamw_bf16(void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_correction1, float bias_correction2, const float* grad_coef, x2i_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,4 +297,21 @@ int x2i_zero_if_nonfinite_bf16(void* g, int64_t n, const float* term, x2i_stream
   return x2i_launch_zero_if_nonfinite(g, n, term, (hipStream_t)stream);
 }
 
+int x2i_proj_conv5x5_wgrad(const void* x, const void* dy, float* partial, int32_t B, int32_t C, int32_t S, int32_t H, x2i_stream_t stream) {
+  return x2i_launch_conv5x5_wgrad(x, dy, partial, B, C, S, H, (hipStream_t)stream);
+}
+int x2i_plane_dot_bf16(const void* x, const void* dy, float* partial, int32_t B, int32_t C, int64_t plane, int32_t nchunk, x2i_stream_t stream) {
+  return x2i_launch_plane_dot(x, dy, partial, B, C, plane, nchunk, (hipStream_t)stream);
+}
+int x2i_sum_partials(const void* x, int32_t is_bf16, int64_t n, int32_t squares, float* partial, int32_t nblocks, x2i_stream_t stream) {
+  return x2i_launch_sum(x, is_bf16, n, squares, partial, nblocks, (hipStream_t)stream);
+}
+int x2i_clip_coef_f32(const float* sumsq, float max_norm, float* out, x2i_stream_t stream) {
+  return x2i_launch_clip_coef(sumsq, max_norm, out, (hipStream_t)stream);
+}
+int x2i_adamw_bf16(void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_correction1, float bias_correction2, const float* grad_coef, x2i_stream_t stream) {
+  return x2i_launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_coef, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -580,9 +580,165 @@ __global__ void zero_if_nonfinite_kernel(bf16_t* __restrict__ g, long long n8, c
   if (i < n8) *(bf16x8_t*)(g + i * 8) = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Projector side (the trainable module): weight gradients of the layer fusion, gradient norm, AdamW.
+//
+// conv5x5 weight gradient: dw[c][ds][dh] = sum_{b,s,h} dy[b][s][h] * x[b][c][s + ds - 2][h + dh - 2]  (utils/proj.py:50,68-69 backward).
+// A block takes 16 input rows of one (b, c) plane; a thread owns 8 columns per pass and the 25 running sums; dy rows come from L2.
+// partial: [C][B][nchunk][25].
+__global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ partial,
+                                                            int C, int S, int H, int nchunk) {
+  __shared__ float red[4][25];
+  const int chunk = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const bf16_t* xp = x + ((long long)b * C + c) * S * H;
+  const bf16_t* dp = dy + (long long)b * S * H;
+  float acc[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = 0.f;
+  const int nh = H >> 3;
+  for (int rr = 0; rr < 16; ++rr) {
+    const int sp = chunk * 16 + rr;   // input row s'
+    if (sp >= S) break;
+    for (int hc = threadIdx.x; hc < nh; hc += 256) {
+      float xv[8];
+      unpack8(*(const bf16x8_t*)(xp + (long long)sp * H + hc * 8), xv);
+#pragma unroll
+      for (int ds = 0; ds < 5; ++ds) {
+        const int r = sp - ds + 2;   // output row that sees x row s' through kernel row ds
+        if (r < 0 || r >= S) continue;
+        // dy[r][hc*8 - 2 .. hc*8 + 9]: the aligned chunk and one neighbour element pair on each side
+        float d[12];
+        float mid[8];
+        unpack8(*(const bf16x8_t*)(dp + (long long)r * H + hc * 8), mid);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j + 2] = mid[j];
+        const long long base = (long long)r * H + hc * 8;
+        d[0] = hc > 0 ? bf16_to_f32(dp[base - 2]) : 0.f;
+        d[1] = hc > 0 ? bf16_to_f32(dp[base - 1]) : 0.f;
+        d[10] = hc + 1 < nh ? bf16_to_f32(dp[base + 8]) : 0.f;
+        d[11] = hc + 1 < nh ? bf16_to_f32(dp[base + 9]) : 0.f;
+        // x[s'][h'] pairs with dy[r][h' - dh + 2]
+#pragma unroll
+        for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[ds][dh] = fmaf(xv[j], d[j + 4 - dh], acc[ds][dh]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float v = wave_sum(acc[i][j]);
+      if (lane == 0) red[wave][i * 5 + j] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 25)
+    partial[(((long long)c * gridDim.z + b) * nchunk + chunk) * 25 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// partial[c][b][chunk] = sum_i dy[b][i] * x[b][c][i] over a chunk of the (S, H) plane  (cha_scale gradient, utils/proj.py:66-67)
+__global__ __launch_bounds__(256) void plane_dot_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ partial, int C,
+                                                        long long plane8, int nchunk, long long per_chunk) {
+  __shared__ float red[4];
+  const int chunk = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const bf16_t* xp = x + ((long long)b * C + c) * plane8 * 8;
+  const bf16_t* dp = dy + (long long)b * plane8 * 8;
+  float acc = 0.f;
+  const long long lo = (long long)chunk * per_chunk, hi = min(plane8, lo + per_chunk);
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    float a[8], d[8];
+    unpack8(*(const bf16x8_t*)(xp + i * 8), a);
+    unpack8(*(const bf16x8_t*)(dp + i * 8), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = fmaf(a[j], d[j], acc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[((long long)c * gridDim.z + b) * nchunk + chunk] = red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[block] = sum x (mode 0) or sum x^2 (mode 1) over a grid-strided slice; x is f32 or bf16
+__global__ __launch_bounds__(256) void sum_kernel(const void* __restrict__ xv, int is_bf16, long long n, int mode, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float v = is_bf16 ? bf16_to_f32(((const bf16_t*)xv)[i]) : ((const float*)xv)[i];
+    acc += mode ? v * v : v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// torch.nn.utils.clip_grad_norm_ (train/train_qwenvl.py:628): coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)), on the device
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ out /* [2]: coef, total norm */) {
+  const float nrm = sqrtf(sumsq[0]);
+  out[1] = nrm;
+  out[0] = fminf(1.f, max_norm / (nrm + 1e-6f));
+}
+
+// AdamW (torch.optim.AdamW semantics, decoupled weight decay) on bf16 parameters with f32 gradients and f32 moments:
+//   g' = coef * g;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;  p = p (1 - lr wd) - lr (m / bc1) / (sqrt(v / bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ coef) {
+  const float cf = coef ? coef[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gg = cf * g[i];
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    float pw = bf16_to_f32(p[i]);
+    pw = pw * (1.f - lr * wd) - lr * (mm / bc1) / (sqrtf(vv / bc2) + eps);
+    p[i] = f32_to_bf16(pw);
+  }
+}
+
 bool al16p(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+int x2i_launch_conv5x5_wgrad(const void* x, const void* dy, float* partial, int B, int C, int S, int H, hipStream_t stream) {
+  if (!x || !dy || !partial || B <= 0 || C <= 0 || S <= 0 || H <= 0 || H % 8) return x2i_set_error(X2I_ERR_ARG, "conv5x5_wgrad: bad argument (H %% 8 == 0)");
+  const int nchunk = (S + 15) / 16;
+  hipLaunchKernelGGL(conv5x5_wgrad_kernel, dim3(nchunk, C, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, partial, C, S, H, nchunk);
+  return x2i_check_launch("conv5x5_wgrad");
+}
+
+int x2i_launch_plane_dot(const void* x, const void* dy, float* partial, int B, int C, long long plane, int nchunk, hipStream_t stream) {
+  if (!x || !dy || !partial || B <= 0 || C <= 0 || plane <= 0 || plane % 8 || nchunk <= 0) return x2i_set_error(X2I_ERR_ARG, "plane_dot: bad argument");
+  const long long plane8 = plane / 8, per = (plane8 + nchunk - 1) / nchunk;
+  hipLaunchKernelGGL(plane_dot_kernel, dim3(nchunk, C, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, partial, C, plane8, nchunk, per);
+  return x2i_check_launch("plane_dot");
+}
+
+int x2i_launch_sum(const void* x, int is_bf16, long long n, int mode, float* partial, int nblocks, hipStream_t stream) {
+  if (!x || !partial || n <= 0 || nblocks <= 0) return x2i_set_error(X2I_ERR_ARG, "sum: bad argument");
+  hipLaunchKernelGGL(sum_kernel, dim3(nblocks), dim3(256), 0, stream, x, is_bf16, n, mode, partial);
+  return x2i_check_launch("sum");
+}
+
+int x2i_launch_clip_coef(const float* sumsq, float max_norm, float* out, hipStream_t stream) {
+  if (!sumsq || !out) return x2i_set_error(X2I_ERR_ARG, "clip_coef: null pointer");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, max_norm, out);
+  return x2i_check_launch("clip_coef");
+}
+
+int x2i_launch_adamw(void* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                     float bc2, const float* coef, hipStream_t stream) {
+  if (!p || !g || !m || !v || n <= 0) return x2i_set_error(X2I_ERR_ARG, "adamw: bad argument");
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, (bf16_t*)p, g, m, v, n, lr, b1, b2, eps, wd,
+                     bc1, bc2, coef);
+  return x2i_check_launch("adamw");
+}
 
 int x2i_launch_transpose(const void* in, long long in_bs, long long ld_in, void* out, long long out_bs, long long ld_out, int batch, int R, int C,
                          hipStream_t stream) {

@@ -71,3 +71,9 @@ int x2i_launch_skinny_bwd(const float* dy, long long dy_bs, const void* W, int l
 int x2i_launch_kd_loss(const void* teacher, long long ldt, const void* student, long long lds, void* grad, long long ldg, float* row_loss,
                        long long rows, int D, float temperature, float loss_scale, hipStream_t stream);
 int x2i_launch_zero_if_nonfinite(void* g, long long n, const float* term, hipStream_t stream);
+int x2i_launch_conv5x5_wgrad(const void* x, const void* dy, float* partial, int B, int C, int S, int H, hipStream_t stream);
+int x2i_launch_plane_dot(const void* x, const void* dy, float* partial, int B, int C, long long plane, int nchunk, hipStream_t stream);
+int x2i_launch_sum(const void* x, int is_bf16, long long n, int mode, float* partial, int nblocks, hipStream_t stream);
+int x2i_launch_clip_coef(const float* sumsq, float max_norm, float* out, hipStream_t stream);
+int x2i_launch_adamw(void* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                     float bc2, const float* coef, hipStream_t stream);

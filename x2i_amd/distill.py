@@ -5,12 +5,13 @@ What the reference's training step needs from the diffusion transformer, and wha
   * hooks on every block's `attn` module collecting the attention outputs of the teacher (frozen FLUX) and of the student
     (same frozen FLUX driven by the trainable projector's embeddings): `cast_hook_list` below is the reference's helper with the
     same name and list layout; the HIP transformer materialises those outputs only while hooks are registered
-    (x2i_amd/flux.py `_AttnTap`, x2i_gated_residual_bf16) -- PROVIDED, forward only;
+    (x2i_amd/flux.py `_AttnTap`, x2i_gated_residual_bf16) -- PROVIDED;
   * the per-block loss  KL( softmax(normalize(teacher) / 3) || softmax(normalize(student) / 3) ), `kd_attention_loss` below:
     plain torch on the captured tensors (it is a few reductions over tensors that already exist; not a hot-path kernel) -- PROVIDED;
   * the gradient of that loss with respect to the projector's parameters: it flows BACKWARDS THROUGH ALL 57 TRANSFORMER BLOCKS
-    (train/train_qwenvl.py:637 `loss.backward()` with only proj_t5 trainable).  A backward pass of the DiT is NOT built: this
-    package is the sampling path.  `teacher_student_loss` therefore returns the loss value only.
+    (train/train_qwenvl.py:626 `loss.backward()` with only proj_t5 trainable).  That chain, the loss kernel, the projector's
+    backward, gradient clipping and AdamW live in x2i_amd/train.py (`DistillBackward`, `ProjectorTrainer`, `distill_step`) on the
+    HIP path; `teacher_student_loss` below is the forward-only helper (loss value from two hooked forwards).
 The gather / scatter of teacher tensors between inference and training ranks (core/pipeline/train_and_infer.py:80-122) is
 torch.distributed plumbing outside the hot path and is not restated.
 """

@@ -581,3 +581,49 @@ def kd_loss_rows(teacher, student, grad, row_loss, *, rows, D, temperature, loss
 def zero_if_nonfinite_(g, term):
     check(_lib.load().x2i_zero_if_nonfinite_bf16(_p(g), g.numel(), _p(term), _stream()), "zero_if_nonfinite")
     return g
+
+
+def conv5x5_wgrad(x, dy):
+    """dw f32 [C, 25] of Conv2d(C->1, 5, pad 2) over the (S, H) plane: x bf16 [B,C,S,H], dy bf16 [B,S,H] (x2i_proj_conv5x5_wgrad)."""
+    lib = _lib.load()
+    B, Cc, S, H = x.shape
+    nchunk = (S + 15) // 16
+    partial = torch.empty((Cc, B, nchunk, 25), device=x.device, dtype=torch.float32)
+    check(lib.x2i_proj_conv5x5_wgrad(_p(x), _p(dy), _p(partial), B, Cc, S, H, _stream()), "conv5x5_wgrad")
+    out = torch.empty((Cc, 25), device=x.device, dtype=torch.float32)
+    reduce_rows(partial, out, np_=B * nchunk, len_=25, nz=Cc, in_zs=B * nchunk * 25, in_ps=25, out_zs=25)
+    return out
+
+
+def plane_dot(x, dy, alpha=1.0, nchunk=64):
+    """out f32 [C] = alpha * sum_{b,i} dy[b][i] * x[b][c][i]   (x bf16 [B,C,S,H], dy bf16 [B,S,H])."""
+    lib = _lib.load()
+    B, Cc = x.shape[0], x.shape[1]
+    plane = x[0, 0].numel()
+    partial = torch.empty((Cc, B, nchunk), device=x.device, dtype=torch.float32)
+    check(lib.x2i_plane_dot_bf16(_p(x), _p(dy), _p(partial), B, Cc, plane, nchunk, _stream()), "plane_dot")
+    out = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+    reduce_rows(partial, out, np_=B * nchunk, len_=1, nz=Cc, in_zs=B * nchunk, in_ps=1, out_zs=1, alpha=alpha)
+    return out
+
+
+def sum_all(x, squares=False, out=None, accumulate=False, nblocks=256):
+    """out f32 [1] (+)= sum x or sum x^2 over every element of x (f32 or bf16), two-stage."""
+    lib = _lib.load()
+    partial = torch.empty((nblocks,), device=x.device, dtype=torch.float32)
+    check(lib.x2i_sum_partials(_p(x), 1 if x.dtype == torch.bfloat16 else 0, x.numel(), 1 if squares else 0, _p(partial), nblocks, _stream()), "sum")
+    out = torch.zeros((1,), device=x.device, dtype=torch.float32) if out is None else out
+    reduce_rows(partial, out, np_=nblocks, len_=1, in_ps=1, accumulate=accumulate)
+    return out
+
+
+def clip_coef(sumsq, max_norm):
+    out = torch.empty((2,), device=sumsq.device, dtype=torch.float32)
+    check(_lib.load().x2i_clip_coef_f32(_p(sumsq), float(max_norm), _p(out), _stream()), "clip_coef")
+    return out
+
+
+def adamw_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, coef=None):
+    check(_lib.load().x2i_adamw_bf16(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                     1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(coef), _stream()), "adamw")
+    return p

@@ -370,3 +370,165 @@ class DistillBackward:
         st = self.m.prepare_conditioning(encoder_hidden_states, pooled_projections, txt_ids, img_ids, guidance)
         st["pooled"] = pooled_projections.to(device=self.m.device, dtype=torch.bfloat16).contiguous()
         return st
+
+
+class ProjectorTrainer:
+    """The trainable half of the reference's step: Proj7Exp forward with saved activations, its backward (weight gradients), gradient
+    all-reduce over the data-parallel group (what DistributedDataParallel does for the reference, train/train_qwenvl.py:483),
+    `clip_grad_norm_` (:628) and `torch.optim.AdamW` (:447-459, :630).  Parameters stay the module's bf16 tensors; gradients and the two
+    moments are f32 in ONE flat buffer each (a single RCCL all-reduce per step; the reference's moments are bf16 -- stated difference,
+    results agree with torch.optim.AdamW on bf16 parameters to bf16 rounding, tests/test_train_gpu.py)."""
+
+    def __init__(self, proj, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, process_group=None):
+        self.proj = proj
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.pg = process_group
+        self.names = [n for n, _ in proj.named_parameters()]
+        self.params = [p for _, p in proj.named_parameters()]
+        sizes = [p.numel() for p in self.params]
+        dev = self.params[0].device
+        total = sum(sizes)
+        self.grad = torch.zeros((total,), device=dev, dtype=torch.float32)
+        self.m = torch.zeros_like(self.grad)
+        self.v = torch.zeros_like(self.grad)
+        self.off = {}
+        o = 0
+        for n, s in zip(self.names, sizes):
+            self.off[n] = (o, s)
+            o += s
+        self.step_count = 0
+        self.saved = None
+        self.last_norm = None
+
+    def g(self, name):
+        o, s = self.off[name]
+        return self.grad[o:o + s]
+
+    @torch.no_grad()
+    def forward(self, x):
+        """Proj7Exp.forward (utils/proj.py:62-72, :28-33) keeping the activations its backward needs.  Returns (pooled, prompt_embeds)."""
+        pr = self.proj
+        mlp = pr.mlp
+        B, Cc, S, H = x.shape
+        x = x.to(torch.bfloat16).contiguous()
+        if pr.use_scale:
+            x0 = ops.proj_layer_mean(x, pr.cha_scale.float().reshape(-1).contiguous())
+        elif pr.use_cnn:
+            from .proj import _conv5x5
+            x0 = _conv5x5(pr, x)
+        else:
+            x0 = ops.proj_layer_mean(x, None)
+        xn = ops.ln_affine(x0, mlp.layernorm.weight, mlp.layernorm.bias, mlp.eps)
+        W0, W2, Wf, bfc = mlp.projector[0].weight, mlp.projector[2].weight, mlp.fc[1].weight, mlp.fc[1].bias
+        bf = dict(device=x.device, dtype=torch.bfloat16)
+        pre0 = torch.empty((B * S, W0.shape[0]), **bf)
+        h = torch.empty_like(pre0)
+        ops.gemm(xn, W0, out=pre0, out2=h, act2=ACT_GELU_ERF, M=B * S)
+        x2 = torch.empty((B, S, W2.shape[0]), **bf)
+        g2 = torch.empty_like(x2)
+        ops.gemm(h, W2, out=x2, out2=g2, act2=ACT_GELU_ERF, M=B * S)
+        x1_tok = ops.gemm(g2, Wf, bfc, M=B * S, out_f32=True)
+        x1 = ops.seq_mean(x1_tok.view(B, S, -1))
+        self.saved = dict(x=x, x0=x0, xn=xn, pre0=pre0, h=h, x2=x2, g2=g2, B=B, S=S)
+        return x1.to(torch.bfloat16), x2
+
+    @torch.no_grad()
+    def _wgrad(self, dY, X, out):
+        """out f32 [N, K] = dY^T X   (dY bf16 [M, N], X bf16 [M, K]) -- the forward GEMM on transposed operands"""
+        M = dY.shape[0]
+        dYT, XT = ops.transpose(dY.contiguous()), ops.transpose(X.contiguous())
+        ops.gemm(dYT, XT, out=out.view(dYT.shape[0], XT.shape[0]), M=dYT.shape[0], N=XT.shape[0], K=M, out_f32=True)
+
+    @torch.no_grad()
+    def backward(self, d_enc, d_pooled, keep=False):
+        """Weight gradients from d loss / d prompt_embeds (bf16 [B,S,4096]) and d loss / d pooled (f32 [B,768]); gradients ACCUMULATE
+        (gradient accumulation steps, :560) until step()."""
+        sv, pr = self.saved, self.proj
+        mlp = pr.mlp
+        B, S = sv["B"], sv["S"]
+        dev = sv["x"].device
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        W0, W2, Wf = mlp.projector[0].weight, mlp.projector[2].weight, mlp.fc[1].weight
+        N1 = Wf.shape[0]
+        tmp = torch.empty((Wf.numel(),), device=dev, dtype=torch.float32)
+
+        def acc(name, t):
+            ops.reduce_rows(t, self.g(name), np_=1, len_=t.numel(), accumulate=True)
+
+        # fc: x1 = mean_s(g2 Wf^T + b): every token row receives d_pooled[b] / S
+        dp = torch.empty((B, N1), device=dev, dtype=torch.float32)
+        ops.reduce_rows(d_pooled.contiguous(), dp, np_=1, len_=B * N1, alpha=1.0 / S)
+        dtok = ops.to_bf16(dp).view(B, 1, N1).expand(B, S, N1).contiguous().view(B * S, N1)
+        self._wgrad(dtok, sv["g2"].view(B * S, -1), tmp)
+        acc("mlp.fc.1.weight", tmp)
+        ops.reduce_rows(d_pooled.contiguous(), self.g("mlp.fc.1.bias"), np_=B, len_=N1, in_ps=N1, accumulate=True)
+        dg2 = torch.empty((B * S, W2.shape[0]), **bf)
+        ops.gemm(dtok, ops.transpose(Wf.contiguous()), out=dg2, M=B * S)
+        ops.act_bwd_(dg2, sv["x2"].view(B * S, -1), ACT_GELU_ERF)
+        # d x2 = d_enc + d g2 * gelu'(x2)
+        ops.gate_bwd(dg2, None, None, d_enc.to(**bf).contiguous(), dg2, None, B=1, S=B * S, D=W2.shape[0], R=8)
+        tmp2 = torch.empty((W2.numel(),), device=dev, dtype=torch.float32)
+        self._wgrad(dg2, sv["h"], tmp2)
+        acc("mlp.projector.2.weight", tmp2)
+        dh = torch.empty((B * S, W2.shape[1]), **bf)
+        ops.gemm(dg2, ops.transpose(W2.contiguous()), out=dh, M=B * S)
+        ops.act_bwd_(dh, sv["pre0"], ACT_GELU_ERF)
+        tmp0 = torch.empty((W0.numel(),), device=dev, dtype=torch.float32)
+        self._wgrad(dh, sv["xn"].view(B * S, -1), tmp0)
+        acc("mlp.projector.0.weight", tmp0)
+        Hd = W0.shape[1]
+        dxn = torch.empty((B * S, Hd), **bf)
+        ops.gemm(dh, ops.transpose(W0.contiguous()), out=dxn, M=B * S)
+        # affine LayerNorm backward: d weight / d bias column sums, d x0
+        R = 8
+        nw = (B * S + R - 1) // R
+        part = torch.empty((nw, 2, Hd), device=dev, dtype=torch.float32)
+        dx0 = torch.empty((B, S, Hd), **bf)
+        ops.ln_mod_bwd(sv["x0"], dxn, mlp.layernorm.weight.float().contiguous(), None, dx0, part, B=1, S=B * S, D=Hd, R=R, mult_is_scale=False,
+                       eps=mlp.eps)
+        ops.reduce_rows(part, self.g("mlp.layernorm.weight"), np_=nw, len_=Hd, in_ps=2 * Hd, accumulate=True)
+        ops.reduce_rows(part, self.g("mlp.layernorm.bias"), np_=nw, len_=Hd, in_ps=2 * Hd, accumulate=True, in_offset=Hd)
+        # layer fusion
+        Cc = sv["x"].shape[1]
+        if pr.use_scale:
+            acc("cha_scale", ops.plane_dot(sv["x"], dx0, alpha=1.0 / Cc))
+        elif pr.use_cnn:
+            acc("conv.weight", ops.conv5x5_wgrad(sv["x"], dx0).view(-1))
+            ops.sum_all(dx0, out=self.g("conv.bias"), accumulate=True)
+        if keep:  # intermediates for the parity tests
+            self.kept = dict(dtok=dtok, dx2=dg2, dpre0=dh, dxn=dxn, dx0=dx0)
+
+    @torch.no_grad()
+    def step(self):
+        """all-reduce (mean) over the data-parallel group, clip by global norm, AdamW; clears the gradients.  Returns the device tensor
+        [clip coefficient, gradient norm]."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+            dist.all_reduce(self.grad, group=self.pg)
+            ops.reduce_rows(self.grad.clone(), self.grad, np_=1, len_=self.grad.numel(), alpha=1.0 / dist.get_world_size(self.pg))
+        coef = ops.clip_coef(ops.sum_all(self.grad, squares=True), self.max_norm)
+        self.step_count += 1
+        for n, p in zip(self.names, self.params):
+            o, s = self.off[n]
+            ops.adamw_(p, self.grad[o:o + s], self.m[o:o + s], self.v[o:o + s], lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                       eps=self.eps, weight_decay=self.wd, step=self.step_count, coef=coef)
+        self.proj.__dict__.pop("_conv5x5_cache", None)  # the packed conv table is keyed on the weight's version counter; drop it
+        self.grad.zero_()
+        self.last_norm = coef
+        return coef
+
+
+@torch.no_grad()
+def distill_step(trainer, chain, text_embeddings, latents, timestep, teacher, txt_ids, img_ids, guidance=None, temperature=3.0,
+                 optimizer_step=True):
+    """train/train_qwenvl.py:575-632 on the HIP path: projector forward, student transformer forward with the distillation loss
+    evaluated at every attention tap, backward through the frozen transformer into the projector's outputs, projector backward,
+    (clip + AdamW).  `timestep` as the reference passes it to the transformer (already / 1000).  Returns the loss (device scalar)."""
+    pooled, prompt = trainer.forward(text_embeddings)
+    st = chain.prepare_conditioning(prompt, pooled, txt_ids, img_ids, guidance)
+    _, loss = chain.forward_train(st, latents, timestep, teacher=teacher, temperature=temperature)
+    d_enc, d_pooled = chain.backward()
+    trainer.backward(d_enc, d_pooled)
+    if optimizer_step:
+        trainer.step()
+    return loss
