@@ -66,7 +66,7 @@ def gemm_roofline(B, iters=10):
     # HBM-side traffic of the same two launches from the committed rocprofv3 PMC pass (tools/pmc_collect.sh; FETCH_SIZE
     # doubled per the gfx950 correction, + WRITE_SIZE).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r02a_pmc_gemm_attn.json")
+    pj = os.path.join(ROOT, "profiles", "r02d_pmc_gemm_attn.json")
     if B == 4 and os.path.exists(pj):
         d = json.load(open(pj))
         # the launcher peels the last partly filled round of 256^2 tiles into a 128^2 launch: four kernels for the two GEMMs
@@ -74,7 +74,7 @@ def gemm_roofline(B, iters=10):
                  "gemm256l_bf16_kernel<0, false, false, false, false> grid=393216", "gemm_bf16_kernel<0, false, false, false, false> grid=98304")
         try:
             traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"] for k in grids)
-            src = ("profiles/r02a_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
+            src = ("profiles/r02d_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
                    "boundary for both GEMMs incl. their peeled 128x128 tail launches)")
         except KeyError:
             traffic = None
@@ -114,13 +114,13 @@ def gemm_roofline_fp8(B, iters=10):
     fl, tt = sum(r[0] for r in res), sum(r[1] for r in res)
     alg_bytes = (B * S * D + 4 * D * D + B * S * 4 * D) + (B * S * 5 * D + 5 * D * D + 2 * 2 * B * S * D)
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r02a_pmc_gemm_attn.json")
+    pj = os.path.join(ROOT, "profiles", "r02d_pmc_gemm_attn.json")
     if B == 4 and os.path.exists(pj):
         d = json.load(open(pj))
         try:
             traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"]
                           for k in ("gemm256_fp8_kernel<1, false, true> grid=1769472", "gemm256_fp8_kernel<0, true, false> grid=442368"))
-            src = "profiles/r02a_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes; L2<->fabric bytes of both launches)"
+            src = "profiles/r02d_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes; L2<->fabric bytes of both launches)"
         except KeyError:
             traffic = None
     return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_FP8 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_FP8, traffic=traffic,

@@ -309,6 +309,15 @@ int x2i_kd_loss_bf16(const void* teacher, int64_t ldt, const void* student, int6
 /* g[0..n) <- 0 when *term is NaN / Inf (the reference skips non-finite per-block loss terms, :617-620); no host synchronisation */
 int x2i_zero_if_nonfinite_bf16(void* g, int64_t n, const float* term, x2i_stream_t stream);
 
+/* Fused (flash-style) attention backward, head_dim 128 (csrc/attention_bwd.hip): dQ, dK, dV bf16 [B,H,Spad,128] from
+ *   Q, K, V, dO  bf16 [B,H,Spad,128] (row-major per head, zero beyond S)      QT, KT, dOT  bf16 [B,H,128,Spad] (their transposes)
+ *   D  f32 [B,H,Spad] = rowsum(dO * O) (x2i_attention_bwd_prep_bf16 from the token-major dO / O)     lse2  f32 [B,H,Spad] scratch
+ * Three launches: log2-sum-exp statistics into lse2, dQ (persistent query blocks), dK / dV (persistent key blocks); no atomics. */
+int x2i_attention_bwd_bf16(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dO, const void* dOT, float* lse2,
+                           const float* D, void* dQ, void* dK, void* dV, int32_t B, int32_t H, int32_t S, int32_t Spad, float scale,
+                           x2i_stream_t stream);
+int x2i_attention_bwd_prep_bf16(const void* dO, int64_t do_bs, int32_t lddo, const void* O, int64_t o_bs, int32_t ldo, float* D, int32_t B, int32_t H,
+                                int32_t S, int32_t Spad, x2i_stream_t stream);
 /* -- the trainable side (projector): weight gradients of the layer fusion, gradient clipping, AdamW.  Linear-layer weight gradients are
  * x2i_gemm_bf16 launches on transposed operands (dW = dY^T X). */
 /* conv5x5 (utils/proj.py:50,68-69) weight gradient: partial f32 [C][B][ceil(S/16)][25], dw[c] = sum over [B][chunk] (x2i_reduce_rows_f32) */

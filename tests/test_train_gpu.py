@@ -193,7 +193,8 @@ def _inputs(B, St, h2, w2):
     return hid, enc, pooled, ts, OS.prepare_latent_image_ids(h2, w2), torch.zeros(St, 3)
 
 
-def test_activation_gradient_chain_vs_oracle_autograd_with_explicit_tap_gradients():
+@pytest.mark.parametrize("fused", [True, False])
+def test_activation_gradient_chain_vs_oracle_autograd_with_explicit_tap_gradients(fused):
     """d loss / d encoder_hidden_states and d loss / d pooled_projections for loss = sum over all taps of <tap, G> with random G: the HIP
     chain (bf16 activations, every block's backward) against torch autograd through the fp32 oracle on the same bf16-rounded weights."""
     from oracle import flux as OF
@@ -211,7 +212,7 @@ def test_activation_gradient_chain_vs_oracle_autograd_with_explicit_tap_gradient
     ref_out = OF.flux_forward(sd, cfg, hid.float(), er, pr, ts, ids, tids, taps=taps)
     loss = sum((t * gg.float()).sum() for k in range(3) for t, gg in zip(taps[k], G[k]))
     loss.backward()
-    bw = DistillBackward(m)
+    bw = DistillBackward(m, fused_attention_backward=fused)
     st = bw.prepare_conditioning(enc.to(DEV), pooled.to(DEV), tids.to(DEV), ids.to(DEV))
     out, _ = bw.forward_train(st, hid.to(DEV), ts.to(DEV), tap_grads=[[x.to(DEV) for x in k] for k in G])
     assert rel_l2(out, ref_out.detach()) < 2e-2
@@ -219,7 +220,8 @@ def test_activation_gradient_chain_vs_oracle_autograd_with_explicit_tap_gradient
     assert rel_l2(out, m.denoise(st, hid.to(DEV), ts.to(DEV))) < 1e-2
     d_enc, d_pooled = bw.backward()
     e1, e2 = rel_l2(d_enc, er.grad), rel_l2(d_pooled, pr.grad)
-    print(f"activation-gradient chain (2+2 blocks): d_enc rel-L2 {e1:.3e}, d_pooled rel-L2 {e2:.3e}")
+    print(f"activation-gradient chain (2+2 blocks, {'fused' if fused else 'explicit-matrix'} attention backward): d_enc rel-L2 {e1:.3e}, "
+          f"d_pooled rel-L2 {e2:.3e}")
     assert e1 < 2.5e-2 and e2 < 2.5e-2  # measured 9.6e-3 / 5.4e-3
 
 
@@ -374,3 +376,39 @@ def test_distill_step_end_to_end_loss_decreases_and_matches_autograd():
         losses.append(float(distill_step(tr, chain, g(x), hid.to(DEV), ts.to(DEV), **kw)))
     print("  loss over repeated steps on one batch:", " ".join(f"{v:.4f}" for v in losses))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 200), (2, 3, 192), (1, 1, 64), (1, 2, 333 // 8 * 8)])
+def test_fused_attention_backward_vs_autograd(ops, B, H, S):
+    """x2i_attention_bwd_bf16 (statistics pass, dQ pass, dK / dV pass) against torch autograd through fp32 softmax attention on the same
+    bf16 operands; ragged sequence lengths (S % 64 != 0, S % 128 != 0) exercise the key mask and the row neutralisation."""
+    Spad = ops.pad128(S)
+    scale = 1.0 / math.sqrt(128.0)
+
+    def padded(seed, sc=1.0):
+        t = torch.zeros((B, H, Spad, 128))
+        t[:, :, :S] = seeded((B, H, S, 128), seed, sc)
+        return bf(t)
+    Q, K, V = padded(70), padded(71), padded(72)
+    dO = bf(seeded((B, S, H * 128), 73))
+    q, k, v = (t[:, :, :S].float().requires_grad_(True) for t in (Q, K, V))
+    o = torch.softmax(scale * q @ k.transpose(-1, -2), dim=-1) @ v          # [B,H,S,128]
+    o_tok = o.permute(0, 2, 1, 3).reshape(B, S, H * 128)
+    (o_tok * dO.float()).sum().backward()
+    Qg, Kg, Vg, dOg, Og = g(Q), g(K), g(V), g(dO), g(bf(o_tok.detach()))
+    QT, KT = ops.transpose(Qg.view(B * H, Spad, 128)), ops.transpose(Kg.view(B * H, Spad, 128))
+    dOT = torch.zeros((B * H, 128, Spad), device=DEV, dtype=torch.bfloat16)
+    for b in range(B):
+        ops.transpose(dOg, dOT[b * H:], batch=H, R=S, C=128, in_bs=128, ld_in=H * 128, out_bs=128 * Spad, ld_out=Spad, in_offset=b * S * H * 128)
+    dOh = ops.transpose(dOT)                                                    # [B*H, Spad, 128], zero beyond S
+    Dv = torch.empty((B, H, Spad), device=DEV)
+    ops.attention_bwd_prep(dOg, Og, Dv, B, H, S, Spad, do_bs=S * H * 128, lddo=H * 128, o_bs=S * H * 128, ldo=H * 128)
+    assert rel_l2(Dv[:, :, :S], (o.detach() * dO.float().view(B, S, H, 128).permute(0, 2, 1, 3)).sum(-1)) < 1e-2
+    lse = torch.empty((B, H, Spad), device=DEV)
+    dQ, dK, dV = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse, Dv, dQ, dK, dV, B, H, S, Spad, scale)
+    ref_lse = torch.logsumexp(scale * q.detach() @ k.detach().transpose(-1, -2), dim=-1) * 1.4426950408889634
+    assert rel_l2(lse[:, :, :S], ref_lse) < 1e-4
+    eq, ek, ev = rel_l2(dQ[:, :, :S], q.grad), rel_l2(dK[:, :, :S], k.grad), rel_l2(dV[:, :, :S], v.grad)
+    print(f"fused attention backward B={B} H={H} S={S}: dQ {eq:.3e} dK {ek:.3e} dV {ev:.3e}")
+    assert eq < 1.5e-2 and ek < 1.5e-2 and ev < 1.5e-2

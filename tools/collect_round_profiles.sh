@@ -16,11 +16,15 @@ run_stats() {  # name, command...
 cd "$R"
 python bench.py > "$OUT/${TAG}_bench_b4_1024.json.log" 2>&1
 python bench.py --dtype fp8 --no-cpu-baseline > "$OUT/${TAG}_bench_b4_1024_fp8.json.log" 2>&1
+python bench.py --dtype fp8 --fp8-mode all --no-cpu-baseline > "$OUT/${TAG}_bench_b4_1024_fp8_all.json.log" 2>&1
 python bench.py --config 3 --no-cpu-baseline > "$OUT/${TAG}_bench_config3.json.log" 2>&1
 python bench.py --config 5 --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/${TAG}_bench_config5.json.log" 2>&1
 for b in 1 2 8; do python bench.py --batch $b --no-cpu-baseline > "$OUT/${TAG}_bench_batch$b.json.log" 2>&1; done
 python tools/microbench.py > "$OUT/${TAG}_microbench.log" 2>&1
 python tools/fp8_bench.py > "$OUT/${TAG}_fp8_bench.log" 2>&1
+python tools/conv_bench.py 4 > "$OUT/${TAG}_conv_bench.log" 2>&1
+python tools/attn_bench.py 4 > "$OUT/${TAG}_attn_bench.log" 2>&1
+timeout 600 python tools/train_bench.py 1 2 > "$OUT/${TAG}_train_bench.log" 2>&1
 cd /tmp
 run_stats bench_b4_1024 python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline
 run_stats bench_b4_1024_fp8 python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dtype fp8

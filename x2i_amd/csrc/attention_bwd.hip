@@ -1,0 +1,333 @@
+// Flash-style attention BACKWARD for the distillation step: gradients of
+// O = softmax(scale Q K^T) V with respect to Q, K, V from dO, without materialising the [S, S] matrices.  Same head geometry as the
+// forward kernels (attention.hip: head_dim 128, bf16 operands, fp32 statistics, 64-row streamed tiles through LDS, 32 persistent rows
+// per wave held as MFMA B operands, v_mfma_f32_32x32x16_bf16 with the bit-2/3 row permutation that makes the probability registers
+// the next MFMA's B operand directly).
+//
+// With L2[q] = log2 sum_j exp(scale s_qj) (pass 2 below) and D[q] = sum_d dO[q][d] O[q][d] (attn_bwd_prep_kernel):
+//     P = exp2(scale_log2 S - L2),   dP = dO V^T,   dS = P * (dP - D),   dQ = scale dS K,   dK = scale dS^T Q,   dV = P^T dO
+//
+//   MODE 2  statistics : persistent 128-query block, streams K tiles, online max / sum            -> L2            (1 MFMA group / tile)
+//   MODE 0  dQ         : persistent queries (Q and dO rows as B operands), streams K, V, K^T      -> dQ            (3 groups / tile)
+//   MODE 1  dK, dV     : persistent keys (K and V rows as B operands), streams Q, dO, dO^T, Q^T   -> dV, dK        (4 groups / tile)
+//
+// Two passes over the score matrix instead of atomics on dQ: deterministic, and each pass is the forward kernel's loop with other
+// operands.  Operand layouts: row-major [B,H,Spad,128] for Q, K, V, dO; transposed [B,H,128,Spad] for K^T, Q^T, dO^T -- produced
+// by x2i_transpose_bf16 from what the forward keeps (the transposes are ~1 % of the pass).  Rows >= S are neutralised through the
+// statistics (L2 = +big -> P = 0), keys >= S of the last tile by an explicit mask.
+#include "x2i_common.h"
+#include "x2i_kernels.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int KVB = 64;
+constexpr int TILE = 16384;  // 64 x 128 bf16, either orientation
+constexpr float BIG = 1.0e30f;
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct Geo {
+  int hi, li, k_row_off, k_swz, v_row_off, v_swz;
+};
+
+// A-operand fragments, exactly the forward's addressing: row tile [64 rows][128 d] (group g, fragment f: ds = 2g + (f >> 1), sub-tile f & 1)
+__device__ __forceinline__ bf16x8_t row_frag(const char* tb, const Geo& G, int g, int f) {
+  const int ds = 2 * g + (f >> 1), u = f & 1;
+  return *(const bf16x8_t*)(tb + u * 32 * 256 + G.k_row_off + (((ds * 2 + G.hi) ^ G.k_swz) << 4));
+}
+// transposed tile [128 d][64 rows] (group g = (u, kt), d-block db)
+__device__ __forceinline__ bf16x8_t col_frag(const char* tb, const Geo& G, int g, int db) {
+  const int u = g >> 1, kt = g & 1;
+  return *(const bf16x8_t*)(tb + db * 32 * 128 + G.v_row_off + (((4 * u + 2 * kt + G.hi) ^ G.v_swz) << 4));
+}
+
+// acc[sub-tile] = tile rows x persistent fragments  (the forward's S^T = K Q^T loop)
+__device__ __forceinline__ void score_mma(const char* tb, const Geo& G, const bf16x8_t (&pf)[8], f32x16_t (&acc)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+  bf16x8_t fr[2][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) fr[0][f] = row_frag(tb, G, 0, f);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < 3) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fr[(g + 1) & 1][f] = row_frag(tb, G, g + 1, f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][f], pf[2 * g + (f >> 1)], acc[f & 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// oacc[d-block] += transposed tile x probability-like fragments  (the forward's O^T += V^T P^T loop)
+__device__ __forceinline__ void accum_mma(const char* tb, const Geo& G, const bf16x8_t (&pf)[2][2], f32x16_t (&oacc)[4]) {
+  bf16x8_t fr[2][4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) fr[0][db] = col_frag(tb, G, 0, db);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < 3) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) fr[(g + 1) & 1][db] = col_frag(tb, G, g + 1, db);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][db], pf[g >> 1][g & 1], oacc[db], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ __forceinline__ void pack_frags(const f32x16_t (&a)[2], bf16x8_t (&pf)[2][2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      union { bf16x8_t v; uint32_t w[4]; } cv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cv.w[j] = pack_bf16x2(a[u][kt * 8 + 2 * j], a[u][kt * 8 + 2 * j + 1]);
+      pf[u][kt] = cv.v;
+    }
+}
+// out[row][d] = alpha * acc^T: lane (row = li, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3); half-wave exchange -> 16-byte stores
+__device__ __forceinline__ void store_rows(bf16_t* orow, const f32x16_t (&acc)[4], float alpha, int hi, bool live) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      const uint32_t a0 = pack_bf16x2(acc[db][4 * g] * alpha, acc[db][4 * g + 1] * alpha);
+      const uint32_t a1 = pack_bf16x2(acc[db][4 * g + 2] * alpha, acc[db][4 * g + 3] * alpha);
+      const uint32_t b0 = pack_bf16x2(acc[db][4 * g + 4] * alpha, acc[db][4 * g + 5] * alpha);
+      const uint32_t b1 = pack_bf16x2(acc[db][4 * g + 6] * alpha, acc[db][4 * g + 7] * alpha);
+      const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+      if (live) *(uint4*)(orow + db * 32 + 8 * (g + hi)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ PA, const bf16_t* __restrict__ PB,
+                                                         const bf16_t* __restrict__ TA, const bf16_t* __restrict__ TB,
+                                                         const bf16_t* __restrict__ TC, const bf16_t* __restrict__ TD, float* __restrict__ L2,
+                                                         const float* __restrict__ Dv, bf16_t* __restrict__ OUT0, bf16_t* __restrict__ OUT1,
+                                                         int H, int S, int Spad, float scale, float scale_log2, int nbatch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTILE = MODE == 2 ? 1 : MODE == 0 ? 3 : 4;  // tiles per stage
+  constexpr int STAGE = NTILE * TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Geo G;
+  G.hi = lane >> 5; G.li = lane & 31;
+  {
+    const int kvm = (G.li & 0x13) | ((G.li & 4) << 1) | ((G.li & 8) >> 1);
+    G.k_row_off = kvm * 256; G.k_swz = kvm & 15; G.v_row_off = G.li * 128; G.v_swz = (G.li >> 1) & 7;
+  }
+  const int nblk = Spad / 128;
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int blk = bid % nblk, h = (bid / nblk) % H, b = bid / (nblk * H);
+  const long long bh = (long long)b * H + h;
+  const long long hoff = bh * Spad * 128;
+  const int r0 = blk * 128 + wave * 32 + G.li;   // this lane's persistent row (query in MODE 0 / 2, key in MODE 1)
+
+  bf16x8_t pa[8], pb[8];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) {
+    pa[ds] = *(const bf16x8_t*)(PA + hoff + (long long)r0 * 128 + ds * 16 + G.hi * 8);
+    if (MODE != 2) pb[ds] = *(const bf16x8_t*)(PB + hoff + (long long)r0 * 128 + ds * 16 + G.hi * 8);
+  }
+  float myL = 0.f, myD = 0.f;
+  if (MODE == 0) { myL = L2[bh * Spad + r0]; myD = Dv[bh * Spad + r0]; }
+
+  // DMA source offsets: 1024 chunks per tile, 4 per thread
+  int row_src[4], col_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + tid;
+    { const int row = p >> 4, c = p & 15; row_src[j] = row * 128 + ((c ^ (row & 15)) << 3); }
+    { const int row = p >> 3, c = p & 7; col_src[j] = row * Spad + ((c ^ ((row >> 1) & 7)) << 3); }
+  }
+  auto stage = [&](int buf, int s0) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* dst = base + (j * 256 + wave * 64) * 16;
+      glds16(TA + hoff + (long long)s0 * 128 + row_src[j], dst);
+      if (MODE != 2) {
+        glds16(TB + hoff + (long long)s0 * 128 + row_src[j], dst + TILE);
+        glds16(TC + hoff + s0 + col_src[j], dst + 2 * TILE);
+        if (MODE == 1) glds16(TD + hoff + s0 + col_src[j], dst + 3 * TILE);
+      }
+    }
+  };
+
+  f32x16_t oacc0[4], oacc1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc0[i][r] = 0.f; oacc1[i][r] = 0.f; }
+  float m_run = -BIG, l_run = 0.f;
+
+  const int nt = (S + KVB - 1) / KVB;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1, s0 = t * KVB;
+    if (t + 1 < nt) stage(buf ^ 1, (t + 1) * KVB);
+    const char* base = smem + buf * STAGE;
+    f32x16_t sacc[2], dacc[2];
+    // per streamed row statistics (MODE 1): lane (hi), sub-tile u, reg r <-> row s0 + u*32 + 16*(r>>3) + 8*hi + (r&7)
+    float Lr[2][16], Dr[2][16];
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const long long o = bh * Spad + s0 + u * 32 + 16 * a + 8 * G.hi;
+          const f32x4_t l0 = *(const f32x4_t*)(L2 + o), l1 = *(const f32x4_t*)(L2 + o + 4);
+          const f32x4_t d0 = *(const f32x4_t*)(Dv + o), d1 = *(const f32x4_t*)(Dv + o + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            Lr[u][8 * a + j] = l0[j]; Lr[u][8 * a + 4 + j] = l1[j];
+            Dr[u][8 * a + j] = d0[j]; Dr[u][8 * a + 4 + j] = d1[j];
+          }
+        }
+    }
+    score_mma(base, G, pa, sacc);
+    if (MODE == 2) {
+      // online max / sum of scale_log2 * s over the valid keys
+      float mx = -BIG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
+          sacc[u][r] = key < S ? sacc[u][r] * scale_log2 : -BIG;
+          mx = fmaxf(mx, sacc[u][r]);
+        }
+      mx = xhalf_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      float ps = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(sacc[u][r] - m_new);
+      l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ps;
+      m_run = m_new;
+    } else {
+      score_mma(base + TILE, G, pb, dacc);
+      f32x16_t pv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float p;
+          if (MODE == 0) {
+            const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
+            p = key < S ? __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - myL) : 0.f;
+            dacc[u][r] = p * (dacc[u][r] - myD);
+          } else {
+            p = __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - Lr[u][r]);
+            dacc[u][r] = p * (dacc[u][r] - Dr[u][r]);
+          }
+          pv[u][r] = p;
+        }
+      bf16x8_t dsf[2][2];
+      pack_frags(dacc, dsf);
+      if (MODE == 0) {
+        accum_mma(base + 2 * TILE, G, dsf, oacc0);             // dQ^T += K^T dS^T
+      } else {
+        bf16x8_t pf[2][2];
+        pack_frags(pv, pf);
+        accum_mma(base + 2 * TILE, G, pf, oacc0);              // dV^T += dO^T P
+        accum_mma(base + 3 * TILE, G, dsf, oacc1);             // dK^T += Q^T dS
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (MODE == 2) {
+    l_run = xhalf_sum(l_run);
+    // (both half-waves hold the same row: identical values, either writes)
+    if (G.hi == 0) L2[bh * Spad + r0] = r0 < S ? m_run + __log2f(l_run) : BIG;
+    return;
+  }
+  const bool live = r0 < S;
+  if (MODE == 0) {
+    store_rows(OUT0 + hoff + (long long)r0 * 128, oacc0, scale, G.hi, live);
+  } else {
+    store_rows(OUT0 + hoff + (long long)r0 * 128, oacc0, 1.f, G.hi, live);
+    store_rows(OUT1 + hoff + (long long)r0 * 128, oacc1, scale, G.hi, live);
+  }
+}
+
+// D[b][h][s] = sum_d dO[b][s][h*128 + d] * O[b][s][h*128 + d] for s < S, 0 for the padding rows; 16 lanes x 8 elements per (token, head)
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, long long do_bs, int lddo, const bf16_t* __restrict__ O,
+                                                            long long o_bs, int ldo, float* __restrict__ Dv, int H, int S, int Spad) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  for (int u = threadIdx.x; u < H * 16; u += 256) {
+    const int h = u >> 4, c = u & 15;
+    float acc = 0.f;
+    if (s < S) {
+      const bf16x8_t a = *(const bf16x8_t*)(dO + (long long)b * do_bs + (long long)s * lddo + h * 128 + c * 8);
+      const bf16x8_t o = *(const bf16x8_t*)(O + (long long)b * o_bs + (long long)s * ldo + h * 128 + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(bf16_to_f32((bf16_t)a[j]), bf16_to_f32((bf16_t)o[j]), acc);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (c == 0) Dv[((long long)b * H + h) * Spad + s] = acc;
+  }
+}
+
+}  // namespace
+
+int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dOh, const void* dOT,
+                             float* L2, const float* Dv, void* dQ, void* dK, void* dV, int B, int H, int S, int Spad, float scale,
+                             hipStream_t stream) {
+  if (!Q || !K || !V || !QT || !KT || !dOh || !dOT || !L2 || !Dv || !dQ || !dK || !dV) return x2i_set_error(X2I_ERR_ARG, "attention_bwd: null pointer");
+  if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention_bwd: Spad must be a multiple of 128 and >= S");
+  const uintptr_t all = (uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)QT | (uintptr_t)KT | (uintptr_t)dOh | (uintptr_t)dOT |
+                        (uintptr_t)L2 | (uintptr_t)Dv | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV;
+  if (all & 15) return x2i_set_error(X2I_ERR_ALIGN, "attention_bwd: pointers must be 16-byte aligned");
+  const float scale_log2 = scale * 1.4426950408889634f;
+  dim3 grid((Spad / 128) * H * B);
+  {
+    const int shm = 2 * 1 * TILE;
+    hipLaunchKernelGGL((attn_bwd_kernel<2>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)nullptr, (const bf16_t*)K,
+                       (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)nullptr, (bf16_t*)nullptr, H, S,
+                       Spad, scale, scale_log2, B);
+  }
+  {
+    const int shm = 2 * 3 * TILE;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<0>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_kernel<0>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)dOh, (const bf16_t*)K, (const bf16_t*)V,
+                       (const bf16_t*)KT, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)dQ, (bf16_t*)nullptr, H, S, Spad, scale, scale_log2, B);
+  }
+  {
+    const int shm = 2 * 4 * TILE;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<1>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_kernel<1>), grid, dim3(256), shm, stream, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Q, (const bf16_t*)dOh,
+                       (const bf16_t*)dOT, (const bf16_t*)QT, L2, Dv, (bf16_t*)dV, (bf16_t*)dK, H, S, Spad, scale, scale_log2, B);
+  }
+  return x2i_check_launch("attention_bwd");
+}
+
+int x2i_launch_attention_bwd_prep(const void* dO, long long do_bs, int lddo, const void* O, long long o_bs, int ldo, float* Dv, int B, int H,
+                                  int S, int Spad, hipStream_t stream) {
+  if (!dO || !O || !Dv || B <= 0 || H <= 0 || S <= 0 || Spad < S) return x2i_set_error(X2I_ERR_ARG, "attention_bwd_prep: bad argument");
+  if (lddo % 8 || ldo % 8 || do_bs % 8 || o_bs % 8 || (((uintptr_t)dO | (uintptr_t)O) & 15)) return x2i_set_error(X2I_ERR_ALIGN, "attention_bwd_prep: 16-byte aligned rows");
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Spad, B), dim3(256), 0, stream, (const bf16_t*)dO, do_bs, lddo, (const bf16_t*)O, o_bs, ldo, Dv, H, S, Spad);
+  return x2i_check_launch("attention_bwd_prep");
+}

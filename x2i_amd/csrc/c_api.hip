@@ -314,4 +314,14 @@ int x2i_adamw_bf16(void* p, const float* g, float* m, float* v, int64_t n, float
   return x2i_launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_coef, (hipStream_t)stream);
 }
 
+int x2i_attention_bwd_bf16(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dO, const void* dOT, float* lse2,
+                           const float* D, void* dQ, void* dK, void* dV, int32_t B, int32_t H, int32_t S, int32_t Spad, float scale,
+                           x2i_stream_t stream) {
+  return x2i_launch_attention_bwd(Q, K, V, QT, KT, dO, dOT, lse2, D, dQ, dK, dV, B, H, S, Spad, scale, (hipStream_t)stream);
+}
+int x2i_attention_bwd_prep_bf16(const void* dO, int64_t do_bs, int32_t lddo, const void* O, int64_t o_bs, int32_t ldo, float* D, int32_t B, int32_t H,
+                                int32_t S, int32_t Spad, x2i_stream_t stream) {
+  return x2i_launch_attention_bwd_prep(dO, do_bs, lddo, O, o_bs, ldo, D, B, H, S, Spad, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -77,3 +77,8 @@ int x2i_launch_sum(const void* x, int is_bf16, long long n, int mode, float* par
 int x2i_launch_clip_coef(const float* sumsq, float max_norm, float* out, hipStream_t stream);
 int x2i_launch_adamw(void* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, float bc1,
                      float bc2, const float* coef, hipStream_t stream);
+int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dOh, const void* dOT,
+                             float* L2, const float* Dv, void* dQ, void* dK, void* dV, int B, int H, int S, int Spad, float scale,
+                             hipStream_t stream);
+int x2i_launch_attention_bwd_prep(const void* dO, long long do_bs, int lddo, const void* O, long long o_bs, int ldo, float* Dv, int B, int H,
+                                  int S, int Spad, hipStream_t stream);

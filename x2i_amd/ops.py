@@ -627,3 +627,14 @@ def adamw_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, coef=None):
     check(_lib.load().x2i_adamw_bf16(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                      1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(coef), _stream()), "adamw")
     return p
+
+
+def attention_bwd(Q, K, V, QT, KT, dOh, dOT, lse2, Dv, dQ, dK, dV, B, H, S, Spad, scale):
+    """Fused attention backward (include/x2i.h: x2i_attention_bwd_bf16)."""
+    check(_lib.load().x2i_attention_bwd_bf16(_p(Q), _p(K), _p(V), _p(QT), _p(KT), _p(dOh), _p(dOT), _p(lse2), _p(Dv), _p(dQ), _p(dK), _p(dV), B, H, S,
+                                             Spad, float(scale), _stream()), "attention_bwd")
+
+
+def attention_bwd_prep(dO, O, Dv, B, H, S, Spad, *, do_bs, lddo, o_bs, ldo, do_offset=0, o_offset=0):
+    check(_lib.load().x2i_attention_bwd_prep_bf16(_off(dO, do_offset), do_bs, lddo, _off(O, o_offset), o_bs, ldo, _p(Dv), B, H, S, Spad, _stream()),
+          "attention_bwd_prep")

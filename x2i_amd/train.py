@@ -37,10 +37,13 @@ def _gcd_rows(*ns):
 class DistillBackward:
     """Activation-gradient chain of a frozen x2i_amd FluxTransformer2DModel (see the module docstring)."""
 
-    def __init__(self, model):
+    def __init__(self, model, fused_attention_backward=True):
         self.m = model
         self.WT = {}
         self.saved = None
+        # True: x2i_attention_bwd_bf16 (flash-style, no [S, S] matrices); False: the explicit-matrix form built from GEMM launches and
+        # row kernels (kept as the A/B reference: both are tested against autograd)
+        self.fused_attention_backward = fused_attention_backward
 
     # ------------------------------------------------------------------ frozen weights, transposed once
     @torch.no_grad()
@@ -137,6 +140,7 @@ class DistillBackward:
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=OP, M=St, batch=B, a_batch_stride=S * D, lda=D,
                      c_batch_stride=S * D, ldc=D)
+            sv["O"] = ATT.clone()                                # attention output (rowsum(dO * O) of the fused attention backward)
             sv["Gimg"] = tap(0, i, OP, Si, D, offset_rows=St)   # reference lists[0]: image-stream attention output
             sv["Gtxt"] = tap(1, i, OP, St, D, offset_rows=0)    # lists[1]: text-stream attention output
             ops.gated_residual_(X, OP, mod(oi + 2 * D), B, Si, D, S * D, D, S * D, D, Ntot, x_offset=St * D, t_offset=St * D)
@@ -171,6 +175,7 @@ class DistillBackward:
             ops.gemm(NRM, w, bias, out=IN, M=B * S)
             ops.qkv_split(None, IN, 7 * D, 7 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
             ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+            sv["O"] = CAT.view(B, S, 5 * D)[:, :, :D].contiguous()
             sv["G"] = tap(2, i, CAT.view(B, S, 5 * D), S, 5 * D)   # lists[2]: the un-projected joint attention output
             # GELU(proj_mlp) into CAT[:, D:]: one elementwise pass through the GEMM epilogue is not available here, so the kernel that
             # owns the activation (x2i_gemm_bf16 with act) recomputes that slice from NRM -- the saved pre-activation stays exact
@@ -194,7 +199,7 @@ class DistillBackward:
 
     # ------------------------------------------------------------------ backward pieces
     @torch.no_grad()
-    def _attention_bwd(self, qkv0, qkv1, ld, S0, norms, dATT, ld_datt, dQKV0, dQKV1):
+    def _attention_bwd(self, qkv0, qkv1, ld, S0, norms, dATT, ld_datt, dQKV0, dQKV1, O=None):
         """d(q|k|v rows) from d(attention output) [B, S, *] (row stride ld_datt): recompute Q / K / V^T, then per sample the explicit
         P = softmax(scale Q K^T), dP = dO V^T, dS, dQ = dS K, dK = dS^T Q, dV = P^T dO -- all x2i_gemm_bf16 launches."""
         sv = self.saved
@@ -209,6 +214,27 @@ class DistillBackward:
         nq0, nk0, nq1, nk1 = norms
         ops.qkv_split(qkv0, qkv1, ld, ld, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, Q, K, VT, Spad)
         scale = 1.0 / math.sqrt(128.0)
+        if self.fused_attention_backward and O is not None:
+            w2 = self.__dict__.get("_attn_ws2")
+            if w2 is None or w2["key"] != (B, H, Spad):
+                hm = lambda: torch.empty((B * H, Spad, 128), **bf)  # noqa: E731
+                tm = lambda: torch.empty((B * H, 128, Spad), **bf)  # noqa: E731
+                w2 = dict(key=(B, H, Spad), V=hm(), QT=tm(), KT=tm(), dOT=torch.zeros((B * H, 128, Spad), **bf), dOh=hm(), dQ=hm(), dK=hm(), dV=hm(),
+                          D=torch.empty((B, H, Spad), device=dev, dtype=torch.float32), L=torch.empty((B, H, Spad), device=dev, dtype=torch.float32))
+                self._attn_ws2 = w2
+            BH = B * H
+            ops.transpose(VT, w2["V"], batch=BH, R=128, C=Spad, in_bs=128 * Spad, ld_in=Spad, out_bs=Spad * 128, ld_out=128)
+            ops.transpose(Q, w2["QT"], batch=BH, R=Spad, C=128, in_bs=Spad * 128, ld_in=128, out_bs=128 * Spad, ld_out=Spad)
+            ops.transpose(K, w2["KT"], batch=BH, R=Spad, C=128, in_bs=Spad * 128, ld_in=128, out_bs=128 * Spad, ld_out=Spad)
+            for b in range(B):  # token-major d(attention output) -> per-head transposed and row-major copies (zero beyond S)
+                ops.transpose(dATT, w2["dOT"][b * H:], batch=H, R=S, C=128, in_bs=128, ld_in=ld_datt, out_bs=128 * Spad, ld_out=Spad,
+                              in_offset=b * S * ld_datt)
+            ops.transpose(w2["dOT"], w2["dOh"], batch=BH, R=128, C=Spad, in_bs=128 * Spad, ld_in=Spad, out_bs=Spad * 128, ld_out=128)
+            ops.attention_bwd_prep(dATT, O, w2["D"], B, H, S, Spad, do_bs=S * ld_datt, lddo=ld_datt, o_bs=S * O.shape[-1], ldo=O.shape[-1])
+            ops.attention_bwd(Q, K, w2["V"], w2["QT"], w2["KT"], w2["dOh"], w2["dOT"], w2["L"], w2["D"], w2["dQ"], w2["dK"], w2["dV"], B, H, S,
+                              Spad, scale)
+            ops.qkv_split_bwd(qkv0, qkv1, ld, ld, dQKV0, dQKV1, ld, ld, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, w2["dQ"], w2["dK"], w2["dV"], Spad)
+            return
         big = self.__dict__.get("_attn_ws")
         if big is None or big["key"] != (H, Spad):
             big = dict(key=(H, Spad), P=torch.empty((H, Spad, Spad), **bf), dP=torch.empty((H, Spad, Spad), **bf),
@@ -302,7 +328,7 @@ class DistillBackward:
             # d proj_mlp pre-activation -> columns [3D, 7D) of dIN
             dIN.view(B * S, 7 * D)[:, 3 * D:].copy_(dCAT.view(B * S, 5 * D)[:, D:])
             ops.act_bwd_(dIN, s_["IN"], ACT_GELU_TANH, rows=B * S, cols=4 * D, ldd=7 * D, ldp=7 * D, d_offset=3 * D, p_offset=3 * D)
-            self._attention_bwd(None, s_["IN"], 7 * D, 0, (None, None, f[p + ".norm_q"], f[p + ".norm_k"]), dCAT, 5 * D, None, dIN)
+            self._attention_bwd(None, s_["IN"], 7 * D, 0, (None, None, f[p + ".norm_q"], f[p + ".norm_k"]), dCAT, 5 * D, None, dIN, O=s_["O"])
             ops.gemm(dIN, self._wt(p + ".in.w"), out=dN, M=B * S)
             ln_bwd(s_["Xin"], o + D, o, 0, S)
             del dCAT, dIN
@@ -340,7 +366,7 @@ class DistillBackward:
             img = B * St * 3 * D
             self._attention_bwd(d_["QKV"], d_["QKV"].view(-1)[img:], 3 * D, St,
                                 (f[p + ".norm_added_q"], f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"]), dATT, D, dQKV,
-                                dQKV.view(-1)[img:])
+                                dQKV.view(-1)[img:], O=d_["O"])
             ops.gemm(dQKV, self._wt(p + ".qkv.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 3 * D, lda=3 * D, a_offset=img,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(dQKV, self._wt(p + ".cqkv.w"), out=dN, M=St, batch=B, a_batch_stride=St * 3 * D, lda=3 * D, c_batch_stride=S * D, ldc=D)
