@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from x2i_amd import _lib, ops  # noqa: E402
 
 

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from x2i_amd.flux import FluxTransformer2DModel  # noqa: E402
 from x2i_amd.proj import create_proj3_qwen3b  # noqa: E402
 from x2i_amd.train import DistillBackward, ProjectorTrainer  # noqa: E402

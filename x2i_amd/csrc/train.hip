@@ -304,16 +304,34 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
-// out[z][i] (op)= sum_{p < np} in[z][p][i]   (second stage of every column sum); accumulate != 0: add to what is there
+// out[z][i] (op)= sum_{p < np} in[z][p][i]   (second stage of every column sum); accumulate != 0: add to what is there.
+// A block owns 64 consecutive i and splits the partial rows over its 4 waves (fixed order: deterministic), four loads in flight per lane.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, long long in_zs, int np, long long in_ps, float* __restrict__ out,
                                                           long long out_zs, int len, int accumulate, float alpha) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= len) return;
-  const float* p = in + (long long)blockIdx.y * in_zs + i;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int k = 0; k < np; ++k) s += p[(long long)k * in_ps];
-  float* o = out + (long long)blockIdx.y * out_zs + i;
-  *o = accumulate ? *o + alpha * s : alpha * s;
+  if (i < len) {
+    const float* p = in + (long long)blockIdx.y * in_zs + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = w;
+    for (; k + 12 < np; k += 16) {
+      s0 += p[(long long)k * in_ps];
+      s1 += p[(long long)(k + 4) * in_ps];
+      s2 += p[(long long)(k + 8) * in_ps];
+      s3 += p[(long long)(k + 12) * in_ps];
+    }
+    for (; k < np; k += 4) s0 += p[(long long)k * in_ps];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < len) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float* o = out + (long long)blockIdx.y * out_zs + i;
+    *o = accumulate ? *o + alpha * t : alpha * t;
+  }
 }
 
 // d(pre) = d(act) * act'(pre), written over d(act); rows x cols with independent row strides
@@ -800,7 +818,7 @@ int x2i_launch_gate_bwd(const void* dX, long long dx_bs, int lddx, const void* T
 int x2i_launch_reduce_rows(const float* in, long long in_zs, int np, long long in_ps, float* out, long long out_zs, int nz, int len,
                            int accumulate, float alpha, hipStream_t stream) {
   if (!in || !out || np <= 0 || nz <= 0 || len <= 0) return x2i_set_error(X2I_ERR_ARG, "reduce_rows: bad argument");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((len + 255) / 256, nz), dim3(256), 0, stream, in, in_zs, np, in_ps, out, out_zs, len, accumulate, alpha);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((len + 63) / 64, nz), dim3(256), 0, stream, in, in_zs, np, in_ps, out, out_zs, len, accumulate, alpha);
   return x2i_check_launch("reduce_rows");
 }
 

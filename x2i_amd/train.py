@@ -27,7 +27,8 @@ from .ops import ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_SILU
 
 
 def _gcd_rows(*ns):
-    g = 32
+    """rows per wave of the two-stage column-sum kernels: a divisor of every segment length, small enough that B * S / R waves fill the chip"""
+    g = 8
     for n in ns:
         if n:
             g = math.gcd(g, n)
