@@ -531,8 +531,8 @@ class ProjectorTrainer:
         [clip coefficient, gradient norm]."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1:
-            dist.all_reduce(self.grad, group=self.pg)
-            ops.reduce_rows(self.grad.clone(), self.grad, np_=1, len_=self.grad.numel(), alpha=1.0 / dist.get_world_size(self.pg))
+            dist.all_reduce(self.grad, group=self.pg)  # one flat buffer: a single RCCL ring all-reduce per step
+            ops.reduce_rows(self.grad, self.grad, np_=1, len_=self.grad.numel(), alpha=1.0 / dist.get_world_size(self.pg))  # in place: mean
         coef = ops.clip_coef(ops.sum_all(self.grad, squares=True), self.max_norm)
         self.step_count += 1
         for n, p in zip(self.names, self.params):
