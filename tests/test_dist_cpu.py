@@ -97,3 +97,57 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _ts_worker(rank, world, port, q):
+    """4 ranks on one node, 2 teacher ranks: groups [0, 1] and [2, 3] (reference new_infer_pg / new_train_pg with
+    local_infer_world_size = 2), then the two exchanges of the distillation step and the trainers' gradient all-reduce."""
+    import torch.distributed as dist
+    from x2i_amd import dist as xd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = xd.TeacherStudentGroups(rank, world, local_world_size=4, local_infer_world_size=2, backend="gloo")
+        prompts = torch.full((2, 3), float(rank))
+        got = xd.send_to_infer_device(prompts, g)
+        teacher = None
+        if g.is_infer_rank:
+            teacher = torch.cat([got * 10 + 1])          # "teacher tensors" computed from the trainers' prompts
+        mine = xd.receive_from_infer_device(teacher if g.is_infer_rank else torch.empty((2, 3)), g)
+        grad = torch.full((5,), float(rank))
+        if not g.is_infer_rank:
+            dist.all_reduce(grad, group=g.train_pg)
+        q.put((rank, g.infer_ranks, g.infer_rank, g.is_infer_rank, g.train_ranks, None if got is None else got.tolist(),
+               None if mine is None else mine.tolist(), grad.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_teacher_student_groups_gather_scatter_and_train_group():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ts_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(4))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, infer_ranks, infer_rank, is_infer, train_ranks, got, mine, grad in res:
+        assert infer_ranks == ([0, 1] if rank < 2 else [2, 3]) and infer_rank == infer_ranks[0] and is_infer == (rank in (0, 2))
+        assert train_ranks == [1, 3]
+        if is_infer:
+            assert got == [[float(rank + 1)] * 3] * 2 and mine is None       # the teacher received its trainer's prompts
+            assert grad == [float(rank)] * 5                                    # and takes no part in the gradient all-reduce
+        else:
+            assert got is None and mine == [[float(rank) * 10 + 1] * 3] * 2    # the trainer got the tensors computed from ITS prompts
+            assert grad == [4.0] * 5                                            # 1 + 3 over the train group
+
+
+def test_teacher_student_groups_reject_a_teacher_without_trainers():
+    import pytest
+    from x2i_amd import dist as xd
+    with pytest.raises(ValueError):
+        xd.TeacherStudentGroups(0, 4, local_world_size=4, local_infer_world_size=4)

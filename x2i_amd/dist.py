@@ -78,3 +78,78 @@ def sample_sharded(pipeline, prompt_embeds, pooled_prompt_embeds, latents=None, 
     else:  # more ranks than samples: contribute an empty shard
         local = latents.new_zeros((0,) + tuple(latents.shape[1:]))
     return all_gather_batch(local, total, group)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training ranks / teacher ranks (row N4; reference core/pipeline/train_and_infer.py:31-122).  The reference dedicates the first rank
+# of every `infer group` of a node to the frozen teacher pipeline: the group's other ranks (the trainers) send it their prompts, it runs
+# the teacher and hands every trainer its slice of the teacher tensors; the trainers form the data-parallel group of the projector.
+# On MI355X the 8 GPUs of a node are fully connected point to point, so both exchanges are issued as direct sends / receives between the
+# teacher rank and each trainer (one xGMI link each, all in flight together) instead of a rooted collective.
+class TeacherStudentGroups:
+    """Rank layout of one job: `local_infer_world_size` teacher ranks per node, each serving a contiguous group of
+    ceil(local_world_size / local_infer_world_size) ranks whose first member is the teacher.  Attributes: infer_ranks (this rank's group),
+    infer_rank (its teacher), is_infer_rank, train_ranks (all trainers of the job), infer_pg / train_pg (process groups; every rank must
+    construct this object, as with any dist.new_group)."""
+
+    def __init__(self, rank, world_size, local_world_size, local_infer_world_size=1, backend=None):
+        if world_size % local_world_size:
+            raise ValueError("world_size must be a multiple of local_world_size")
+        per = -(-local_world_size // local_infer_world_size)
+        if per < 2:
+            raise ValueError("every teacher rank needs at least one trainer: ceil(local_world_size / local_infer_world_size) must be > 1")
+        self.rank, self.world_size = rank, world_size
+        groups = []
+        for node in range(world_size // local_world_size):
+            ranks = list(range(node * local_world_size, (node + 1) * local_world_size))
+            for g in range(local_infer_world_size):
+                grp = ranks[g * per:(g + 1) * per]
+                if len(grp) < 2:
+                    raise ValueError(f"infer group {grp} has no trainer (local_world_size={local_world_size}, local_infer_world_size={local_infer_world_size})")
+                groups.append(grp)
+        self.groups = groups
+        teachers = [g[0] for g in groups]
+        self.train_ranks = sorted(set(range(world_size)) - set(teachers))
+        self.infer_pg, self.infer_ranks = None, None
+        for grp in groups:   # every rank creates every group, in the same order
+            pg = dist.new_group(ranks=grp, backend=backend)
+            if rank in grp:
+                self.infer_pg, self.infer_ranks = pg, grp
+        self.train_pg = dist.new_group(ranks=self.train_ranks, backend=backend)
+        self.infer_rank = self.infer_ranks[0]
+        self.is_infer_rank = rank == self.infer_rank
+
+    @property
+    def trainers(self):
+        return self.infer_ranks[1:]
+
+
+def _wait_all(reqs):
+    for r in reqs:
+        r.wait()
+
+
+def send_to_infer_device(data, groups):
+    """Trainers -> teacher (reference send_to_infer_device): every trainer passes its tensor; the teacher passes a tensor of the per-rank
+    shape (only shape / dtype / device are used) and receives the trainers' tensors concatenated along dim 0 in rank order; trainers get
+    None."""
+    if groups.is_infer_rank:
+        n = len(groups.trainers)
+        out = torch.empty((n * data.shape[0],) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
+        _wait_all([dist.irecv(c, src=r) for c, r in zip(out.chunk(n, dim=0), groups.trainers)])
+        return out
+    dist.isend(data.contiguous(), dst=groups.infer_rank).wait()
+    return None
+
+
+def receive_from_infer_device(data, groups):
+    """Teacher -> trainers (reference receive_from_infer_device): the teacher passes the concatenation (dim 0, trainer order) of what each
+    trainer is to get; a trainer passes a tensor of its slice's shape to receive into.  Returns the trainer's slice (None on the teacher)."""
+    if groups.is_infer_rank:
+        n = len(groups.trainers)
+        if data.shape[0] % n:
+            raise ValueError(f"receive_from_infer_device: dim 0 ({data.shape[0]}) is not a multiple of the {n} trainers")
+        _wait_all([dist.isend(c.contiguous(), dst=r) for c, r in zip(data.chunk(n, dim=0), groups.trainers)])
+        return None
+    dist.irecv(data, src=groups.infer_rank).wait()
+    return data

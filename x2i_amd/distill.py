@@ -12,8 +12,8 @@ What the reference's training step needs from the diffusion transformer, and wha
     (train/train_qwenvl.py:626 `loss.backward()` with only proj_t5 trainable).  That chain, the loss kernel, the projector's
     backward, gradient clipping and AdamW live in x2i_amd/train.py (`DistillBackward`, `ProjectorTrainer`, `distill_step`) on the
     HIP path; `teacher_student_loss` below is the forward-only helper (loss value from two hooked forwards).
-The gather / scatter of teacher tensors between inference and training ranks (core/pipeline/train_and_infer.py:80-122) is
-torch.distributed plumbing outside the hot path and is not restated.
+The gather / scatter of prompts and teacher tensors between teacher ranks and training ranks (core/pipeline/train_and_infer.py:31-122)
+is x2i_amd/dist.py (`TeacherStudentGroups`, `send_to_infer_device`, `receive_from_infer_device`).
 """
 import torch
 import torch.nn.functional as F
