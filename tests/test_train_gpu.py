@@ -412,3 +412,43 @@ def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     eq, ek, ev = rel_l2(dQ[:, :, :S], q.grad), rel_l2(dK[:, :, :S], k.grad), rel_l2(dV[:, :, :S], v.grad)
     print(f"fused attention backward B={B} H={H} S={S}: dQ {eq:.3e} dK {ek:.3e} dV {ev:.3e}")
     assert eq < 1.5e-2 and ek < 1.5e-2 and ev < 1.5e-2
+
+
+def test_full_width_distillation_gradient_vs_oracle_autograd():
+    """D = 3072, 24 heads, one double + one single block on 512 + 1024 tokens, B = 2: the training chain at the real GEMM / attention
+    shapes (256^2 MFMA kernels in the dgrad launches, the fused attention backward at S = 1536, the 43 008-row modulation table) with
+    the reference's loss against teacher tensors -- loss value and d loss / d encoder_hidden_states, d loss / d pooled against torch
+    autograd through the fp32 oracle."""
+    from oracle import flux as OF
+    from oracle import sampler as OS
+    from x2i_amd.distill import kd_attention_loss
+    from x2i_amd.flux import FluxTransformer2DModel
+    from x2i_amd.train import DistillBackward
+    cfg = dict(OF.DEFAULT_CFG)
+    cfg.update(num_layers=1, num_single_layers=1)
+    sd = OF.random_flux_state_dict(cfg, seed=21, std=0.02)
+    m = FluxTransformer2DModel(**cfg, device=DEV)
+    m.load_state_dict({k: v.bfloat16() for k, v in sd.items()}, strict=True)
+    sdf = {k: v.bfloat16().float() for k, v in sd.items()}
+    B = 2
+    hidden, enc, pooled = bf(seeded((B, 1024, 64), 1)), bf(seeded((B, 512, 4096), 2)), bf(seeded((B, 768), 3))
+    enc_t, pooled_t = bf(seeded((B, 512, 4096), 4)), bf(seeded((B, 768), 5))
+    ts = torch.tensor([0.5, 0.25])  # t * 1000 is formed in the latents' dtype (lightcontrol_flux.py:447): values exact in bf16, as the fp32 oracle sees them
+    img_ids, txt_ids = OS.prepare_latent_image_ids(32, 32), torch.zeros(512, 3)
+    tt = [[], [], []]
+    with torch.no_grad():
+        OF.flux_forward(sdf, cfg, hidden.float(), enc_t.float(), pooled_t.float(), ts, img_ids, txt_ids, taps=tt)
+    teacher = [torch.stack(k, dim=1).bfloat16() for k in tt]
+    er, pr = enc.float().requires_grad_(True), pooled.float().requires_grad_(True)
+    taps = [[], [], []]
+    OF.flux_forward(sdf, cfg, hidden.float(), er, pr, ts, img_ids, txt_ids, taps=taps)
+    ref_loss = kd_attention_loss([t.float() for t in teacher], [torch.stack(k, dim=1) for k in taps])
+    ref_loss.backward()
+    bw = DistillBackward(m)
+    st = bw.prepare_conditioning(enc.to(DEV), pooled.to(DEV), txt_ids.to(DEV), img_ids.to(DEV))
+    _, loss = bw.forward_train(st, hidden.to(DEV), ts.to(DEV), teacher=[t.to(DEV) for t in teacher])
+    d_enc, d_pooled = bw.backward()
+    e1, e2 = rel_l2(d_enc, er.grad), rel_l2(d_pooled, pr.grad)
+    print(f"full-width 1+1 blocks, B=2: loss {float(loss):.5f} vs {float(ref_loss.detach()):.5f}; d_enc rel-L2 {e1:.3e}, d_pooled rel-L2 {e2:.3e}")
+    assert abs(float(loss) - float(ref_loss.detach())) < 1e-3 * abs(float(ref_loss.detach()))   # measured 250.90887 vs 250.90886
+    assert e1 < 1.5e-2 and e2 < 1.5e-2                                                          # measured 3.8e-3 / 4.0e-4
