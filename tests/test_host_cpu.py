@@ -209,3 +209,15 @@ def test_c_abi_argument_validation_returns_codes_without_a_gpu():
     assert lib.x2i_timestep_sinusoid(fake, fake, 1, 255, 0, None) < 0
     assert lib.x2i_conv_stem_bf16(None, None, None, None, 1, 8, 8, 64, None) < 0
     assert lib.x2i_abi_version() >= 1
+
+
+def test_training_harness_arguments_and_schedules():
+    """x2i_amd.train_distill: the reference's argument names / defaults (train/train_qwenvl.py:63-167) and the lr schedule factors."""
+    from x2i_amd import train_distill as TD
+    a = TD.parse_args([])
+    assert (a.learning_rate, a.adam_beta1, a.adam_beta2, a.adam_weight_decay, a.adam_epsilon, a.max_grad_norm) == (1e-4, 0.9, 0.999, 1e-2, 1e-8, 1.0)
+    assert (a.max_train_steps, a.checkpointing_steps, a.gradient_accumulation_steps, a.lr_scheduler, a.lr_warmup_steps) == (200000, 500, 1, "constant", 500)
+    assert TD.lr_factor("constant", 7, 500, 1000) == 1.0
+    assert TD.lr_factor("constant_with_warmup", 250, 500, 1000) == 0.5 and TD.lr_factor("constant_with_warmup", 900, 500, 1000) == 1.0
+    assert abs(TD.lr_factor("linear", 750, 500, 1000) - 0.5) < 1e-12 and TD.lr_factor("linear", 1000, 500, 1000) == 0.0
+    assert abs(TD.lr_factor("cosine", 750, 500, 1000) - 0.5) < 1e-12 and abs(TD.lr_factor("cosine", 500, 500, 1000) - 1.0) < 1e-12

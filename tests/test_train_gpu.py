@@ -452,3 +452,19 @@ def test_full_width_distillation_gradient_vs_oracle_autograd():
     print(f"full-width 1+1 blocks, B=2: loss {float(loss):.5f} vs {float(ref_loss.detach()):.5f}; d_enc rel-L2 {e1:.3e}, d_pooled rel-L2 {e2:.3e}")
     assert abs(float(loss) - float(ref_loss.detach())) < 1e-3 * abs(float(ref_loss.detach()))   # measured 250.90887 vs 250.90886
     assert e1 < 1.5e-2 and e2 < 1.5e-2                                                          # measured 3.8e-3 / 4.0e-4
+
+
+def test_training_harness_synthetic_tiny_writes_loadable_checkpoints(tmp_path):
+    """x2i_amd.train_distill (counterpart of the reference's training loop): a few synthetic steps with gradient accumulation, warm-up
+    schedule and checkpointing; the written .bin is the projector state dict the inference loaders accept."""
+    from x2i_amd import train_distill as TD
+    from x2i_amd.checkpoints import load_projector_checkpoint
+    losses = TD.main(["--synthetic", "--tiny", "--batch_size", "2", "--max_train_steps", "4", "--gradient_accumulation_steps", "2",
+                      "--checkpointing_steps", "2", "--lr_scheduler", "constant_with_warmup", "--lr_warmup_steps", "2", "--learning_rate", "1e-3",
+                      "--output_dir", str(tmp_path), "--seed", "1"])
+    assert len(losses) == 4 and all(math.isfinite(v) for v in losses)
+    for step in (2, 4):
+        f = tmp_path / str(step) / "diffusion_pytorch_model.bin"
+        assert f.exists()
+    pr = load_projector_checkpoint(str(tmp_path / "4" / "diffusion_pytorch_model.bin"), device=DEV, in_channels=5)
+    assert pr.use_cnn and pr.conv.weight.shape == (1, 5, 5, 5)
