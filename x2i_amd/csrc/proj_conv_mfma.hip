@@ -95,6 +95,29 @@ struct StageSrc {
   uint32_t plane_bytes;    // S * H * 2
 };
 
+// byte offset of chunk q (8 columns from h0 - 8 + 8 q) of staged row R (token s0 - 2 + R) inside one layer's plane, or OOB (zero fill)
+__device__ __forceinline__ uint32_t chunk_src(int R, int q, int s0, int h0, int S, int H, int rows) {
+  const int s = s0 - 2 + R, h = h0 - 8 + 8 * q;
+  return (R < rows && s >= 0 && s < S && h >= 0 && h < H) ? (uint32_t)(((long long)s * H + h) * 2) : OOB;
+}
+// this lane's DMA sources of the 16-row forms: the wave's two main pieces (piece p = rows 2p, 2p + 1: lane -> row 2p + (lane >> 5), slot
+// lane & 31 holds chunk slot ^ (R & 15)) and the halo piece ([layer = lane >> 5][row = (lane & 31) >> 1][chunk 32 + (lane & 1)])
+__device__ __forceinline__ StageSrc make_stage_src(int wave, int lane, int s0, int h0, int S, int H) {
+  StageSrc src;
+  src.plane_bytes = (uint32_t)((long long)S * H * 2);
+  const int R0 = 2 * (2 * wave) + (lane >> 5), R1 = 2 * (2 * wave + 1) + (lane >> 5), slot = lane & 31;
+  src.main0 = chunk_src(R0, slot ^ (R0 & 15), s0, h0, S, H, PR);
+  src.main1 = chunk_src(R1, slot ^ (R1 & 15), s0, h0, S, H, PR);
+  src.tail = chunk_src((lane & 31) >> 1, 32 + (lane & 1), s0, h0, S, H, PR);
+  return src;
+}
+// LDS offset of the X fragment of tile t = 4 wave + tt for row block `blk` (rows 12 blk ...): lane (R, g = lane >> 4) reads chunk 2t + g;
+// chunks 32, 33 live in the halo piece at tail_off ([row][2 chunks])
+__device__ __forceinline__ uint32_t frag_off(int wave, int lane, int tt, int blk, uint32_t tail_off) {
+  const int R = 12 * blk + (lane & 15), q = 2 * (4 * wave + tt) + (lane >> 4);
+  return q < 32 ? (uint32_t)(R * 512 + ((q ^ (R & 15)) * 16)) : tail_off + (uint32_t)(R * 32 + (q - 32) * 16);
+}
+
 // LDS-DMA of stage `st` (layers st * PCS ...) into dst: per wave 4 main pieces, 2-3 Toeplitz pieces, wave 3 the halo piece
 template <int PCS>
 __device__ __forceinline__ void issue_stage(char* __restrict__ dst, int st, int C, __amdgpu_buffer_rsrc_t xr, __amdgpu_buffer_rsrc_t tr,
@@ -171,27 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv5x5_mfma_kernel(const bf16_t* __re
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)(C * plane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, C * 5 * 1024, 0x00020000);
 
-  StageSrc src;
-  src.plane_bytes = (uint32_t)(plane * 2);
-  {
-    auto off = [&](int R, int q) -> uint32_t {
-      const int s = s0 - 2 + R, h = h0 - 8 + 8 * q;
-      return (s >= 0 && s < S && h >= 0 && h < H) ? (uint32_t)(((long long)s * H + h) * 2) : OOB;
-    };
-    // main piece p covers rows 2p, 2p + 1: lane -> row 2p + (lane >> 5), slot lane & 31 holds chunk slot ^ (R & 15)
-    const int R0 = 2 * (2 * wave) + (lane >> 5), R1 = 2 * (2 * wave + 1) + (lane >> 5), slot = lane & 31;
-    src.main0 = off(R0, slot ^ (R0 & 15));
-    src.main1 = off(R1, slot ^ (R1 & 15));
-    // halo piece: [layer = lane >> 5][row = (lane & 31) >> 1][chunk 32 + (lane & 1)]
-    src.tail = off((lane & 31) >> 1, 32 + (lane & 1));
-  }
-  // X fragment of tile t = 4 wave + tt: lane (R = lane & 15, g = lane >> 4) reads chunk q = 2t + g of row R
+  const StageSrc src = make_stage_src(wave, lane, s0, h0, S, H);
   uint32_t xoff[4];
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const int R = lane & 15, q = 2 * (4 * wave + tt) + (lane >> 4);
-    xoff[tt] = q < 32 ? (uint32_t)(R * 512 + ((q ^ R) * 16)) : (uint32_t)(PCS * P_CH + R * 32 + (q - 32) * 16);
-  }
+  for (int tt = 0; tt < 4; ++tt) xoff[tt] = frag_off(wave, lane, tt, 0, PCS * P_CH);
   pf32x4_t acc[5][4];
 #pragma unroll
   for (int ds = 0; ds < 5; ++ds)
@@ -279,24 +285,10 @@ __global__ __launch_bounds__(256, 2) void conv5x5_mfma_pipe_kernel(const bf16_t*
   const bf16_t* xb = x + (long long)b * C * plane;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)(C * plane * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, C * 5 * 1024, 0x00020000);
-  StageSrc src;
-  src.plane_bytes = (uint32_t)(plane * 2);
-  {
-    auto off = [&](int R, int q) -> uint32_t {
-      const int s = s0 - 2 + R, h = h0 - 8 + 8 * q;
-      return (s >= 0 && s < S && h >= 0 && h < H) ? (uint32_t)(((long long)s * H + h) * 2) : OOB;
-    };
-    const int R0 = 2 * (2 * wave) + (lane >> 5), R1 = 2 * (2 * wave + 1) + (lane >> 5), slot = lane & 31;
-    src.main0 = off(R0, slot ^ (R0 & 15));
-    src.main1 = off(R1, slot ^ (R1 & 15));
-    src.tail = off((lane & 31) >> 1, 32 + (lane & 1));
-  }
+  const StageSrc src = make_stage_src(wave, lane, s0, h0, S, H);
   uint32_t xoff[4];
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const int R = lane & 15, q = 2 * (4 * wave + tt) + (lane >> 4);
-    xoff[tt] = q < 32 ? (uint32_t)(R * 512 + ((q ^ R) * 16)) : (uint32_t)(P_CH + R * 32 + (q - 32) * 16);
-  }
+  for (int tt = 0; tt < 4; ++tt) xoff[tt] = frag_off(wave, lane, tt, 0, P_CH);
   pf32x4_t acc[5][4];
 #pragma unroll
   for (int ds = 0; ds < 5; ++ds)
@@ -441,26 +433,17 @@ __global__ __launch_bounds__(256, 2) void conv5x5_mfma_rb2_kernel(const bf16_t* 
   const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, C * 5 * 1024, 0x00020000);
   Stage2Src src;
   src.plane_bytes = (uint32_t)(plane * 2);
-  {
-    auto off = [&](int R, int q) -> uint32_t {
-      const int s = s0 - 2 + R, h = h0 - 8 + 8 * q;
-      return (R < R2 && s >= 0 && s < S && h >= 0 && h < H) ? (uint32_t)(((long long)s * H + h) * 2) : OOB;
-    };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int R = 2 * (wave + 4 * i) + (lane >> 5), slot = lane & 31;
-      src.main[i] = off(R, slot ^ (R & 15));
-    }
-    src.tail = off(lane >> 1, 32 + (lane & 1));  // halo piece: [row = lane >> 1][chunk 32 + (lane & 1)], rows >= 28 zero fill
+  for (int i = 0; i < 4; ++i) {
+    const int R = 2 * (wave + 4 * i) + (lane >> 5), slot = lane & 31;
+    src.main[i] = chunk_src(R, slot ^ (R & 15), s0, h0, S, H, R2);
   }
+  src.tail = chunk_src(lane >> 1, 32 + (lane & 1), s0, h0, S, H, R2);  // halo piece: [row = lane >> 1][chunk 32 + (lane & 1)], rows >= 28 zero fill
   uint32_t xoff[2][4];
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int R = 12 * blk + (lane & 15), q = 2 * (4 * wave + tt) + (lane >> 4);
-      xoff[blk][tt] = q < 32 ? (uint32_t)(R * 512 + ((q ^ (R & 15)) * 16)) : (uint32_t)(P2_TAIL_OFF + R * 32 + (q - 32) * 16);
-    }
+    for (int tt = 0; tt < 4; ++tt) xoff[blk][tt] = frag_off(wave, lane, tt, blk, P2_TAIL_OFF);
   pf32x4_t acc[2][5][4];
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk)

@@ -48,16 +48,12 @@ class DistillBackward:
 
     # ------------------------------------------------------------------ frozen weights, transposed once
     @torch.no_grad()
-    def _wt(self, key, rows=None):
-        """W^T of fused weight `key` (optionally of its row slice): the B operand of dX = dY W as the GEMM wants it ([K_in, N_out])."""
-        k = (key, rows)
-        t = self.WT.get(k)
+    def _wt(self, key):
+        """W^T of fused weight `key`: the B operand of dX = dY W as the GEMM wants it ([K_in, N_out]); made once (the weights are frozen)."""
+        t = self.WT.get(key)
         if t is None:
-            w = self.m._fused[key]
-            if rows is not None:
-                w = w[rows[0]:rows[1]]
-            t = ops.transpose(w.contiguous())
-            self.WT[k] = t
+            t = ops.transpose(self.m._fused[key].contiguous())
+            self.WT[key] = t
         return t
 
     # ------------------------------------------------------------------ forward with saves
