@@ -320,6 +320,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 is still timing the roofline kernels: leave the job together
         dist.destroy_process_group()
 
 
