@@ -371,10 +371,55 @@ def gen_flux():
          dict(ref="lightcontrol/lightcontrol_flux.py:575-749", weight_seed=560, scale=float(o["scale"])))
 
 
+# --------------------------------------------------------------------------- distillation loss (reference statements executed as they stand)
+def gen_distill():
+    """train/train_qwenvl.py:58-61 (`normalize`) and :611-634 (`loss = 0`, `temperature0 = 3`, the two `for i in range(19 / 38)` loops with
+    their F.kl_div terms and non-finite guards) extracted by `ast` and executed on seeded tensors; the loss value and, through autograd, its
+    gradient with respect to the three student tensors are the golden outputs."""
+    import torch.nn.functional as F
+    qw = os.path.join(REF, "train/train_qwenvl.py")
+    ns = _extract(qw, {"normalize"})
+    tree = ast.parse(open(qw).read())
+
+    def has_kl(node):
+        return any(isinstance(n, ast.Attribute) and n.attr == "kl_div" for n in ast.walk(node))
+
+    stmts = None
+    for fn in ast.walk(tree):
+        if isinstance(fn, ast.FunctionDef) and has_kl(fn):
+            body = []
+            for n in ast.walk(fn):
+                if isinstance(n, ast.Assign) and len(n.targets) == 1 and getattr(n.targets[0], "id", None) in ("loss", "temperature0") \
+                        and isinstance(n.value, ast.Constant):
+                    body.append(n)
+                if isinstance(n, ast.For) and has_kl(n) and isinstance(n.iter, ast.Call) and getattr(n.iter.func, "id", "") == "range" \
+                        and getattr(n.target, "id", "") == "i":   # the innermost per-block loops, not the epoch / batch loops around them
+                    body.append(n)
+            body.sort(key=lambda n: n.lineno)
+            stmts = body
+            break
+    assert stmts and sum(isinstance(n, ast.For) for n in stmts) == 2, "reference loss statements not found"
+    B, S0, S1, S2, D = 2, 6, 4, 10, 64
+    # (values rounded to bf16 so that the bf16 HIP kernel sees exactly the tensors the reference statements saw)
+    t = [seeded(sh, 700 + i, 0.8).bfloat16().float() for i, sh in enumerate(((B, 19, S0, D), (B, 19, S1, D), (B, 38, S2, D)))]
+    s_ = [(t[i] * 0.5 + seeded(t[i].shape, 710 + i, 0.9)).bfloat16().float() for i in range(3)]
+    with torch.enable_grad():
+        st = [x.clone().requires_grad_(True) for x in s_]
+        ns.update(F=F, torch=torch, KD_teacher_tensor0=t[0], KD_teacher_tensor1=t[1], KD_teacher_tensor2=t[2], KD_student_tensor0=st[0],
+                  KD_student_tensor1=st[1], KD_student_tensor2=st[2], print=lambda *a, **k: None)
+        exec(compile(ast.Module(body=stmts, type_ignores=[]), qw, "exec"), ns)
+        loss = ns["loss"]
+        loss.backward()
+    save("distill_loss", dict(teacher0=t[0], teacher1=t[1], teacher2=t[2], student0=s_[0], student1=s_[1], student2=s_[2],
+                              loss=loss.detach().reshape(1), grad0=st[0].grad, grad1=st[1].grad, grad2=st[2].grad),
+         dict(ref="train/train_qwenvl.py:58-61 and the statements at the listed lines", temperature=float(ns["temperature0"]),
+              lines=[int(n.lineno) for n in stmts]))
+
+
 if __name__ == "__main__":
     torch.set_grad_enabled(False)
     sections = [("legacy", gen_legacy),  # before gen_flux: its permissive stub modules must not shadow the shim
-                ("projector", gen_projector), ("helpers", gen_helpers), ("scheduler", gen_scheduler), ("flux", gen_flux)]
+                ("projector", gen_projector), ("helpers", gen_helpers), ("scheduler", gen_scheduler), ("flux", gen_flux), ("distill", gen_distill)]
     only = set(sys.argv[1:])
     if only:  # partial regeneration: keep the other sections' manifest entries
         MANIFEST.update(json.load(open(os.path.join(HERE, "manifest.json"))))

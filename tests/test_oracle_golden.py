@@ -129,3 +129,19 @@ def test_legacy_proj_classes_mirror_the_reference_parameter_tree(cls):
     m2 = XP.Transformer_proj(64, 2, 32, 48, num_layers=2, device="cpu")
     t2, _ = golden("legacy_Transformer_proj")
     assert {k: tuple(v.shape) for k, v in m2.state_dict().items()} == {k[3:]: tuple(v.shape) for k, v in t2.items() if k.startswith("sd.")}
+
+
+def test_distillation_loss_restatement_vs_reference_statements():
+    """x2i_amd.distill.kd_attention_loss (the torch restatement the GPU parity tests check the HIP kernel against) reproduces the loss value
+    and the autograd gradients obtained by executing the reference's own statements (train/train_qwenvl.py normalize + the two kl_div
+    loops; tests/golden/make_golden.py gen_distill)."""
+    import os
+    from safetensors.torch import load_file
+    from x2i_amd.distill import kd_attention_loss
+    g = load_file(os.path.join(os.path.dirname(__file__), "golden", "distill_loss.safetensors"))
+    st = [g[f"student{i}"].clone().requires_grad_(True) for i in range(3)]
+    loss = kd_attention_loss([g[f"teacher{i}"] for i in range(3)], st, temperature=3.0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for i in range(3):
+        assert torch.allclose(st[i].grad, g[f"grad{i}"], rtol=1e-4, atol=1e-7), i

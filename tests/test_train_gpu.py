@@ -468,3 +468,24 @@ def test_training_harness_synthetic_tiny_writes_loadable_checkpoints(tmp_path):
         assert f.exists()
     pr = load_projector_checkpoint(str(tmp_path / "4" / "diffusion_pytorch_model.bin"), device=DEV, in_channels=5)
     assert pr.use_cnn and pr.conv.weight.shape == (1, 5, 5, 5)
+
+
+def test_distillation_loss_kernel_vs_reference_golden(ops):
+    """x2i_kd_loss_bf16 against the golden produced by EXECUTING the reference's statements (train/train_qwenvl.py normalize and the
+    kl_div loops, tests/golden/make_golden.py gen_distill): the summed loss and the gradient with respect to every student tensor."""
+    import os
+    from safetensors.torch import load_file
+    gold = load_file(os.path.join(os.path.dirname(__file__), "golden", "distill_loss.safetensors"))
+    total = 0.0
+    for k in range(3):
+        t, s = bf(gold[f"teacher{k}"]), bf(gold[f"student{k}"])
+        assert torch.equal(t.float(), gold[f"teacher{k}"]) and torch.equal(s.float(), gold[f"student{k}"])  # fixture values are bf16-exact
+        B, n, S, D = t.shape
+        grad = torch.empty((B, n, S, D), device=DEV, dtype=torch.bfloat16)
+        rl = torch.empty((B * n * S,), device=DEV)
+        ops.kd_loss_rows(g(t), g(s), grad, rl, rows=B * n * S, D=D, temperature=3.0, loss_scale=1.0 / B)   # 'batchmean' = / B per block
+        total += float(rl.sum()) / B
+        e = rel_l2(grad, gold[f"grad{k}"])
+        print(f"  reference-statement golden, tensor {k}: gradient rel-L2 {e:.3e}")
+        assert e < 5e-3
+    assert abs(total - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
