@@ -41,10 +41,29 @@ class DistillBackward:
     def __init__(self, model, fused_attention_backward=True):
         self.m = model
         self.WT = {}
+        self._pool = {}
         self.saved = None
         # True: x2i_attention_bwd_bf16 (flash-style, no [S, S] matrices); False: the explicit-matrix form built from GEMM launches and
         # row kernels (kept as the A/B reference: both are tested against autograd)
         self.fused_attention_backward = fused_attention_backward
+
+    # ------------------------------------------------------------------ buffers: allocated once per shape, reused by every step
+    def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):
+        """Named device buffer (saved activation, gradient, scratch).  Reusing them across steps keeps the caching allocator out of
+        the step: at B = 4 the kept activations are ~140 GiB and re-allocating them every step cost more than the kernels."""
+        key = (name, tuple(shape), dtype)
+        t = self._pool.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), device=self.m.device, dtype=dtype)
+            self._pool[key] = t
+        if zero:
+            t.zero_()
+        return t
+
+    def _keep(self, name, src):
+        t = self._buf(name, src.shape, src.dtype)
+        t.copy_(src)
+        return t
 
     # ------------------------------------------------------------------ frozen weights, transposed once
     @torch.no_grad()
@@ -83,7 +102,7 @@ class DistillBackward:
         t1000 = (timestep.to(device=dev, dtype=hidden_states.dtype) * 1000).float().contiguous()
         tp = ops.timestep_sinusoid(t1000, 256, round_bf16=state["round_bf16"])
         h1 = ops.skinny_linear(tp, f["tte.timestep_embedder.1.w"], f["tte.timestep_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
-        temb = torch.empty((B, D), device=dev, dtype=torch.float32)
+        temb = self._buf("temb", (B, D), torch.float32)
         temb.copy_(state["cond"])
         ops.skinny_linear(h1, f["tte.timestep_embedder.2.w"], f["tte.timestep_embedder.2.b"], out=temb, accumulate=True)
         ops.skinny_linear(temb, f["mod.w"], f["mod.b"], out=MOD, act_in=ACT_SILU)
@@ -94,7 +113,7 @@ class DistillBackward:
             return MOD[:, off:]
 
         loss_terms = []
-        row_loss = torch.empty((B * S,), device=dev, dtype=torch.float32)
+        row_loss = self._buf("row_loss", (B * S,), torch.float32)
 
         def tap(kind, i, tensor, rows, ld, offset_rows=0):
             """gradient injected at a tap: explicit, or d(loss term) / d(tap) from the teacher's tensor; `tensor` rows = [B][rows][D] with
@@ -104,9 +123,9 @@ class DistillBackward:
             if teacher is None:
                 return None
             t_all = teacher[kind]
-            t = (t_all[i] if isinstance(t_all, (list, tuple)) else t_all[:, i]).to(**bf).contiguous()  # [B, rows, D]
-            g = torch.empty((B, rows, D), **bf)
-            term = torch.zeros((1,), device=dev, dtype=torch.float32)
+            t = self._keep(f"teacher{kind}", (t_all[i] if isinstance(t_all, (list, tuple)) else t_all[:, i]).to(**bf))  # [B, rows, D]
+            g = self._buf(f"G{kind}.{i}", (B, rows, D))
+            term = self._buf(f"term{kind}.{i}", (1,), torch.float32)
             # F.kl_div(..., reduction='batchmean') divides the summed rows by B (:616); one launch per sample keeps the strides simple
             for b in range(B):
                 ops.kd_loss_rows(t[b], tensor[b, offset_rows:offset_rows + rows], g[b], row_loss[b * rows:], rows=rows, D=D,
@@ -116,15 +135,15 @@ class DistillBackward:
             loss_terms.append(term)
             return g
 
-        saved = dict(state=state, B=B, St=St, Si=Si, S=S, Spad=Spad, temb=temb, MOD=MOD.clone(), double=[], single=[])
+        saved = dict(state=state, B=B, St=St, Si=Si, S=S, Spad=Spad, temb=temb, MOD=self._keep("MOD", MOD), double=[], single=[])
         qkv_img_off = B * St * 3 * D
         for i in range(cfg.num_layers):
             p = f"d{i}"
             oi = i * 12 * D
             oc = oi + 6 * D
-            sv = dict(Xin=X.clone())
+            sv = dict(Xin=self._keep(p + ".Xin", X))
             ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
-            qkv = torch.empty((B * S, 3 * D), **bf)
+            qkv = self._buf(p + ".QKV", (B * S, 3 * D))
             ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=qkv, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
                      c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
             ops.gemm(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], out=qkv, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=St * 3 * D,
@@ -132,26 +151,26 @@ class DistillBackward:
             ops.qkv_split(qkv, qkv.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
                           f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
             ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
-            OP = torch.empty((B, S, D), **bf)
+            OP = self._buf(p + ".OP", (B, S, D))
             ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=OP, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=OP, M=St, batch=B, a_batch_stride=S * D, lda=D,
                      c_batch_stride=S * D, ldc=D)
-            sv["O"] = ATT.clone()                                # attention output (rowsum(dO * O) of the fused attention backward)
+            sv["O"] = self._keep(p + ".O", ATT)                             # attention output (rowsum(dO * O) of the fused attention backward)
             sv["Gimg"] = tap(0, i, OP, Si, D, offset_rows=St)   # reference lists[0]: image-stream attention output
             sv["Gtxt"] = tap(1, i, OP, St, D, offset_rows=0)    # lists[1]: text-stream attention output
             ops.gated_residual_(X, OP, mod(oi + 2 * D), B, Si, D, S * D, D, S * D, D, Ntot, x_offset=St * D, t_offset=St * D)
             ops.gated_residual_(X, OP, mod(oc + 2 * D), B, St, D, S * D, D, S * D, D, Ntot)
-            sv.update(QKV=qkv, OP=OP, Xmid=X.clone())
+            sv.update(QKV=qkv, OP=OP, Xmid=self._keep(p + ".Xmid", X))
             ops.ln_modulate(X, NRM, B, S, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oi + 3 * D), mod(oi + 4 * D), Ntot)
-            PRE = torch.empty((B * S, 4 * D), **bf)   # text rows [B*St] first, image rows behind (as CAT in denoise)
-            Hh = torch.empty((B * S, 4 * D), **bf)
+            PRE = self._buf(p + ".PRE", (B * S, 4 * D))   # text rows [B*St] first, image rows behind (as CAT in denoise)
+            Hh = self._buf("Hh", (B * S, 4 * D))
             ff_img = B * St * 4 * D
             ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=Si, batch=B, a_batch_stride=S * D, lda=D,
                      a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img)
             ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=St, batch=B,
                      a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D, ldc=4 * D)
-            FF = torch.empty((B, S, D), **bf)
+            FF = self._buf(p + ".FF", (B, S, D))
             ops.gemm(Hh, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=FF, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, a_offset=ff_img,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(Hh, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=FF, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D,
@@ -159,25 +178,24 @@ class DistillBackward:
             ops.gated_residual_(X, FF, mod(oi + 5 * D), B, Si, D, S * D, D, S * D, D, Ntot, x_offset=St * D, t_offset=St * D)
             ops.gated_residual_(X, FF, mod(oc + 5 * D), B, St, D, S * D, D, S * D, D, Ntot)
             sv.update(PRE=PRE, FF=FF)
-            del Hh
             saved["double"].append(sv)
         base = cfg.num_layers * 12 * D
         for i in range(cfg.num_single_layers):
             p = f"s{i}"
             o = base + i * 3 * D
-            sv = dict(Xin=X.clone())
+            sv = dict(Xin=self._keep(p + ".Xin", X))
             ops.ln_modulate(X, NRM, B, S, D, 0, None, None, mod(o), mod(o + D), Ntot)
             w, bias = f[p + ".in.w"], f[p + ".in.b"]
-            IN = torch.empty((B * S, 7 * D), **bf)   # [q|k|v pre-norm | proj_mlp pre-GELU]
+            IN = self._buf(p + ".IN", (B * S, 7 * D))   # [q|k|v pre-norm | proj_mlp pre-GELU]
             ops.gemm(NRM, w, bias, out=IN, M=B * S)
             ops.qkv_split(None, IN, 7 * D, 7 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
             ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
-            sv["O"] = CAT.view(B, S, 5 * D)[:, :, :D].contiguous()
+            sv["O"] = self._keep(p + ".O", CAT.view(B, S, 5 * D)[:, :, :D])
             sv["G"] = tap(2, i, CAT.view(B, S, 5 * D), S, 5 * D)   # lists[2]: the un-projected joint attention output
             # GELU(proj_mlp) into CAT[:, D:]: one elementwise pass through the GEMM epilogue is not available here, so the kernel that
             # owns the activation (x2i_gemm_bf16 with act) recomputes that slice from NRM -- the saved pre-activation stays exact
             ops.gemm(NRM, w[3 * D:], bias[3 * D:], out=CAT, M=B * S, N=4 * D, ldc=5 * D, c_offset=D, act=ACT_GELU_TANH)
-            PO = torch.empty((B, S, D), **bf)
+            PO = self._buf(p + ".PO", (B, S, D))
             ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=PO, M=S, batch=B, a_batch_stride=S * 5 * D, lda=5 * D,
                      c_batch_stride=S * D, ldc=D)
             ops.gated_residual_(X, PO, mod(o + 2 * D), B, S, D, S * D, D, S * D, D, Ntot)
@@ -239,9 +257,7 @@ class DistillBackward:
                        QT=torch.empty((H, 128, Spad), **bf), dOT=torch.zeros((H, 128, Spad), **bf))
             self._attn_ws = big
         P, dP, T, V, KT, QT, dOT = (big[k] for k in ("P", "dP", "T", "V", "KT", "QT", "dOT"))
-        dQ = torch.empty((B, H, Spad, 128), **bf)
-        dK = torch.empty((B, H, Spad, 128), **bf)
-        dV = torch.empty((B, H, Spad, 128), **bf)
+        dQ, dK, dV = (self._buf(n, (B, H, Spad, 128)) for n in ("xdQ", "xdK", "xdV"))
         L2 = Spad * Spad
         for b in range(B):
             ops.gemm(Q[b], K[b], out=P, M=Spad, N=Spad, K=128, batch=H, a_batch_stride=Spad * 128, lda=128, w_batch_stride=Spad * 128,
@@ -281,11 +297,11 @@ class DistillBackward:
         MOD = sv["MOD"]
         Ntot = m._mod_rows
         R = _gcd_rows(St, Si)
-        dX = torch.zeros((B, S, D), **bf)                      # gradient of the residual stream
-        dT = torch.empty((B, S, D), **bf)
-        dN = torch.empty((B, S, D), **bf)
-        dMOD = torch.zeros((B, Ntot), device=dev, dtype=torch.float32)
-        part = torch.empty((B * ((S + R - 1) // R) * 2 * D,), device=dev, dtype=torch.float32)
+        dX = self._buf("dX", (B, S, D), zero=True)            # gradient of the residual stream
+        dT = self._buf("dT", (B, S, D))
+        dN = self._buf("dN", (B, S, D))
+        dMOD = self._buf("dMOD", (B, Ntot), torch.float32, zero=True)
+        part = self._buf("part", (B * ((S + R - 1) // R) * 2 * D,), torch.float32)
 
         def mod(off):
             return MOD[:, off:]
@@ -316,19 +332,18 @@ class DistillBackward:
             o = base + i * 3 * D
             s_ = sv["single"][i]
             gate_bwd(s_["PO"], None, o + 2 * D, 0, S)                                     # dT = d proj_out output
-            dCAT = torch.empty((B * S, 5 * D), **bf)
+            dCAT = self._buf("dCAT", (B * S, 5 * D))
             ops.gemm(dT, self._wt(p + ".proj_out.w"), out=dCAT, M=B * S)                    # [d attention | d GELU(proj_mlp)]
             if s_["G"] is not None:
                 ops.gate_bwd(dCAT, None, None, s_["G"], dCAT, None, B=B, S=S, D=D, R=R, dx_bs=S * 5 * D, lddx=5 * D, g_bs=S * D, dt_bs=S * 5 * D,
                              lddt=5 * D)                                                    # d attention += tap gradient
-            dIN = torch.empty((B * S, 7 * D), **bf)
+            dIN = self._buf("dIN", (B * S, 7 * D))
             # d proj_mlp pre-activation -> columns [3D, 7D) of dIN
             dIN.view(B * S, 7 * D)[:, 3 * D:].copy_(dCAT.view(B * S, 5 * D)[:, D:])
             ops.act_bwd_(dIN, s_["IN"], ACT_GELU_TANH, rows=B * S, cols=4 * D, ldd=7 * D, ldp=7 * D, d_offset=3 * D, p_offset=3 * D)
             self._attention_bwd(None, s_["IN"], 7 * D, 0, (None, None, f[p + ".norm_q"], f[p + ".norm_k"]), dCAT, 5 * D, None, dIN, O=s_["O"])
             ops.gemm(dIN, self._wt(p + ".in.w"), out=dN, M=B * S)
             ln_bwd(s_["Xin"], o + D, o, 0, S)
-            del dCAT, dIN
         # ---- double-stream blocks
         for i in reversed(range(cfg.num_layers)):
             p = f"d{i}"
@@ -338,7 +353,7 @@ class DistillBackward:
             # feed-forward: x = x_mid + gate_mlp * FF
             gate_bwd(d_["FF"], None, oi + 5 * D, St, Si)
             gate_bwd(d_["FF"], None, oc + 5 * D, 0, St)
-            dH = torch.empty((B * S, 4 * D), **bf)
+            dH = self._buf("dH", (B * S, 4 * D))
             ff_img = B * St * 4 * D
             ops.gemm(dT, self._wt(p + ".ff.2.w"), out=dH, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
                      c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img)
@@ -349,17 +364,16 @@ class DistillBackward:
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(dH, self._wt(p + ".ff_context.0.w"), out=dN, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D,
                      ldc=D)
-            del dH
             ln_bwd(d_["Xmid"], oi + 4 * D, oi + 3 * D, St, Si)
             ln_bwd(d_["Xmid"], oc + 4 * D, oc + 3 * D, 0, St)
             # attention: x_mid = x_in + gate_msa * OP, OP = to_out(attention) -- the taps sit on OP
             gate_bwd(d_["OP"], d_["Gimg"], oi + 2 * D, St, Si)
             gate_bwd(d_["OP"], d_["Gtxt"], oc + 2 * D, 0, St)
-            dATT = torch.empty((B, S, D), **bf)
+            dATT = self._buf("dATT", (B, S, D))
             ops.gemm(dT, self._wt(p + ".to_out.w"), out=dATT, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(dT, self._wt(p + ".to_add_out.w"), out=dATT, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=S * D, ldc=D)
-            dQKV = torch.empty((B * S, 3 * D), **bf)
+            dQKV = self._buf("dQKV", (B * S, 3 * D))
             img = B * St * 3 * D
             self._attention_bwd(d_["QKV"], d_["QKV"].view(-1)[img:], 3 * D, St,
                                 (f[p + ".norm_added_q"], f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"]), dATT, D, dQKV,
@@ -367,7 +381,6 @@ class DistillBackward:
             ops.gemm(dQKV, self._wt(p + ".qkv.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 3 * D, lda=3 * D, a_offset=img,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(dQKV, self._wt(p + ".cqkv.w"), out=dN, M=St, batch=B, a_batch_stride=St * 3 * D, lda=3 * D, c_batch_stride=S * D, ldc=D)
-            del dATT, dQKV
             ln_bwd(d_["Xin"], oi + D, oi, St, Si)
             ln_bwd(d_["Xin"], oc + D, oc, 0, St)
         # ---- embedders: text rows of dX -> context_embedder -> encoder_hidden_states
