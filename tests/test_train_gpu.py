@@ -489,3 +489,38 @@ def test_distillation_loss_kernel_vs_reference_golden(ops):
         print(f"  reference-statement golden, tensor {k}: gradient rel-L2 {e:.3e}")
         assert e < 5e-3
     assert abs(total - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+
+
+def test_graphed_step_equals_eager_step():
+    """GraphedDistillStep (one hipGraph for everything but the optimizer) produces bit-identical losses, gradients and updated parameters
+    to the eager distill_step over several steps with changing batches."""
+    from oracle import sampler as OS
+    from x2i_amd.proj import Proj7Exp
+    from x2i_amd.train import DistillBackward, GraphedDistillStep, ProjectorTrainer, distill_step
+
+    def setup():
+        m, _, _ = _tiny()
+        pr = Proj7Exp(in_channels=5, input_dim=128, output_dim0=32, output_dim1=64, use_t5=False, use_scale=False, use_cnn=True, device=DEV).init_random_(7)
+        return ProjectorTrainer(pr, lr=2e-3), DistillBackward(m)
+    B, St, h2, w2 = 2, 24, 6, 8
+    ids, tids = OS.prepare_latent_image_ids(h2, w2).to(DEV), torch.zeros(St, 3, device=DEV)
+
+    def batch(i):
+        gen = torch.Generator().manual_seed(100 + i)
+        rn = lambda *s: torch.randn(s, generator=gen)  # noqa: E731
+        return (bf(rn(B, 5, St, 128) * 2).to(DEV), bf(rn(B, h2 * w2, 64)).to(DEV), torch.tensor([0.5, 0.25]).to(DEV),
+                [bf(rn(B, 2, h2 * w2, 256)).to(DEV), bf(rn(B, 2, St, 256)).to(DEV), bf(rn(B, 2, St + h2 * w2, 256)).to(DEV)])
+    tr_e, ch_e = setup()
+    tr_g, ch_g = setup()
+    gs = GraphedDistillStep(tr_g, ch_g, tids, ids)
+    for i in range(5):
+        x, lat, ts, teacher = batch(i)
+        le = distill_step(tr_e, ch_e, x, lat, ts, teacher, tids, ids, optimizer_step=False)
+        lg = gs(x, lat, ts, teacher, optimizer_step=False)
+        assert torch.equal(le, lg), i
+        assert torch.equal(tr_e.grad, tr_g.grad), i
+        tr_e.step()
+        tr_g.step()
+        for pe, pg in zip(tr_e.params, tr_g.params):
+            assert torch.equal(pe, pg), i
+    assert gs.graph is not None

@@ -13,8 +13,9 @@ from x2i_amd.train import DistillBackward, ProjectorTrainer  # noqa: E402
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B = int(pos[0]) if len(pos) > 0 else 1
+    steps = int(pos[1]) if len(pos) > 1 else 3
     dev = "cuda"
     m = FluxTransformer2DModel(guidance_embeds=True, device=dev).init_random_(seed=1)
     pr = create_proj3_qwen3b(in_channels=37, use_t5=False, use_scale=False, use_cnn=True, device=dev).init_random_(2)
@@ -55,6 +56,17 @@ def main():
               + ("  (first step: weight transposes, allocations)" if it == 0 else ""), flush=True)
         if it > 0:
             tot = [a + b for a, b in zip(tot, dt)]
+    if "--graph" in sys.argv:
+        from x2i_amd.train import GraphedDistillStep
+        gs = GraphedDistillStep(tr, chain, txt_ids, img_ids, gd)
+        for it in range(steps + 2):   # eager warm-up, capture, then replays
+            e0, e1 = ev(), ev()
+            e0.record()
+            loss = gs(x, lat, ts, teacher)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"graphed step {it}: loss {float(loss):.4f}  total {e0.elapsed_time(e1):8.1f} ms" + ("  (eager warm-up)" if it == 0 else "  (capture + replay)" if it == 1 else ""),
+                  flush=True)
     print(f"B = {B}, 1024^2, 19 + 38 blocks; mean over {steps} steps:")
     for n, v in zip(names, tot):
         print(f"  {n:50s} {v / steps:9.1f} ms")
