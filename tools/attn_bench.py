@@ -36,5 +36,27 @@ def main():
     _lib.set_option("attn_variant", 0)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "bwd"):
     main()
+
+
+def backward_bench():
+    """fused attention backward (statistics + dQ + dK/dV passes) at the DiT shape: python tools/attn_bench.py B bwd"""
+    B = int(sys.argv[1])
+    H, S = 24, 4608
+    Spad = ops.pad128(S)
+    rnd = lambda *sh: torch.randn(sh, device="cuda").bfloat16()  # noqa: E731
+    Q, K_, V = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, Spad, 128)
+    QT, KT = ops.transpose(Q.view(B * H, Spad, 128)), ops.transpose(K_.view(B * H, Spad, 128))
+    dOh = rnd(B * H, Spad, 128)
+    dOT = ops.transpose(dOh)
+    Dv = torch.randn((B, H, Spad), device="cuda") * 0.1
+    L = torch.empty((B, H, Spad), device="cuda")
+    dQ, dK, dV = (torch.empty((B, H, Spad, 128), device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    t = timeit(lambda: ops.attention_bwd(Q, K_, V, QT, KT, dOh, dOT, L, Dv, dQ, dK, dV, B, H, S, Spad, 1 / math.sqrt(128)))
+    fl = (1 + 3 + 4) * 2 * B * H * S * S * 128
+    print(f"attention backward (3 passes, 8 MFMA groups) B={B}: {t*1e3:8.3f} ms  {fl/t/1e12:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "bwd":
+    backward_bench()

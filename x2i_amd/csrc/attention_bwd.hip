@@ -25,9 +25,10 @@ constexpr int KVB = 64;
 constexpr int TILE = 16384;  // 64 x 128 bf16, either orientation
 constexpr float BIG = 1.0e30f;
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// LDS-DMA through the MUBUF path (buffer_load_dwordx4 ... lds): counted in vmcnt only.  The flat form (global_load_lds) also counts in
+// lgkmcnt, so the first fragment wait of a tile (lgkmcnt(0)) would wait for the NEXT tile's DMA as well.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff_bytes, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, 0, 0, 0);
 }
 
 struct Geo {
@@ -83,6 +84,55 @@ __device__ __forceinline__ void accum_mma(const char* tb, const Geo& G, const bf
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// The two score products of a tile as ONE fragment pipeline (steps 0-3: rows of tile A x pa -> sa, steps 4-7: rows of tile B x pb -> sb):
+// no LDS-latency bubble between them.  NS = 4 runs the first product only.
+template <int NS>
+__device__ __forceinline__ void score_phase(const char* ta, const char* tb, const Geo& G, const bf16x8_t (&pa)[8], const bf16x8_t (&pb)[8],
+                                            f32x16_t (&sa)[2], f32x16_t (&sb)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[u][r] = 0.f; sb[u][r] = 0.f; }
+  bf16x8_t fr[2][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) fr[0][f] = row_frag(ta, G, 0, f);
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st + 1 < NS) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fr[(st + 1) & 1][f] = row_frag(st + 1 < 4 ? ta : tb, G, (st + 1) & 3, f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int g = st & 3;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (st < 4) sa[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][f], pa[2 * g + (f >> 1)], sa[f & 1], 0, 0, 0);
+      else sb[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][f], pb[2 * g + (f >> 1)], sb[f & 1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// The accumulation products of a tile as one pipeline whose first fragments (`fr0`) were read BEFORE the element-wise section:
+// steps 0-3: transposed tile C x f0 -> o0; steps 4-7 (NS = 8): transposed tile D x f1 -> o1.
+template <int NS>
+__device__ __forceinline__ void accum_phase(const char* tc, const char* td, const Geo& G, const bf16x8_t (&f0)[2][2], const bf16x8_t (&f1)[2][2],
+                                            f32x16_t (&o0)[4], f32x16_t (&o1)[4], bf16x8_t (&fr)[2][4]) {
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st + 1 < NS) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) fr[(st + 1) & 1][db] = col_frag(st + 1 < 4 ? tc : td, G, (st + 1) & 3, db);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int g = st & 3;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      if (st < 4) o0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][db], f0[g >> 1][g & 1], o0[db], 0, 0, 0);
+      else o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][db], f1[g >> 1][g & 1], o1[db], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 __device__ __forceinline__ void pack_frags(const f32x16_t (&a)[2], bf16x8_t (&pf)[2][2]) {
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -108,6 +158,104 @@ __device__ __forceinline__ void store_rows(bf16_t* orow, const f32x16_t (&acc)[4
       const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
       if (live) *(uint4*)(orow + db * 32 + 8 * (g + hi)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
     }
+}
+
+struct Rsrc4 {
+  __amdgpu_buffer_rsrc_t a, b, c, d;
+};
+
+// One streamed tile: start the DMA of the next tile into `nxt`, then run this tile's MFMA groups on `cur`.  cur / nxt are __restrict__
+// parameters of one function so that hipcc can tell the fragment reads from the buffer being filled (else every ds_read behind a DMA
+// issue gets a conservative vmcnt(0)).
+template <int MODE>
+__device__ __forceinline__ void bwd_tile(const char* __restrict__ cur, char* __restrict__ nxt, bool issue, int s_next, int s0, const Rsrc4& R,
+                                         const int (&row_src)[4], const int (&col_src)[4], int wave, const Geo& G, const bf16x8_t (&pa)[8],
+                                         const bf16x8_t (&pb)[8], float myL, float myD, const float* __restrict__ L2h,
+                                         const float* __restrict__ Dh, int S, float scale_log2, f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4],
+                                         float& m_run, float& l_run) {
+  if (issue) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* dst = nxt + (j * 256 + wave * 64) * 16;
+      dma16(R.a, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
+      if (MODE != 2) {
+        dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst + TILE);
+        dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst + 2 * TILE);
+        if (MODE == 1) dma16(R.d, (uint32_t)(s_next * 2 + col_src[j] * 2), dst + 3 * TILE);
+      }
+    }
+  }
+  f32x16_t sacc[2], dacc[2];
+  // per streamed row statistics (MODE 1): lane (hi), sub-tile u, reg r <-> row s0 + u*32 + 16*(r>>3) + 8*hi + (r&7)
+  float Lr[2][16], Dr[2][16];
+  if (MODE == 1) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int o = s0 + u * 32 + 16 * a + 8 * G.hi;
+        const f32x4_t l0 = *(const f32x4_t*)(L2h + o), l1 = *(const f32x4_t*)(L2h + o + 4);
+        const f32x4_t d0 = *(const f32x4_t*)(Dh + o), d1 = *(const f32x4_t*)(Dh + o + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Lr[u][8 * a + j] = l0[j]; Lr[u][8 * a + 4 + j] = l1[j];
+          Dr[u][8 * a + j] = d0[j]; Dr[u][8 * a + 4 + j] = d1[j];
+        }
+      }
+  }
+  if (MODE == 2) {
+    score_phase<4>(cur, cur, G, pa, pa, sacc, dacc);
+    // online max / sum of scale_log2 * s over the valid keys
+    float mx = -BIG;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
+        sacc[u][r] = key < S ? sacc[u][r] * scale_log2 : -BIG;
+        mx = fmaxf(mx, sacc[u][r]);
+      }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(sacc[u][r] - m_new);
+    l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ps;
+    m_run = m_new;
+  } else {
+    score_phase<8>(cur, cur + TILE, G, pa, pb, sacc, dacc);
+    // first fragments of the accumulation pipeline: in flight while the element-wise section runs
+    bf16x8_t fr[2][4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) fr[0][db] = col_frag(cur + 2 * TILE, G, 0, db);
+    f32x16_t pv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p;
+        if (MODE == 0) {
+          const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
+          p = key < S ? __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - myL) : 0.f;
+          dacc[u][r] = p * (dacc[u][r] - myD);
+        } else {
+          p = __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - Lr[u][r]);
+          dacc[u][r] = p * (dacc[u][r] - Dr[u][r]);
+        }
+        pv[u][r] = p;
+      }
+    bf16x8_t dsf[2][2];
+    pack_frags(dacc, dsf);
+    if (MODE == 0) {
+      accum_phase<4>(cur + 2 * TILE, cur + 2 * TILE, G, dsf, dsf, oacc0, oacc1, fr);   // dQ^T += K^T dS^T
+    } else {
+      bf16x8_t pf[2][2];
+      pack_frags(pv, pf);
+      accum_phase<8>(cur + 2 * TILE, cur + 3 * TILE, G, pf, dsf, oacc0, oacc1, fr);   // dV^T += dO^T P;  dK^T += Q^T dS
+    }
+  }
 }
 
 template <int MODE>
@@ -155,103 +303,42 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
     { const int row = p >> 4, c = p & 15; row_src[j] = row * 128 + ((c ^ (row & 15)) << 3); }
     { const int row = p >> 3, c = p & 7; col_src[j] = row * Spad + ((c ^ ((row >> 1) & 7)) << 3); }
   }
-  auto stage = [&](int buf, int s0) {
-    char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* dst = base + (j * 256 + wave * 64) * 16;
-      glds16(TA + hoff + (long long)s0 * 128 + row_src[j], dst);
-      if (MODE != 2) {
-        glds16(TB + hoff + (long long)s0 * 128 + row_src[j], dst + TILE);
-        glds16(TC + hoff + s0 + col_src[j], dst + 2 * TILE);
-        if (MODE == 1) glds16(TD + hoff + s0 + col_src[j], dst + 3 * TILE);
-      }
-    }
-  };
-
+  Rsrc4 R;
+  {
+    const uint32_t bytes = (uint32_t)Spad * 256u;
+    R.a = __builtin_amdgcn_make_buffer_rsrc((void*)(TA + hoff), 0, bytes, 0x00020000);
+    R.b = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE != 2 ? TB : TA) + hoff), 0, bytes, 0x00020000);
+    R.c = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE != 2 ? TC : TA) + hoff), 0, bytes, 0x00020000);
+    R.d = __builtin_amdgcn_make_buffer_rsrc((void*)((MODE == 1 ? TD : TA) + hoff), 0, bytes, 0x00020000);
+  }
   f32x16_t oacc0[4], oacc1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc0[i][r] = 0.f; oacc1[i][r] = 0.f; }
   float m_run = -BIG, l_run = 0.f;
+  const float* L2h = L2 + bh * Spad;
+  const float* Dh = Dv + bh * Spad;
 
   const int nt = (S + KVB - 1) / KVB;
-  stage(0, 0);
+  {  // prologue: tile 0 (bwd_tile with nothing to compute would need a third form)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* dst = smem + (j * 256 + wave * 64) * 16;
+      dma16(R.a, (uint32_t)(row_src[j] * 2), dst);
+      if (MODE != 2) {
+        dma16(R.b, (uint32_t)(row_src[j] * 2), dst + TILE);
+        dma16(R.c, (uint32_t)(col_src[j] * 2), dst + 2 * TILE);
+        if (MODE == 1) dma16(R.d, (uint32_t)(col_src[j] * 2), dst + 3 * TILE);
+      }
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1, s0 = t * KVB;
-    if (t + 1 < nt) stage(buf ^ 1, (t + 1) * KVB);
-    const char* base = smem + buf * STAGE;
-    f32x16_t sacc[2], dacc[2];
-    // per streamed row statistics (MODE 1): lane (hi), sub-tile u, reg r <-> row s0 + u*32 + 16*(r>>3) + 8*hi + (r&7)
-    float Lr[2][16], Dr[2][16];
-    if (MODE == 1) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const long long o = bh * Spad + s0 + u * 32 + 16 * a + 8 * G.hi;
-          const f32x4_t l0 = *(const f32x4_t*)(L2 + o), l1 = *(const f32x4_t*)(L2 + o + 4);
-          const f32x4_t d0 = *(const f32x4_t*)(Dv + o), d1 = *(const f32x4_t*)(Dv + o + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            Lr[u][8 * a + j] = l0[j]; Lr[u][8 * a + 4 + j] = l1[j];
-            Dr[u][8 * a + j] = d0[j]; Dr[u][8 * a + 4 + j] = d1[j];
-          }
-        }
-    }
-    score_mma(base, G, pa, sacc);
-    if (MODE == 2) {
-      // online max / sum of scale_log2 * s over the valid keys
-      float mx = -BIG;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
-          sacc[u][r] = key < S ? sacc[u][r] * scale_log2 : -BIG;
-          mx = fmaxf(mx, sacc[u][r]);
-        }
-      mx = xhalf_max(mx);
-      const float m_new = fmaxf(m_run, mx);
-      float ps = 0.f;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(sacc[u][r] - m_new);
-      l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ps;
-      m_run = m_new;
-    } else {
-      score_mma(base + TILE, G, pb, dacc);
-      f32x16_t pv[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float p;
-          if (MODE == 0) {
-            const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
-            p = key < S ? __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - myL) : 0.f;
-            dacc[u][r] = p * (dacc[u][r] - myD);
-          } else {
-            p = __builtin_amdgcn_exp2f(sacc[u][r] * scale_log2 - Lr[u][r]);
-            dacc[u][r] = p * (dacc[u][r] - Dr[u][r]);
-          }
-          pv[u][r] = p;
-        }
-      bf16x8_t dsf[2][2];
-      pack_frags(dacc, dsf);
-      if (MODE == 0) {
-        accum_mma(base + 2 * TILE, G, dsf, oacc0);             // dQ^T += K^T dS^T
-      } else {
-        bf16x8_t pf[2][2];
-        pack_frags(pv, pf);
-        accum_mma(base + 2 * TILE, G, pf, oacc0);              // dV^T += dO^T P
-        accum_mma(base + 3 * TILE, G, dsf, oacc1);             // dK^T += Q^T dS
-      }
-    }
+    const int buf = t & 1;
+    bwd_tile<MODE>(smem + buf * STAGE, smem + (buf ^ 1) * STAGE, t + 1 < nt, (t + 1) * KVB, t * KVB, R, row_src, col_src, wave, G, pa, pb, myL, myD,
+                   L2h, Dh, S, scale_log2, oacc0, oacc1, m_run, l_run);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
