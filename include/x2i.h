@@ -312,10 +312,15 @@ int x2i_zero_if_nonfinite_bf16(void* g, int64_t n, const float* term, x2i_stream
 /* Fused (flash-style) attention backward, head_dim 128 (csrc/attention_bwd.hip): dQ, dK, dV bf16 [B,H,Spad,128] from
  *   Q, K, V, dO  bf16 [B,H,Spad,128] (row-major per head, zero beyond S)      QT, KT, dOT  bf16 [B,H,128,Spad] (their transposes)
  *   D  f32 [B,H,Spad] = rowsum(dO * O) (x2i_attention_bwd_prep_bf16 from the token-major dO / O)     lse2  f32 [B,H,Spad] scratch
- * Three launches: log2-sum-exp statistics into lse2, dQ (persistent query blocks), dK / dV (persistent key blocks); no atomics. */
+ * Three launches: log2-sum-exp statistics into lse2 (skipped when have_lse != 0: lse2 then is an input), dQ (persistent query blocks),
+ * dK / dV (persistent key blocks); no atomics. */
 int x2i_attention_bwd_bf16(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dO, const void* dOT, float* lse2,
                            const float* D, void* dQ, void* dK, void* dV, int32_t B, int32_t H, int32_t S, int32_t Spad, float scale,
-                           x2i_stream_t stream);
+                           int32_t have_lse, x2i_stream_t stream);
+/* x2i_attention_bf16 that also writes lse2 f32 [B,H,Spad] = log2 sum_j exp(scale * s_qj) (+big on the padding rows): handed to
+ * x2i_attention_bwd_bf16 with have_lse = 1 it saves the statistics pass of the backward. */
+int x2i_attention_lse_bf16(const void* Q, const void* K, const void* VT, void* O, float* lse2, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                           int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
 int x2i_attention_bwd_prep_bf16(const void* dO, int64_t do_bs, int32_t lddo, const void* O, int64_t o_bs, int32_t ldo, float* D, int32_t B, int32_t H,
                                 int32_t S, int32_t Spad, x2i_stream_t stream);
 /* -- the trainable side (projector): weight gradients of the layer fusion, gradient clipping, AdamW.  Linear-layer weight gradients are

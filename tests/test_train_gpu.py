@@ -412,6 +412,20 @@ def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     eq, ek, ev = rel_l2(dQ[:, :, :S], q.grad), rel_l2(dK[:, :, :S], k.grad), rel_l2(dV[:, :, :S], v.grad)
     print(f"fused attention backward B={B} H={H} S={S}: dQ {eq:.3e} dK {ek:.3e} dV {ev:.3e}")
     assert eq < 1.5e-2 and ek < 1.5e-2 and ev < 1.5e-2
+    # the forward kernel can hand over the statistics itself (x2i_attention_lse_bf16): same output as x2i_attention_bf16, same lse, and the
+    # backward without its statistics pass gives the same gradients
+    VT = ops.transpose(Vg.view(B * H, Spad, 128)).view(B, H, 128, Spad)
+    o1 = torch.empty((B, S, H * 128), device=DEV, dtype=torch.bfloat16)
+    o2 = torch.empty_like(o1)
+    lse_f = torch.zeros((B, H, Spad), device=DEV)
+    ops.attention(Qg, Kg, VT, o1, B, H, S, Spad, H * 128, S * H * 128, scale)
+    ops.attention_lse(Qg, Kg, VT, o2, lse_f, B, H, S, Spad, H * 128, S * H * 128, scale)
+    assert torch.equal(o1, o2) and rel_l2(o2, o_tok.detach()) < 1e-2
+    assert rel_l2(lse_f[:, :, :S], ref_lse) < 1e-4 and bool((lse_f[:, :, S:] > 1e29).all())
+    dQ2, dK2, dV2 = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ2, dK2, dV2, B, H, S, Spad, scale, have_lse=True)
+    for a, b_ in ((dQ2, dQ), (dK2, dK), (dV2, dV)):
+        assert rel_l2(a[:, :, :S], b_[:, :, :S].float().cpu()) < 2e-3
 
 
 def test_full_width_distillation_gradient_vs_oracle_autograd():

@@ -89,7 +89,8 @@ SIGNATURES = {
     "x2i_skinny_linear_bwd": [_vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_kd_loss_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp],
     "x2i_zero_if_nonfinite_bf16": [_vp, _i64, _vp, _vp],
-    "x2i_attention_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "x2i_attention_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "x2i_attention_lse_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
     "x2i_attention_bwd_prep_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_proj_conv5x5_wgrad": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_plane_dot_bf16": [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],

@@ -47,7 +47,7 @@ template <int NW, int THR, int ABL = 0, bool OUT8 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S,
                                                            int Spad, int ldo, long long o_bs, float scale_log2, int nbatch,
-                                                           float oinv) {
+                                                           float oinv, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K 16K | VT 16K]
   constexpr int NT = NW * 64;
   constexpr int CH = 1024 / NT;  // 16-byte chunks per thread per tile (1024 chunks per 16 KiB tile)
@@ -259,6 +259,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   l_run = xhalf_sum(l_run);
   const float inv = 1.f / l_run;
   const int q = q0 + li;
+  // log2-sum-exp of the scaled scores (the statistic the backward pass needs, x2i_attention_lse_bf16); +big on the padding rows
+  if (lse && hi == 0 && q < Spad) lse[bh * Spad + q] = q < S ? m_run + __log2f(l_run) : 1.0e30f;
   if constexpr (OUT8) {
     uint8_t* orow8 = (uint8_t*)O + (long long)b * o_bs + (long long)q * ldo + h * 128;
     const float sc = inv * oinv;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 }  // namespace
 
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
-                         long long o_bs, float scale, hipStream_t stream, int out8, float oinv) {
+                         long long o_bs, float scale, hipStream_t stream, int out8, float oinv, float* lse) {
   if (!Q || !K || !VT || !O) return x2i_set_error(X2I_ERR_ARG, "attention: null pointer");
   if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention: need Spad %% 128 == 0 and Spad >= S (S=%d Spad=%d)", S, Spad);
   if (out8 ? (ldo % 8 || o_bs % 8 || (((uintptr_t)O) & 7)) : (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)))
@@ -320,7 +322,7 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   const int var = opt.attn_variant;  // 0 = automatic; A/B: 1 = 8 lock-step waves, 2 = no defer-max, 3 = both, 4 = 4-wave kernel, 5 / 6 = ping-pong schedule 0 (defer-max / none), 7 / 8 = ping-pong schedules 1 / 2
   // the 8-wave ping-pong kernel (attention_pp.hip) serves sequences long enough to fill the chip with 256-row workgroups
   if ((var == 0 && (long long)((S + 255) / 256) * H * B >= 256) || var == 5 || var == 6 || var == 7 || var == 8) {
-    const int rc = x2i_launch_attention_pp(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, out8, oinv, var == 6 ? 0 : 8);
+    const int rc = x2i_launch_attention_pp(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, out8, oinv, var == 6 ? 0 : 8, lse);
     if (rc != X2I_ERR_STATE) return rc;  // X2I_ERR_STATE: shape / alignment not served by that kernel -> fall through
   }
 #define X2I_ATTN_LAUNCH(NW_, THR_)                                                                                          \
@@ -329,14 +331,14 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     if (rc_) return rc_;                                                                                                    \
     dim3 grid(((S + 32 * NW_ - 1) / (32 * NW_)) * H * B);                                                                   \
     hipLaunchKernelGGL((attn_fwd_kernel<NW_, THR_>), grid, dim3(NW_ * 64), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, 1.f);                           \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, 1.f, lse);                      \
   }
   if (out8) {
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_fwd_kernel<4, 8, 0, true>, (int)shm);
     if (rc_) return rc_;
     dim3 grid(((S + 127) / 128) * H * B);
     hipLaunchKernelGGL((attn_fwd_kernel<4, 8, 0, true>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv, lse);
     return x2i_check_launch("attention");
   }
 #ifdef X2I_ABLATION
@@ -347,7 +349,7 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     if (rc_) return rc_;                                                                                                     \
     dim3 grid(((S + 127) / 128) * H * B);                                                                                    \
     hipLaunchKernelGGL((attn_fwd_kernel<4, 8, A_>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, 1.f);                            \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, 1.f, lse);                       \
   }
   if (abl == 1) X2I_ATTN_LAUNCH_ABL(1)
   else if (abl == 2) X2I_ATTN_LAUNCH_ABL(2)

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 
 int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dOh, const void* dOT,
                              float* L2, const float* Dv, void* dQ, void* dK, void* dV, int B, int H, int S, int Spad, float scale,
-                             hipStream_t stream) {
+                             int have_lse, hipStream_t stream) {
   if (!Q || !K || !V || !QT || !KT || !dOh || !dOT || !L2 || !Dv || !dQ || !dK || !dV) return x2i_set_error(X2I_ERR_ARG, "attention_bwd: null pointer");
   if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention_bwd: Spad must be a multiple of 128 and >= S");
   const uintptr_t all = (uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)QT | (uintptr_t)KT | (uintptr_t)dOh | (uintptr_t)dOT |
@@ -388,7 +388,7 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
   if (all & 15) return x2i_set_error(X2I_ERR_ALIGN, "attention_bwd: pointers must be 16-byte aligned");
   const float scale_log2 = scale * 1.4426950408889634f;
   dim3 grid((Spad / 128) * H * B);
-  {
+  if (!have_lse) {  // statistics pass; skipped when the forward already wrote them (x2i_attention_lse_bf16)
     const int shm = 2 * 1 * TILE;
     hipLaunchKernelGGL((attn_bwd_kernel<2>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)nullptr, (const bf16_t*)K,
                        (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)nullptr, (bf16_t*)nullptr, H, S,

@@ -147,7 +147,7 @@ __device__ __forceinline__ void matrix_phase(const char* __restrict__ kb, const 
 template <int THR, bool OUT8, int SCH>
 __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ VT, bf16_t* __restrict__ O, int H, int S, int Spad,
-                                                      int ldo, long long o_bs, float scale_log2, int nbatch, float oinv) {
+                                                      int ldo, long long o_bs, float scale_log2, int nbatch, float oinv, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K[2] 32 KiB | VT[2] 32 KiB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -388,6 +388,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
   l_run = xhalf_sum(l_run);
   const float inv = 1.f / l_run;
   const int q = q0 + li;
+  if (lse && hi == 0 && q < Spad) lse[bh * Spad + q] = q < S ? m_run + __log2f(l_run) : 1.0e30f;  // see attention.hip
   if constexpr (OUT8) {
     uint8_t* orow8 = (uint8_t*)O + (long long)b * o_bs + (long long)q * ldo + h * 128;
     const float sc = inv * oinv;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_pp_kernel(const bf16_t* __restric
 
 // Launcher of the ping-pong form; returns X2I_ERR_STATE when the shape is not served (the caller then uses attn_fwd_kernel).
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
-                            long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr) {
+                            long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr, float* lse) {
   if (!out8 && ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7))) return X2I_ERR_STATE;  // 16-byte row stores only
   const int var = x2i_options().attn_variant;
   // schedule: 2 (four-deep rings, fragment prefetch in the vector phase; +2 % measured) for the bf16 / defer-max launches unless an
@@ -438,14 +439,14 @@ int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* 
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 1>, (int)shm);
     if (rc_) return rc_;
     hipLaunchKernelGGL((attn_pp_kernel<8, false, 1>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
-                       (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
+                       (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv, lse);
     return x2i_check_launch("attention");
   }
   if (sch == 2 && !out8) {
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 2>, (int)shm);
     if (rc_) return rc_;
     hipLaunchKernelGGL((attn_pp_kernel<8, false, 2>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT,
-                       (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);
+                       (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv, lse);
     return x2i_check_launch("attention");
   }
 #define X2I_PP(THR_, O8_)                                                                                                   \
@@ -453,7 +454,7 @@ int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* 
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<THR_, O8_, 0>, (int)shm);                           \
     if (rc_) return rc_;                                                                                                    \
     hipLaunchKernelGGL((attn_pp_kernel<THR_, O8_, 0>), grid, dim3(NTH), shm, stream, (const bf16_t*)Q, (const bf16_t*)K,    \
-                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv);                          \
+                       (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv, lse);                          \
   }
   if (out8) X2I_PP(8, true)
   else if (thr == 0) X2I_PP(0, false)

@@ -168,6 +168,12 @@ int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, in
   return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream);
 }
 
+int x2i_attention_lse_bf16(const void* Q, const void* K, const void* VT, void* O, float* lse2, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                           int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
+  if (!lse2 || (((uintptr_t)lse2) & 3)) return x2i_set_error(X2I_ERR_ARG, "attention_lse: lse2 must be a valid f32 pointer");
+  return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream, 0, 1.f, lse2);
+}
+
 int x2i_attention_e4m3out(const void* Q, const void* K, const void* VT, void* O8, int32_t B, int32_t H, int32_t S, int32_t Spad,
                           int32_t ldo, int64_t o_batch_stride, float scale, float out_inv_scale, x2i_stream_t stream) {
   return x2i_launch_attention(Q, K, VT, O8, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream, 1, out_inv_scale);
@@ -316,8 +322,8 @@ int x2i_adamw_bf16(void* p, const float* g, float* m, float* v, int64_t n, float
 
 int x2i_attention_bwd_bf16(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dO, const void* dOT, float* lse2,
                            const float* D, void* dQ, void* dK, void* dV, int32_t B, int32_t H, int32_t S, int32_t Spad, float scale,
-                           x2i_stream_t stream) {
-  return x2i_launch_attention_bwd(Q, K, V, QT, KT, dO, dOT, lse2, D, dQ, dK, dV, B, H, S, Spad, scale, (hipStream_t)stream);
+                           int32_t have_lse, x2i_stream_t stream) {
+  return x2i_launch_attention_bwd(Q, K, V, QT, KT, dO, dOT, lse2, D, dQ, dK, dV, B, H, S, Spad, scale, have_lse, (hipStream_t)stream);
 }
 int x2i_attention_bwd_prep_bf16(const void* dO, int64_t do_bs, int32_t lddo, const void* O, int64_t o_bs, int32_t ldo, float* D, int32_t B, int32_t H,
                                 int32_t S, int32_t Spad, x2i_stream_t stream) {

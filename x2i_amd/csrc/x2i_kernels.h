@@ -19,9 +19,9 @@ long long x2i_groupnorm_scratch(int B, int G);
 int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps,
                          int act, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
-                         long long o_bs, float scale, hipStream_t stream, int out8 = 0, float oinv = 1.f);
+                         long long o_bs, float scale, hipStream_t stream, int out8 = 0, float oinv = 1.f, float* lse = nullptr);
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
-                            long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr);
+                            long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr, float* lse);
 int x2i_launch_qkv_split(const void* qkv0, const void* qkv1, int ld0, int ld1, int B, int S, int S0, int H,
                          const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cosp,
                          const float* sinp, void* Q, void* K, void* VT, int Spad, float eps, hipStream_t stream);
@@ -79,6 +79,6 @@ int x2i_launch_adamw(void* p, const float* g, float* m, float* v, long long n, f
                      float bc2, const float* coef, hipStream_t stream);
 int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const void* QT, const void* KT, const void* dOh, const void* dOT,
                              float* L2, const float* Dv, void* dQ, void* dK, void* dV, int B, int H, int S, int Spad, float scale,
-                             hipStream_t stream);
+                             int have_lse, hipStream_t stream);
 int x2i_launch_attention_bwd_prep(const void* dO, long long do_bs, int lddo, const void* O, long long o_bs, int ldo, float* Dv, int B, int H,
                                   int S, int Spad, hipStream_t stream);

@@ -629,10 +629,16 @@ def adamw_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, coef=None):
     return p
 
 
-def attention_bwd(Q, K, V, QT, KT, dOh, dOT, lse2, Dv, dQ, dK, dV, B, H, S, Spad, scale):
-    """Fused attention backward (include/x2i.h: x2i_attention_bwd_bf16)."""
+def attention_bwd(Q, K, V, QT, KT, dOh, dOT, lse2, Dv, dQ, dK, dV, B, H, S, Spad, scale, have_lse=False):
+    """Fused attention backward (include/x2i.h: x2i_attention_bwd_bf16); have_lse: lse2 was written by attention_lse()."""
     check(_lib.load().x2i_attention_bwd_bf16(_p(Q), _p(K), _p(V), _p(QT), _p(KT), _p(dOh), _p(dOT), _p(lse2), _p(Dv), _p(dQ), _p(dK), _p(dV), B, H, S,
-                                             Spad, float(scale), _stream()), "attention_bwd")
+                                             Spad, float(scale), 1 if have_lse else 0, _stream()), "attention_bwd")
+
+
+def attention_lse(Q, K, VT, out, lse2, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0):
+    """attention() that also writes the log2-sum-exp statistics lse2 f32 [B,H,Spad] (x2i_attention_lse_bf16)."""
+    check(_lib.load().x2i_attention_lse_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), _p(lse2), B, H, S, Spad, ldo,
+                                             o_batch_stride, float(scale), _stream()), "attention_lse")
 
 
 def attention_bwd_prep(dO, O, Dv, B, H, S, Spad, *, do_bs, lddo, o_bs, ldo, do_offset=0, o_offset=0):

@@ -150,7 +150,8 @@ class DistillBackward:
                      ldc=3 * D)
             ops.qkv_split(qkv, qkv.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
                           f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
-            ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
+            sv["L"] = self._buf(p + ".L", (B, H, Spad), torch.float32)
+            ops.attention_lse(Q, K, VT, ATT, sv["L"], B, H, S, Spad, D, S * D, scale)
             OP = self._buf(p + ".OP", (B, S, D))
             ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=OP, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
@@ -189,7 +190,8 @@ class DistillBackward:
             IN = self._buf(p + ".IN", (B * S, 7 * D))   # [q|k|v pre-norm | proj_mlp pre-GELU]
             ops.gemm(NRM, w, bias, out=IN, M=B * S)
             ops.qkv_split(None, IN, 7 * D, 7 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
-            ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+            sv["L"] = self._buf(p + ".L", (B, H, Spad), torch.float32)
+            ops.attention_lse(Q, K, VT, CAT, sv["L"], B, H, S, Spad, 5 * D, S * 5 * D, scale)
             sv["O"] = self._keep(p + ".O", CAT.view(B, S, 5 * D)[:, :, :D])
             sv["G"] = tap(2, i, CAT.view(B, S, 5 * D), S, 5 * D)   # lists[2]: the un-projected joint attention output
             # GELU(proj_mlp) into CAT[:, D:]: one elementwise pass through the GEMM epilogue is not available here, so the kernel that
@@ -214,7 +216,7 @@ class DistillBackward:
 
     # ------------------------------------------------------------------ backward pieces
     @torch.no_grad()
-    def _attention_bwd(self, qkv0, qkv1, ld, S0, norms, dATT, ld_datt, dQKV0, dQKV1, O=None):
+    def _attention_bwd(self, qkv0, qkv1, ld, S0, norms, dATT, ld_datt, dQKV0, dQKV1, O=None, L=None):
         """d(q|k|v rows) from d(attention output) [B, S, *] (row stride ld_datt): recompute Q / K / V^T, then per sample the explicit
         P = softmax(scale Q K^T), dP = dO V^T, dS, dQ = dS K, dK = dS^T Q, dV = P^T dO -- all x2i_gemm_bf16 launches."""
         sv = self.saved
@@ -246,8 +248,8 @@ class DistillBackward:
                               in_offset=b * S * ld_datt)
             ops.transpose(w2["dOT"], w2["dOh"], batch=BH, R=128, C=Spad, in_bs=128 * Spad, ld_in=Spad, out_bs=Spad * 128, ld_out=128)
             ops.attention_bwd_prep(dATT, O, w2["D"], B, H, S, Spad, do_bs=S * ld_datt, lddo=ld_datt, o_bs=S * O.shape[-1], ldo=O.shape[-1])
-            ops.attention_bwd(Q, K, w2["V"], w2["QT"], w2["KT"], w2["dOh"], w2["dOT"], w2["L"], w2["D"], w2["dQ"], w2["dK"], w2["dV"], B, H, S,
-                              Spad, scale)
+            ops.attention_bwd(Q, K, w2["V"], w2["QT"], w2["KT"], w2["dOh"], w2["dOT"], L if L is not None else w2["L"], w2["D"], w2["dQ"], w2["dK"],
+                              w2["dV"], B, H, S, Spad, scale, have_lse=L is not None)
             ops.qkv_split_bwd(qkv0, qkv1, ld, ld, dQKV0, dQKV1, ld, ld, B, S, S0, H, nq0, nk0, nq1, nk1, cos, sin, w2["dQ"], w2["dK"], w2["dV"], Spad)
             return
         big = self.__dict__.get("_attn_ws")
@@ -341,7 +343,7 @@ class DistillBackward:
             # d proj_mlp pre-activation -> columns [3D, 7D) of dIN
             dIN.view(B * S, 7 * D)[:, 3 * D:].copy_(dCAT.view(B * S, 5 * D)[:, D:])
             ops.act_bwd_(dIN, s_["IN"], ACT_GELU_TANH, rows=B * S, cols=4 * D, ldd=7 * D, ldp=7 * D, d_offset=3 * D, p_offset=3 * D)
-            self._attention_bwd(None, s_["IN"], 7 * D, 0, (None, None, f[p + ".norm_q"], f[p + ".norm_k"]), dCAT, 5 * D, None, dIN, O=s_["O"])
+            self._attention_bwd(None, s_["IN"], 7 * D, 0, (None, None, f[p + ".norm_q"], f[p + ".norm_k"]), dCAT, 5 * D, None, dIN, O=s_["O"], L=s_["L"])
             ops.gemm(dIN, self._wt(p + ".in.w"), out=dN, M=B * S)
             ln_bwd(s_["Xin"], o + D, o, 0, S)
         # ---- double-stream blocks
@@ -377,7 +379,7 @@ class DistillBackward:
             img = B * St * 3 * D
             self._attention_bwd(d_["QKV"], d_["QKV"].view(-1)[img:], 3 * D, St,
                                 (f[p + ".norm_added_q"], f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"]), dATT, D, dQKV,
-                                dQKV.view(-1)[img:], O=d_["O"])
+                                dQKV.view(-1)[img:], O=d_["O"], L=d_["L"])
             ops.gemm(dQKV, self._wt(p + ".qkv.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 3 * D, lda=3 * D, a_offset=img,
                      c_batch_stride=S * D, ldc=D, c_offset=St * D)
             ops.gemm(dQKV, self._wt(p + ".cqkv.w"), out=dN, M=St, batch=B, a_batch_stride=St * 3 * D, lda=3 * D, c_batch_stride=S * D, ldc=D)
