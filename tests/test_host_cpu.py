@@ -221,3 +221,14 @@ def test_training_harness_arguments_and_schedules():
     assert TD.lr_factor("constant_with_warmup", 250, 500, 1000) == 0.5 and TD.lr_factor("constant_with_warmup", 900, 500, 1000) == 1.0
     assert abs(TD.lr_factor("linear", 750, 500, 1000) - 0.5) < 1e-12 and TD.lr_factor("linear", 1000, 500, 1000) == 0.0
     assert abs(TD.lr_factor("cosine", 750, 500, 1000) - 0.5) < 1e-12 and abs(TD.lr_factor("cosine", 500, 500, 1000) - 1.0) < 1e-12
+
+
+def test_generated_gemm_loop_is_current():
+    """csrc/gemm256w_loop.inc (the hand-scheduled K-loop of the 4-wave GEMM) is what csrc/gen_gemm256w.py emits: the generator asserts
+    the register / buffer hazards of its schedule table and derives the wait counts, so a stale or hand-edited .inc fails here."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = os.path.join(here, "x2i_amd", "csrc", "gen_gemm256w.py")
+    assert subprocess.run([sys.executable, gen, "--check"]).returncode == 0

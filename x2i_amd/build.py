@@ -29,7 +29,7 @@ def _hipcc():
 
 
 def _newest_header():
-    hs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     return max(os.path.getmtime(h) for h in hs)
 
 

@@ -102,9 +102,13 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   X2IOptions& opt = x2i_options();
   kern_t kern = pick_gemm128(p.act, res, f32, c2, conv);
   kern_t kern2 = pick_gemm256l(p.act, res, f32, c2, conv);
+  int threads2 = 512;
+  if (!conv && opt.gemm_w4) {  // plain GEMMs: the 4-wave kernel with the hand-scheduled K-loop (bit-identical results)
+    if (kern_t kw = pick_gemm256w(p.act, res, f32, c2)) kern2 = kw, threads2 = 256;
+  }
 #ifdef X2I_ABLATION
   // measurement-only library: the k-half-unit form (gemm_lform = 0) and its ablation variants replace the product kernel
-  if (!conv && (opt.gemm_ablate || !opt.gemm_lform)) kern2 = pick_gemm256u(p.act, res, f32, c2, opt.gemm_ablate);
+  if (!conv && (opt.gemm_ablate || !opt.gemm_lform)) kern2 = pick_gemm256u(p.act, res, f32, c2, opt.gemm_ablate), threads2 = 512;
 #endif
   const int force = opt.gemm_tile;  // 0 = automatic, 128 / 256 = A/B override
   const long long tiles256 = (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) * a->batch;
@@ -154,7 +158,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     }
     pm.M = (tm_main < tm_all) ? tm_main * BM2 : a->M;
     pm.tilesM = tm_main; pm.tilesN = tn;
-    hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(512), SMEM2_BYTES, stream, pm);
+    hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(threads2), SMEM2_BYTES, stream, pm);
     opt.last_gemm_tile = 256 + (tm_main < tm_all ? 1000 : 0);
     if (tm_main < tm_all) {
       rc = x2i_ensure_dynamic_smem((const void*)kern, 4 * TILE_BYTES);

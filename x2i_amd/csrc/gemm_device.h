@@ -293,34 +293,55 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
 //               writes two 16-byte token runs of VT [B,H,128,Spad]; 8 lanes cover a 128-byte line
 // Same arithmetic as qk_norm_rope_kernel / v_transpose_kernel (elementwise.hip), which remain the unfused form.
 // ------------------------------------------------------------------------------------------------------------
+// step 1: a wave parks one MT*16 x 64 bf16(acc + bias) sub-tile (tile columns n_col0 .. n_col0 + 63) in its LDS region
+template <int MT>
+__device__ __forceinline__ void qkv_park(const GemmP& p, f32x4_t (&acc)[MT][4], int n_col0, int lane, char* wave_lds) {
+  const int mlane = lane & 15, ng = lane >> 4;
+  static_for<4>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n_col0 + j * 16 + ng * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n + 3 < p.N) {
+      const uint2 bb = *(const uint2*)(p.bias + n);
+      bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
+      bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
+    }
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      *(uint2*)(wave_lds + (i * 16 + mlane) * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) =
+          make_uint2(pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
+    });
+  });
+}
+
+// step 2 (after a workgroup barrier): the parked tile -- regions indexed [(row / WR) * WN + (col >> 6)], WR rows x 64 columns each --
+// leaves in attention layout, NT threads
+template <int WR, int WN, int NT>
+__device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0, int lane, int tid, char* smem);
+
 template <int MT, int WN, int NT>
 __device__ __forceinline__ void epilogue_qkv(const GemmP& p, f32x4_t (&acc)[MT][4], int z, int m0, int n0, int wm, int wn, int lane,
                                              int tid, char* smem) {
-  constexpr int WR = MT * 16;  // rows per wave
-  constexpr int TR = 2 * WR;   // tile rows (two waves along M in both kernels)
+  qkv_park<MT>(p, acc, n0 + wn * 64, lane, smem + (wm * WN + wn) * (MT * 16 * EPI_ROW_BYTES));
+  __syncthreads();
+  qkv_finish<MT * 16, WN, NT>(p, z, m0, n0, lane, tid, smem);
+}
+
+// 4-wave 128 x 128 wave tiles (gemm256w.hip): a wave parks its two 64-column halves as the regions two 64-column waves would use
+__device__ __forceinline__ void epilogue_qkv_w4(const GemmP& p, f32x4_t (&acc)[2][8][4], int z, int m0, int n0, int wm, int wn, int lane,
+                                                int tid, char* smem) {
+  qkv_park<8>(p, acc[0], n0 + wn * 128, lane, smem + (wm * 4 + wn * 2) * (128 * EPI_ROW_BYTES));
+  qkv_park<8>(p, acc[1], n0 + wn * 128 + 64, lane, smem + (wm * 4 + wn * 2 + 1) * (128 * EPI_ROW_BYTES));
+  __syncthreads();
+  qkv_finish<128, 4, 256>(p, z, m0, n0, lane, tid, smem);
+}
+
+template <int WR, int WN, int NT>
+__device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0, int lane, int tid, char* smem) {
+  constexpr int TR = 2 * WR;   // tile rows (two waves / wave rows along M in every kernel)
   constexpr int TC = WN * 64;  // tile columns
   constexpr int REGION = WR * EPI_ROW_BYTES;
   constexpr int HEADS = TC / 128;
-  {
-    char* wave_lds = smem + (wm * WN + wn) * REGION;
-    const int mlane = lane & 15, ng = lane >> 4;
-    static_for<4>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const int n = n0 + wn * 64 + j * 16 + ng * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && n + 3 < p.N) {
-        const uint2 bb = *(const uint2*)(p.bias + n);
-        bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
-        bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
-      }
-      static_for<MT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        *(uint2*)(wave_lds + (i * 16 + mlane) * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) =
-            make_uint2(pack_bf16x2(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]), pack_bf16x2(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
-      });
-    });
-  }
-  __syncthreads();
   const int Dm = p.q_H * 128;
   const int sec = n0 / Dm;  // 0 = q, 1 = k, 2 = v (a tile never straddles sections: Dm % TC == 0, checked by the launcher)
   const int head0 = (n0 - sec * Dm) >> 7;
@@ -427,6 +448,7 @@ typedef void (*kern_t)(GemmP);
 // for this epilogue combination
 kern_t pick_gemm128(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
+kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION
 kern_t pick_gemm256u(int act, bool res, bool f32, bool c2, int abl);  // k-half-unit form + measurement-only variants

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K-loop of the 4-wave 256x256x64 bf16 GEMM (gemm256w.hip) -> gemm256w_loop.inc.
+
+The loop is ONE `asm volatile` statement (prologue + loop + drain): hipcc neither re-orders nor re-waits anything inside it, so the
+instruction stream below is exactly what the wave issues.  Organisation (one wave per SIMD, wave tile 128 x 128 = 8 x 8 accumulators
+of `v_mfma_f32_16x16x32_bf16`, 128 MFMAs per K-tile):
+
+  * two LDS tile buffers (A image 32 KiB | W image 32 KiB each, the full-line image of gemm256.hip); the fragments of a k-half live
+    in registers one k-half ahead (four sets of eight: wa/aa = k-half 0, wb/ab = k-half 1);
+  * while tile t is multiplied, tile t+1 is landing / has landed in the other buffer and tile t+2 is fetched INTO THE BUFFER OF TILE t,
+    operand by operand, as soon as a barrier has shown that every wave holds that operand's fragments of tile t in registers
+    (prefetch distance: more than one whole K-tile, with two buffers);
+  * LDS-DMA pieces, fragment reads and scalar bookkeeping sit one or two to a gap between MFMAs; waits are counted
+    (`vmcnt(N)` = the number of younger pieces that may stay in flight), never drains.
+
+The schedule is data: SLOTS maps "after MFMA k" to the events issued there; wait counts are derived by simulating the stream, and
+the register / buffer hazards are asserted (see check()).  `python gen_gemm256w.py` rewrites gemm256w_loop.inc (committed; a CPU
+test regenerates it and compares).
+"""
+import os
+import sys
+
+NF = 8  # fragments per operand per k-half (128 rows / 16)
+
+
+def acc(i, j):
+    return f"%[c{i * NF + j}]"
+
+
+# ------------------------------------------------------------------------------------------------ event vocabulary
+#   ("R1W", j) / ("R1A", i): read k-half 1 fragment of the CURRENT tile          -> wb[j] / ab[i]
+#   ("R0W", j) / ("R0A", i): read k-half 0 fragment of the NEXT tile             -> wa[j] / aa[i]
+#   ("XW",) / ("XA",):       flip the W / A fragment read address to the other buffer
+#   ("TL",n):                scalar bookkeeping for the tile to fetch (three SALU steps, n = 0..2)
+#   ("M0W", jj) / ("M0A", jj): set M0 for piece jj;  ("DW", jj) / ("DA", jj): issue the LDS-DMA piece
+#   ("XD",):                 flip the DMA destination buffer
+#   ("LGK", what):           s_waitcnt lgkmcnt(n) so that the reads named by `what` ("W1", "A1", "all") have returned
+#   ("VM", what):            s_waitcnt vmcnt(n) so that the NEXT tile's pieces of operand `what` ("W", "A") have landed
+#   ("BAR",):                s_barrier
+#   ("CNT", n):              loop counter (0: decrement, 1: compare)
+def default_slots():
+    s = {}
+
+    def put(k, *ev):
+        s.setdefault(k, []).extend(ev)
+
+    for j in range(8):
+        put(2 * j, ("R1W", j))
+    put(1, ("TL", 0)); put(3, ("TL", 1)); put(5, ("TL", 2))
+    put(15, ("XW",))
+    put(18, ("LGK", "W1")); put(19, ("BAR",))
+    k = 20
+    for jj in range(5):  # W pieces 0..4 interleaved with the A k-half-1 reads
+        put(k, ("M0W", jj)); put(k + 1, ("DW", jj)); put(k + 2, ("R1A", jj))
+        k += 3
+    put(36, ("R1A", 5)); put(38, ("R1A", 6)); put(40, ("R1A", 7)); put(41, ("XA",))
+    put(45, ("LGK", "A1")); put(46, ("BAR",))
+    put(47, ("M0W", 5)); put(48, ("DW", 5)); put(50, ("M0W", 6)); put(51, ("DW", 6)); put(53, ("M0W", 7)); put(54, ("DW", 7))
+    put(56, ("M0A", 0)); put(57, ("DA", 0)); put(59, ("M0A", 1)); put(60, ("DA", 1))
+    put(62, ("VM", "W")); put(63, ("BAR",))
+    for j in range(8):
+        put(64 + 2 * j, ("R0W", j))
+    k = 80
+    for jj in range(2, 7):
+        put(k, ("M0A", jj)); put(k + 1, ("DA", jj))
+        k += 3
+    put(96, ("VM", "A")); put(97, ("BAR",))
+    for i in range(8):
+        put(98 + 2 * i, ("R0A", i))
+    put(114, ("M0A", 7)); put(115, ("DA", 7)); put(116, ("XD",))
+    put(121, ("CNT", 0)); put(122, ("CNT", 1))
+    put(125, ("LGK", "all"))
+    return s
+
+
+def emit_event(ev, st):
+    """-> list of asm lines; st = running stream state used to derive the wait counts."""
+    kind = ev[0]
+    if kind in ("R1W", "R1A", "R0W", "R0A"):
+        n = ev[1]
+        half = 512 if kind[1] == "1" else 0
+        if kind[2] == "W":
+            reg, addr = (f"%[wb{n}]" if kind[1] == "1" else f"%[wa{n}]"), "%[lw]"
+        else:
+            reg, addr = (f"%[ab{n}]" if kind[1] == "1" else f"%[aa{n}]"), "%[la]"
+        st["ds"].append(kind + str(n))
+        off = n * 2048 + half
+        return [f"ds_read_b128 {reg}, {addr}" + (f" offset:{off}" if off else "")]
+    if kind == "XW":
+        return ["v_xor_b32 %[lw], 0x10000, %[lw]"]
+    if kind == "XA":
+        return ["v_xor_b32 %[la], 0x10000, %[la]"]
+    if kind == "TL":
+        return [["s_add_u32 %[tl], %[tl], 1", "s_min_u32 %[tmp], %[tl], %[nkm1]", "s_lshl_b32 %[koff], %[tmp], 7"][ev[1]]]
+    if kind == "M0W":
+        return [f"s_add_u32 m0, %[dma], {32768 + ev[1] * 4096}"]
+    if kind == "M0A":
+        return [f"s_add_u32 m0, %[dma], {ev[1] * 4096}" if ev[1] else "s_mov_b32 m0, %[dma]"]
+    if kind == "DW":
+        st["vm"].append(("W", st["iter"], ev[1]))
+        return [f"buffer_load_dwordx4 %[vw{ev[1]}], %[rw], %[koff] offen lds" + st["aux_w"]]
+    if kind == "DA":
+        st["vm"].append(("A", st["iter"], ev[1]))
+        return [f"buffer_load_dwordx4 %[va{ev[1]}], %[ra], %[koff] offen lds" + st["aux_a"]]
+    if kind == "XD":
+        return ["s_xor_b32 %[dma], %[dma], 0x10000"]
+    if kind == "BAR":
+        return ["s_barrier"]
+    if kind == "CNT":
+        return [["s_sub_u32 %[it], %[it], 1", "s_cmp_lg_u32 %[it], 0"][ev[1]]]
+    if kind == "LGK":
+        want = {"W1": "R1W", "A1": "R1A", "all": ""}[ev[1]]
+        last = max((i for i, d in enumerate(st["ds"]) if d.startswith(want)), default=None)
+        n = len(st["ds"]) - 1 - last if last is not None else 0
+        st["ds_waited"] = max(st.get("ds_waited", 0), (last + 1) if last is not None else 0)
+        return [f"s_waitcnt lgkmcnt({n})"]
+    if kind == "VM":
+        # pieces of operand ev[1] of the NEXT tile were issued one iteration ago (st['iter'] - 1)
+        idx = [i for i, (op, it, _) in enumerate(st["vm"]) if op == ev[1] and it == st["iter"] - 1]
+        assert idx, "no pieces of the next tile in the simulated stream"
+        n = len(st["vm"]) - 1 - max(idx)
+        assert n < 64
+        st["vm_n"][ev[1]] = n
+        return [f"s_waitcnt vmcnt({n})"]
+    raise ValueError(ev)
+
+
+def body(slots, st):
+    lines = []
+    for k in range(128):
+        kh, i, j = k >> 6, (k >> 3) & 7, k & 7
+        w = f"%[w{'ab'[kh]}{j}]"
+        a = f"%[a{'ab'[kh]}{i}]"
+        lines.append(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {w}, {a}, {acc(i, j)}")
+        for ev in slots.get(k, []):
+            lines += emit_event(ev, st)
+    return lines
+
+
+def check(slots):
+    """Static hazards of the schedule (register reuse, buffer reuse, wait coverage)."""
+    pos = {}
+    order = []
+    for k in sorted(slots):
+        for n, ev in enumerate(slots[k]):
+            pos[ev] = (k, n)
+            order.append(ev)
+    for j in range(8):
+        # wa[j] is read by MFMAs 8i + j (i = 0..7, k-half 0): last use 56 + j;  aa[i] by 8i .. 8i+7
+        assert pos[("R0W", j)][0] >= 56 + j, "wa[%d] overwritten before its last use" % j
+        assert pos[("R0A", j)][0] >= 8 * j + 7, "aa[%d] overwritten before its last use" % j
+        # k-half 1 fragments must be in registers before MFMA 64 + j (W) / 64 + 8i (A): covered by an LGK wait placed earlier
+        assert pos[("R1W", j)] < pos[("LGK", "W1")] and pos[("LGK", "W1")][0] < 64
+        assert pos[("R1A", j)] < pos[("LGK", "A1")] and pos[("LGK", "A1")][0] < 64
+        assert pos[("R1W", j)] < pos[("XW",)] < pos[("R0W", j)]
+        assert pos[("R1A", j)] < pos[("XA",)] < pos[("R0A", j)]
+        assert pos[("M0W", j)] < pos[("DW", j)] and pos[("M0A", j)] < pos[("DA", j)]
+        assert pos[("DW", j)] < pos[("XD",)] and pos[("DA", j)] < pos[("XD",)]
+    bars = [pos[e] for e in order if e == ("BAR",)]
+    # barrier after the W (A) k-half-1 reads have returned, before the first W (A) piece overwrites the current buffer
+    barpos = sorted(p for e, p in pos.items() if e[0] == "BAR")
+    # (BAR events are identical tuples: recover their positions from the slot table)
+    barpos = sorted((k, n) for k in slots for n, ev in enumerate(slots[k]) if ev == ("BAR",))
+    assert len(barpos) == 4
+    assert pos[("LGK", "W1")] < barpos[0] < min(pos[("DW", j)] for j in range(8))
+    assert pos[("LGK", "A1")] < barpos[1] < min(pos[("DA", j)] for j in range(8))
+    assert pos[("VM", "W")] < barpos[2] < min(pos[("R0W", j)] for j in range(8))
+    assert pos[("VM", "A")] < barpos[3] < min(pos[("R0A", j)] for j in range(8))
+    # M0 must be written at least one instruction (here: an MFMA) before the piece that uses it, and not be overwritten in between
+    m0w = sorted((pos[e], e) for e in pos if e[0] in ("M0W", "M0A", "DW", "DA"))
+    for (p0, e0), (p1, e1) in zip(m0w[::2], m0w[1::2]):
+        assert e0[0].startswith("M0") and e1[0].startswith("D") and e0[1] == e1[1] and e0[0][2] == e1[0][1], (e0, e1)
+        assert p1[0] > p0[0], "M0 write and its piece must be separated by an MFMA"
+    # SCC: the compare must be the last SCC-writing scalar instruction of the body
+    assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0W", "M0A", "XD") or e == ("CNT", 0))
+    assert pos[("LGK", "all")] > max(pos[("R0A", j)] for j in range(8))
+    del bars
+
+
+def generate(aux_a="", aux_w=""):
+    slots = default_slots()
+    check(slots)
+    st = dict(ds=[], vm=[], iter=0, aux_a=aux_a, aux_w=aux_w, vm_n={})
+    L = []
+    L.append("s_nop 4")  # scalar operands may be fresh from v_readfirstlane
+    L.append("s_sub_u32 %[nkm1], %[nk], 1")
+    L.append("s_mov_b32 %[koff], 0")
+    # ---- prologue: tile 0 -> buffer 0 (any order), tile 1 (clamped to the last tile) -> buffer 1 in the loop's order (W, then A)
+    for jj in range(8):
+        L += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+    for jj in range(8):
+        L += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+    L += ["s_min_u32 %[tl], %[nkm1], 1", "s_lshl_b32 %[koff], %[tl], 7"]
+    st["iter"] = -1
+    for jj in range(8):
+        L += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+        st["vm"].append(("W", -1, jj))
+    for jj in range(8):
+        L += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+        st["vm"].append(("A", -1, jj))
+    L += ["s_mov_b32 %[tl], 1", "s_mov_b32 %[it], %[nk]"]
+    L += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    for j in range(8):
+        L.append(f"ds_read_b128 %[wa{j}], %[lw]" + (f" offset:{j * 2048}" if j else ""))
+    for i in range(8):
+        L.append(f"ds_read_b128 %[aa{i}], %[la]" + (f" offset:{i * 2048}" if i else ""))
+    L.append("s_waitcnt lgkmcnt(0)")
+    # ---- steady state: simulate iteration 0 (behind the prologue) and iteration 1; their wait counts must agree
+    st["iter"] = 0
+    st["ds"] = []
+    b0 = body(slots, st)
+    n0 = dict(st["vm_n"])
+    st["iter"] = 1
+    st["ds"] = []
+    b1 = body(slots, st)
+    assert b0 == b1 and n0 == st["vm_n"], "the wait counts of the first and of a steady-state iteration differ"
+    L.append("1:")
+    L += b0
+    L.append("s_cbranch_scc1 1b")
+    L += ["s_waitcnt vmcnt(0)", "s_barrier", "s_nop 7", "s_nop 7"]
+    return L, st["vm_n"]
+
+
+OPERANDS_DOC = """// operands of X2I_GEMM256W_LOOP (all named):
+//   c0..c63   "+a"  f32x4  accumulators, c[i*8 + j] = rows 16i.., columns 16j.. of the wave tile
+//   wa0..7, wb0..7, aa0..7, ab0..7  "=&v" bf16x8 fragment registers (scratch)
+//   va0..7, vw0..7  "v"  per-piece byte offsets of this lane's 16 bytes (0x80000000 = out of range -> zeros)
+//   la, lw    "+v"  LDS byte address of this lane's A / W fragment read in buffer 0
+//   ra, rw    "s"   buffer descriptors of A / W
+//   dma       "+s"  LDS byte address of this wave's first A piece in buffer 0 (wave * 1024)
+//   nk        "s"   number of K-tiles (>= 1)
+//   nkm1, koff, tl, tmp, it  "=&s" scratch
+"""
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm256w_loop.inc")
+    variants = {"X2I_GEMM256W_LOOP": ("", "")}
+    txt = ["// GENERATED by gen_gemm256w.py -- do not edit; the schedule table lives in the generator.", OPERANDS_DOC]
+    for name, (aa, aw) in variants.items():
+        L, vm = generate(aa, aw)
+        txt.append(f"// {name}: {len(L)} lines; vmcnt before the next tile's W / A fragments are read: {vm['W']} / {vm['A']}")
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{l}\\n" \\' for l in L[:-1]]
+        txt.append(f'  "{L[-1]}\\n"')
+        txt.append("")
+    # operand lists (the asm statement itself is written out in gemm256w.hip)
+    accs = ", ".join(f'[c{i * NF + j}] "+a"(acc[{j >> 2}][{i}][{j & 3}])' for i in range(NF) for j in range(NF))
+    txt.append("// acc[h][i][jj]: rows 16i.., columns 64h + 16jj.. of the 128 x 128 wave tile (two halves in the layout the shared epilogues take)")
+    txt.append(f"#define X2I_GEMM256W_OPS_ACC(acc) {accs}")
+    frs = ", ".join(f'[{nm}{n}] "=&v"(fr[{b * 8 + n}])' for b, nm in enumerate(("wa", "wb", "aa", "ab")) for n in range(NF))
+    txt.append(f"#define X2I_GEMM256W_OPS_FRAG(fr) {frs}")
+    vo = ", ".join(f'[va{n}] "v"(va[{n}])' for n in range(NF)) + ", " + ", ".join(f'[vw{n}] "v"(vw[{n}])' for n in range(NF))
+    txt.append(f"#define X2I_GEMM256W_OPS_VOFF(va, vw) {vo}")
+    txt.append("")
+    data = "\n".join(txt)
+    if "--check" in sys.argv:
+        cur = open(out).read() if os.path.exists(out) else ""
+        sys.exit(0 if cur == data else 1)
+    with open(out, "w") as fh:
+        fh.write(data)
+    print(f"wrote {out}")
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@ struct X2IOptions {
   long long gemm_min256;  // minimum number of 256^2 tiles for the 256^2 kernel (default 128)            X2I_GEMM_MIN256
   int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
   int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
+  int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
   int conv5_variant;      // matrix-core projector conv: 0 = automatic form choice; 1 = plain stages, 2 = pipelined, 3 = two row blocks   X2I_CONV5_VARIANT
