@@ -50,7 +50,7 @@ const char* x2i_last_error(void);
 /* A/B and tuning switches.  Defaults are the product configuration; each option is initialised ONCE (first use) from the
  * environment variable X2I_<NAME> and afterwards only changes through x2i_set_option -- nothing on the launch path reads
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1), "gemm_w4" (1: 4-wave
- * hand-scheduled 256^2 kernel; 0: the 8-wave form), "conv256" (1), "attn_variant" (0), "conv5_variant" (0), "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
+ * hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output tiles), "conv256" (1), "attn_variant" (0), "conv5_variant" (0), "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
  * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
  * return X2I_ERR_ARG.  Every setting selects between
  * kernels with identical results (bit-identical where the tests say so); the measurement-only kernels ("wrong results by

@@ -53,20 +53,21 @@ def main():
     for (M, N, K, name) in shapes:
         A, W, b = rnd(M, K), rnd(N, K, scale=0.02), rnd(N)
         out = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
-        def x2i(w4):
+        def x2i(w4, persist=1):
             _lib.set_option("gemm_w4", w4)
+            _lib.set_option("gemm_persist", persist)
             ops.gemm(A, W, b, out=out)
 
-        fns = {"vendor": lambda: F.linear(A, W, b), "x2i": lambda: x2i(1), "x2i_8wave": lambda: x2i(0)}
+        fns = {"vendor": lambda: F.linear(A, W, b), "x2i": lambda: x2i(1), "x2i_w4_onetile": lambda: x2i(1, 0), "x2i_8wave": lambda: x2i(0)}
         r = time_rounds(fns)
-        _lib.set_option("gemm_w4", 1)
-        ops.gemm(A, W, b, out=out)
+        x2i(1, 1)
         fl = 2.0 * M * N * K
         ref = F.linear(A, W, b).float()
         err = ((out.float() - ref).norm() / ref.norm()).item()
         print(json.dumps({"shape": name, "M": M, "N": N, "K": K,
                           "vendor_TF_median": round(fl / r["vendor"][0] / 1e12, 1), "vendor_TF_best": round(fl / r["vendor"][1] / 1e12, 1),
                           "x2i_TF_median": round(fl / r["x2i"][0] / 1e12, 1), "x2i_TF_best": round(fl / r["x2i"][1] / 1e12, 1),
+                          "x2i_w4_onetile_TF_median": round(fl / r["x2i_w4_onetile"][0] / 1e12, 1),
                           "x2i_8wave_TF_median": round(fl / r["x2i_8wave"][0] / 1e12, 1),
                           "x2i_tile": _lib.get_option("last_gemm_tile"), "rel_l2_vs_vendor": err}), flush=True)
         del A, W, out, ref

@@ -42,6 +42,7 @@ X2IOptions make_options() {
   o.gemm_gm = env_int("X2I_GEMM_GM", 0);
   o.gemm_split_tail = env_int("X2I_GEMM_NOSPLIT", 0) ? 0 : 1;
   o.gemm_w4 = env_int("X2I_GEMM_W4", 1);
+  o.gemm_persist = env_int("X2I_GEMM_PERSIST", 1);
   o.conv256 = env_int("X2I_CONV256", 1);
   o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
   o.conv5_variant = env_int("X2I_CONV5_VARIANT", 0);
@@ -73,6 +74,19 @@ int x2i_ensure_dynamic_smem(const void* kernel, int bytes) {
   return X2I_OK;
 }
 
+int x2i_num_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 extern "C" {
 
 int x2i_abi_version(void) { return X2I_ABI_VERSION; }
@@ -80,7 +94,7 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
   X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate)
 #endif

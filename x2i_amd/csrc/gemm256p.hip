@@ -1,0 +1,238 @@
+// Persistent form of the 4-wave 256x256x64 bf16 GEMM (gemm256w.hip): one workgroup per CU walks a list of output tiles and the
+// K-loop never stops at a tile boundary -- the last two K-iterations of a tile fetch K-tiles 0 / 1 of the workgroup's NEXT output
+// tile (gen_gemm256w.py, X2I_GEMM256P_MAIN), so the epilogue of tile n (accumulators -> LDS staging -> whole-line stores) runs with
+// the operands of tile n+1 already landing, and tile n+1 starts multiplying straight out of registers.  LDS: 128 KiB operand ring +
+// 4 x 8 KiB per-wave staging = all 160 KiB; epilogues leave in 32-row chunks.  Same image / MFMA / k order as every other bf16
+// GEMM kernel here: bit-identical results (tested).  Launcher: gemm.hip (plain batch-1 launches with whole-line epilogues).
+#include "gemm_device.h"
+#include "gemm256w_loop.inc"
+
+namespace x2i_gemm {
+namespace {
+
+constexpr int P_STAGE_OFF = 2 * TILE2_BYTES;  // 128 KiB: behind the two operand buffers
+constexpr int P_STAGE_WAVE = 8192;
+
+// Epilogue of one wave (128 x 128 outputs) in eight 32-row x 64-column chunks through a double-buffered 2 x 4 KiB staging area.
+// Image of a chunk: [32 rows][128 B], 16-byte chunk ch of row r at physical chunk ch ^ ((r >> 1) & 7); a lane parks its four
+// consecutive columns with one ds_write_b64, rows leave as whole 128-byte lines (16-byte stores, 8 lines per wave instruction).
+// RES: the residual rows of chunk q+1 are fetched by LDS-DMA (swizzle applied on the source address) into the other buffer while
+// chunk q is combined in place and stored; the wait for a chunk's rows is COUNTED (the previous chunk's four stores and the next
+// chunk's four pieces stay in flight) -- a vmcnt(0) per chunk would serialise the epilogue on store latency.  Bias / gate vectors are
+// loaded once, up front, for the same reason (a load behind a store is waited for with the store).  Same arithmetic (explicit fmaf,
+// same rounding points) as epilogue_store_lds: bit-identical results.
+template <int ACT, bool RES, bool HASC2>
+__device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int m_wave, int n_wave, int lane, char* stage) {
+  const int mlane = lane & 15, ng = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  bf16_t* Cz = (bf16_t*)p.C;
+  float bv[8][4], gv[8][4];
+  static_for<8>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n_wave + j * 16 + ng * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f, gv[j][r] = 1.f;
+    if (n + 3 < p.N) {
+      if (p.bias) {
+        const uint2 bb = *(const uint2*)(p.bias + n);
+        bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
+        bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
+      }
+      if (RES && p.gate) {
+        const f32x4_t g4 = *(const f32x4_t*)(p.gate + n);
+        gv[j][0] = g4[0]; gv[j][1] = g4[1]; gv[j][2] = g4[2]; gv[j][3] = g4[3];
+      }
+      if (p.bias2) {
+        const f32x4_t t4 = *(const f32x4_t*)(p.bias2 + n);
+        bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
+      }
+    }
+  });
+  __amdgpu_buffer_rsrc_t r_rsrc;
+  if constexpr (RES)
+    r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
+  auto issue = [&](int q) {  // chunk q = h*4 + c  ->  rows m_wave + 32c .., columns n_wave + 64h ..
+    if constexpr (RES) {
+      const int h = q >> 2, c = q & 3;
+      char* buf = stage + (q & 1) * 4096;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + srow;
+        const int m = m_wave + c * 32 + row, n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
+        const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((long long)m * p.ldr + n) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (__attribute__((address_space(3))) void*)(buf + it * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  asm volatile("" ::: "memory");  // the bias / gate loads stay in front of everything below
+  issue(0);
+  static_for<8>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int h = q >> 2, c = q & 3;
+    char* buf = stage + (q & 1) * 4096;
+    // keep each chunk's accumulator reads (v_accvgpr_read) inside the chunk: hoisted to the top they would need 256 VGPRs at once,
+    // on top of the next tile's fragments that stay live across the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (q + 1 < 8) issue(q + 1);
+    if constexpr (RES) {
+      // chunk q's four pieces have landed once at most {chunk q-1's 4 stores + chunk q+1's 4 pieces} remain in flight
+      if constexpr (q == 0 || q == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    // The accumulators stay in the accumulator file until their chunk: explicit v_accvgpr_read here.  (Left to hipcc, all 256 are
+    // copied to VGPRs straight behind the K-loop statement, which spills the next tile's fragments that are live across the epilogue.)
+    float av[2][4][4];
+    static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t;
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
+          av[i][j][r] = t;
+        }
+      });
+    });
+    constexpr int NPASS = HASC2 ? 2 : 1;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<2>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const int row = i * 16 + mlane;
+          char* slot = buf + row * 128 + ((((j << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(av[i][j][r] + bv[h * 4 + j][r], ACT);
+          if constexpr (RES) {
+            const uint2 r2 = *(const uint2*)slot;
+            v[0] = fmaf(gv[h * 4 + j][0], v[0], __uint_as_float(r2.x << 16));
+            v[1] = fmaf(gv[h * 4 + j][1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+            v[2] = fmaf(gv[h * 4 + j][2], v[2], __uint_as_float(r2.y << 16));
+            v[3] = fmaf(gv[h * 4 + j][3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+          }
+          if (pass == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
+          }
+          *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bf16_t* dst = (pass == 0) ? Cz : p.C2;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + srow;
+        const bf16x8_t d = *(const bf16x8_t*)(buf + it * 1024 + lane * 16);
+        const int m = m_wave + c * 32 + row, n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
+        if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
+      }
+      // the rows have left the buffer before it is written again (next pass / chunk q+2's pieces, issued at the top of step q+1)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  });
+}
+
+template <int ACT, bool RES, bool HASC2>
+__global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A image 32 KiB | W image 32 KiB][4 waves x 8 KiB staging]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int T = p.tilesM * p.tilesN;
+  const int G = gridDim.x;
+
+  auto tile_of = [&](int bid, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = p.gm;
+    const int per_group = GM * p.tilesN;
+    const int group = bid / per_group;
+    const int first_m = group * GM;
+    const int gsize = min(p.tilesM - first_m, GM);
+    m0 = (first_m + (bid % per_group) % gsize) * BM2;
+    n0 = ((bid % per_group) / gsize) * BN2;
+  };
+  const int khl = lane >> 5, r8 = (lane >> 2) & 7, cphys = lane & 3;
+  const int kel = khl * 32 + ((cphys ^ (3 * (wave & 1))) << 3);  // group parity = wave parity (4 pieces per row-group step)
+  auto offsets = [&](int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int row = (jj * 4 + wave) * 8 + r8;
+      va[jj] = (m0 + row < p.M) ? (uint32_t)(((long long)(m0 + row) * p.lda + kel) * 2) : 0x80000000u;
+      vw[jj] = (n0 + row < p.N) ? (uint32_t)(((long long)(n0 + row) * p.ldw + kel) * 2) : 0x80000000u;
+    }
+  };
+
+  const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
+  __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+  const int frow = lane & 15;
+  const uint32_t frag = (frow >> 3) * 1024 + (frow & 7) * 64 + (((lane >> 4) ^ (3 * ((frow >> 3) & 1))) << 4);
+  uint32_t la = (uint32_t)(uintptr_t)smem + wm * 8 * 2048 + frag;
+  uint32_t lw = (uint32_t)(uintptr_t)smem + 32768 + wn * 8 * 2048 + frag;
+  uint32_t dma = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 1024);
+  const int nk = p.K / BK;
+  char* stage = smem + P_STAGE_OFF + wave * P_STAGE_WAVE;
+
+  int bid = blockIdx.x;
+  int m0, n0;
+  tile_of(bid, m0, n0);
+  uint32_t va[8], vw[8], na[8], nw[8];
+  offsets(m0, n0, va, vw);
+  bf16x8_t fr[32];  // wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31
+  uint32_t s_koff, s_it;
+  asm volatile(X2I_GEMM256P_PRO
+               : X2I_GEMM256P_OPS_FRAG0_OUT(fr), [koff] "=&s"(s_koff)
+               : X2I_GEMM256W_OPS_VOFF(va, vw), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc)
+               : "memory", "scc");
+  for (;;) {
+    const int nbid = bid + G;
+    const bool has_next = nbid < T;
+    int nm0 = 0, nn0 = 0;
+    if (has_next) {
+      tile_of(nbid, nm0, nn0);
+      offsets(nm0, nn0, na, nw);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) na[jj] = nw[jj] = 0x80000000u;  // behind the last tile: every piece out of range (zero fill, no fetch)
+    }
+    f32x4_t acc[2][4][2][4];  // written from zero by the first K-tile (C = 0 operand): no clearing pass
+    asm volatile(X2I_GEMM256P_MAIN_Z
+                 : X2I_GEMM256P_OPS_ACC_OUT(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
+                   [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
+                 : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nk] "s"(nk)
+                 : "memory", "scc");
+    // ---- epilogue of (m0, n0): per-wave private staging, no workgroup barrier; the next tile's first two K-tiles are in flight
+    const int m_wave = m0 + wm * 128, n_wave = n0 + wn * 128;
+    epilogue_chunked<ACT, RES, HASC2>(p, acc, m_wave, n_wave, lane, stage);
+    if (!has_next) break;
+    bid = nbid; m0 = nm0; n0 = nn0;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) va[jj] = na[jj], vw[jj] = nw[jj];
+  }
+  asm volatile(X2I_GEMM256P_DRAIN ::: "memory");
+}
+
+}  // namespace
+
+kern_t pick_gemm256p(int act, bool res, bool f32, bool c2) {
+  if (f32) return nullptr;
+  if (res) return (act == X2I_ACT_NONE && !c2) ? (kern_t)gemm256p_bf16_kernel<X2I_ACT_NONE, true, false> : nullptr;
+  if (c2) return act == X2I_ACT_NONE ? (kern_t)gemm256p_bf16_kernel<X2I_ACT_NONE, false, true> : nullptr;
+  switch (act) {
+    case X2I_ACT_NONE: return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false>;
+    case X2I_ACT_GELU_TANH: return gemm256p_bf16_kernel<X2I_ACT_GELU_TANH, false, false>;
+    case X2I_ACT_GELU_ERF: return gemm256p_bf16_kernel<X2I_ACT_GELU_ERF, false, false>;
+    case X2I_ACT_SILU: return gemm256p_bf16_kernel<X2I_ACT_SILU, false, false>;
+    case X2I_ACT_RELU: return gemm256p_bf16_kernel<X2I_ACT_RELU, false, false>;
+  }
+  return nullptr;
+}
+
+}  // namespace x2i_gemm

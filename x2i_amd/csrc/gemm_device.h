@@ -449,6 +449,8 @@ typedef void (*kern_t)(GemmP);
 kern_t pick_gemm128(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
+kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop, persistent over output tiles (gemm256p.hip)
+constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION
 kern_t pick_gemm256u(int act, bool res, bool f32, bool c2, int abl);  // k-half-unit form + measurement-only variants

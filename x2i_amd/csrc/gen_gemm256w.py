@@ -90,23 +90,32 @@ def emit_event(ev, st):
         return ["v_xor_b32 %[lw], 0x10000, %[lw]"]
     if kind == "XA":
         return ["v_xor_b32 %[la], 0x10000, %[la]"]
+    mode = st.get("mode", "W")
     if kind == "TL":
-        return [["s_add_u32 %[tl], %[tl], 1", "s_min_u32 %[tmp], %[tl], %[nkm1]", "s_lshl_b32 %[koff], %[tmp], 7"][ev[1]]]
+        if mode == "W":  # one-tile kernel: fetch tile min(t + 2, nk - 1)
+            return [["s_add_u32 %[tl], %[tl], 1", "s_min_u32 %[tmp], %[tl], %[nkm1]", "s_lshl_b32 %[koff], %[tmp], 7"][ev[1]]]
+        if mode in ("B1", "B2"):  # last two K-tiles of an output tile: fetch K-tiles 0 / 1 of the NEXT output tile
+            return [f"s_mov_b32 %[koff], {0 if mode == 'B1' else 128}"] if ev[1] == 0 else []
+        return []  # mode "A": koff advances behind the last piece (XD)
     if kind == "M0W":
         return [f"s_add_u32 m0, %[dma], {32768 + ev[1] * 4096}"]
     if kind == "M0A":
         return [f"s_add_u32 m0, %[dma], {ev[1] * 4096}" if ev[1] else "s_mov_b32 m0, %[dma]"]
     if kind == "DW":
         st["vm"].append(("W", st["iter"], ev[1]))
-        return [f"buffer_load_dwordx4 %[vw{ev[1]}], %[rw], %[koff] offen lds" + st["aux_w"]]
+        v = "nw" if mode in ("B1", "B2") else "vw"
+        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[rw], %[koff] offen lds" + st["aux_w"]]
     if kind == "DA":
         st["vm"].append(("A", st["iter"], ev[1]))
-        return [f"buffer_load_dwordx4 %[va{ev[1]}], %[ra], %[koff] offen lds" + st["aux_a"]]
+        v = "na" if mode in ("B1", "B2") else "va"
+        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[ra], %[koff] offen lds" + st["aux_a"]]
     if kind == "XD":
-        return ["s_xor_b32 %[dma], %[dma], 0x10000"]
+        return ["s_xor_b32 %[dma], %[dma], 0x10000"] + (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" else [])
     if kind == "BAR":
         return ["s_barrier"]
     if kind == "CNT":
+        if mode in ("B1", "B2"):
+            return []
         return [["s_sub_u32 %[it], %[it], 1", "s_cmp_lg_u32 %[it], 0"][ev[1]]]
     if kind == "LGK":
         want = {"W1": "R1W", "A1": "R1A", "all": ""}[ev[1]]
@@ -125,13 +134,14 @@ def emit_event(ev, st):
     raise ValueError(ev)
 
 
-def body(slots, st):
+def body(slots, st, zero=False):
+    """zero = True: the first K-tile of an output tile -- k-half 0 takes the constant 0 as its C operand (no accumulator clearing)."""
     lines = []
     for k in range(128):
         kh, i, j = k >> 6, (k >> 3) & 7, k & 7
         w = f"%[w{'ab'[kh]}{j}]"
         a = f"%[a{'ab'[kh]}{i}]"
-        lines.append(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {w}, {a}, {acc(i, j)}")
+        lines.append(f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {w}, {a}, " + ("0" if zero and kh == 0 else acc(i, j)))
         for ev in slots.get(k, []):
             lines += emit_event(ev, st)
     return lines
@@ -221,6 +231,54 @@ def generate(aux_a="", aux_w=""):
     return L, st["vm_n"]
 
 
+def generate_persistent(aux_a="", aux_w=""):
+    """Seamless form for the persistent kernel: PRO (first output tile of a workgroup: K-tiles 0 and 1, first fragments), MAIN (the nk
+    K-tiles of one output tile; the last two iterations fetch K-tiles 0 / 1 of the NEXT output tile through the `na` / `nw` offsets and
+    leave its first fragments in wa / aa, so the next MAIN starts multiplying at once), DRAIN (after the last tile)."""
+    slots = default_slots()
+    check(slots)
+    st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A")
+    P = ["s_nop 4", "s_mov_b32 %[koff], 0"]
+    for jj in range(8):
+        P += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+    for jj in range(8):
+        P += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+    P += ["s_mov_b32 %[koff], 128"]
+    for jj in range(8):
+        P += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+        st["vm"].append(("W", -1, jj))
+    for jj in range(8):
+        P += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+        st["vm"].append(("A", -1, jj))
+    P += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    for j in range(8):
+        P.append(f"ds_read_b128 %[wa{j}], %[lw]" + (f" offset:{j * 2048}" if j else ""))
+    for i in range(8):
+        P.append(f"ds_read_b128 %[aa{i}], %[la]" + (f" offset:{i * 2048}" if i else ""))
+    P.append("s_waitcnt lgkmcnt(0)")
+    # simulate PRO, A, A, B1, B2, A (next output tile): every body must derive the same wait counts
+    bodies, counts = {}, []
+    for it, mode in enumerate(["A", "A", "B1", "B2", "A"]):
+        st["iter"], st["ds"], st["mode"] = it, [], mode
+        b = body(slots, st)
+        counts.append(dict(st["vm_n"]))
+        if mode in bodies:
+            assert bodies[mode] == b
+        bodies[mode] = b
+    assert all(c == counts[0] for c in counts), counts
+    # MAIN_C: continue from the accumulators handed in ("+a"; nk >= 2)
+    MC = ["s_nop 4", "s_mov_b32 %[koff], 256", "s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[it], 0", "s_cbranch_scc0 2f", "1:"]
+    MC += bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
+    # MAIN_Z: start from zero ("=&a"; nk >= 3): the first iteration is a copy of body A whose k-half 0 has C = 0; its loop test falls
+    # through to the last two iterations when nk == 3
+    st["iter"], st["ds"], st["mode"] = 5, [], "A"
+    a0 = body(slots, st, zero=True)
+    MZ = ["s_nop 4", "s_mov_b32 %[koff], 256", "s_sub_u32 %[it], %[nk], 2"] + a0 + ["s_cbranch_scc0 2f", "1:"]
+    MZ += bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
+    D = ["s_waitcnt vmcnt(0)", "s_barrier"]
+    return P, MC, MZ, D, counts[0]
+
+
 OPERANDS_DOC = """// operands of X2I_GEMM256W_LOOP (all named):
 //   c0..c63   "+a"  f32x4  accumulators, c[i*8 + j] = rows 16i.., columns 16j.. of the wave tile
 //   wa0..7, wb0..7, aa0..7, ab0..7  "=&v" bf16x8 fragment registers (scratch)
@@ -244,6 +302,15 @@ def main():
         txt += [f'  "{l}\\n" \\' for l in L[:-1]]
         txt.append(f'  "{L[-1]}\\n"')
         txt.append("")
+    P, MC, MZ, D, vm = generate_persistent()
+    txt.append("// persistent (seamless) form -- additional operands: wa0..7 / aa0..7 are \"+v\" (live between the statements), na0..7 / nw0..7 \"v\" = the NEXT")
+    txt.append("// output tile's piece offsets (0x80000000 everywhere behind the last tile); nk >= 2")
+    for name, L in (("X2I_GEMM256P_PRO", P), ("X2I_GEMM256P_MAIN_C", MC), ("X2I_GEMM256P_MAIN_Z", MZ), ("X2I_GEMM256P_DRAIN", D)):
+        txt.append(f"// {name}: {len(L)} lines" + (f"; vmcnt W / A: {vm['W']} / {vm['A']}" if "MAIN" in name else ""))
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{l}\\n" \\' for l in L[:-1]]
+        txt.append(f'  "{L[-1]}\\n"')
+        txt.append("")
     # operand lists (the asm statement itself is written out in gemm256w.hip)
     accs = ", ".join(f'[c{i * NF + j}] "+a"(acc[{j >> 2}][{i}][{j & 3}])' for i in range(NF) for j in range(NF))
     txt.append("// acc[h][i][jj]: rows 16i.., columns 64h + 16jj.. of the 128 x 128 wave tile (two halves in the layout the shared epilogues take)")
@@ -252,6 +319,17 @@ def main():
     txt.append(f"#define X2I_GEMM256W_OPS_FRAG(fr) {frs}")
     vo = ", ".join(f'[va{n}] "v"(va[{n}])' for n in range(NF)) + ", " + ", ".join(f'[vw{n}] "v"(vw[{n}])' for n in range(NF))
     txt.append(f"#define X2I_GEMM256W_OPS_VOFF(va, vw) {vo}")
+    txt.append("// persistent kernel: acc[h][c][r][jj] = rows 32c + 16r.., columns 64h + 16jj.. (the epilogue leaves in 32-row chunks)")
+    for con, tag in (("+a", "IO"), ("=&a", "OUT")):
+        accp = ", ".join(f'[c{i * NF + j}] "{con}"(acc[{j >> 2}][{i >> 1}][{i & 1}][{j & 3}])' for i in range(NF) for j in range(NF))
+        txt.append(f"#define X2I_GEMM256P_OPS_ACC_{tag}(acc) {accp}")
+    for con, tag in (("+v", "IO"), ("=&v", "OUT")):
+        f0 = ", ".join(f'[{nm}{n}] "{con}"(fr[{b * 8 + n}])' for b, nm in ((0, "wa"), (2, "aa")) for n in range(NF))
+        txt.append(f"#define X2I_GEMM256P_OPS_FRAG0_{tag}(fr) {f0}")
+    f1 = ", ".join(f'[{nm}{n}] "=&v"(fr[{b * 8 + n}])' for b, nm in ((1, "wb"), (3, "ab")) for n in range(NF))
+    txt.append(f"#define X2I_GEMM256P_OPS_FRAG1(fr) {f1}")
+    nx = ", ".join(f'[na{n}] "v"(na[{n}])' for n in range(NF)) + ", " + ", ".join(f'[nw{n}] "v"(nw[{n}])' for n in range(NF))
+    txt.append(f"#define X2I_GEMM256P_OPS_NEXT(na, nw) {nx}")
     txt.append("")
     data = "\n".join(txt)
     if "--check" in sys.argv:

@@ -28,6 +28,7 @@ struct X2IOptions {
   int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
   int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
   int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
+  int gemm_persist;       // 1 = batch-1 launches with whole-line epilogues take the persistent form (gemm256p.hip, default)   X2I_GEMM_PERSIST
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
   int conv5_variant;      // matrix-core projector conv: 0 = automatic form choice; 1 = plain stages, 2 = pipelined, 3 = two row blocks   X2I_CONV5_VARIANT
@@ -42,6 +43,7 @@ struct X2IOptions {
 X2IOptions& x2i_options();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch
 int x2i_ensure_dynamic_smem(const void* kernel, int bytes);
+int x2i_num_cus();  // compute units of the current device (cached)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // float -> bf16, round-to-nearest-even (== torch .to(bfloat16)); hipcc lowers these casts to v_cvt_pk_bf16_f32 on gfx950
