@@ -161,15 +161,18 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     // persistent form: plain batch-1 GEMMs whose epilogue leaves as whole lines (the fused QKV epilogue and f32 outputs stay on the
     // one-tile-per-workgroup kernel); needs >= 3 K-tiles (the first one starts the accumulators, the last two prefetch the next tile)
     kern_t kernp = nullptr;
-    if (threads2 == 256 && opt.gemm_persist && !qd && a->batch == 1 && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 &&
-        (a->ldc & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 &&
-        (!res || ((a->ldr & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))
+    if (threads2 == 256 && opt.gemm_persist && !qd && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
+        (a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 &&
+        ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
+        (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))
       kernp = pick_gemm256p(p.act, res, f32, c2);
     if (kernp) {
       rc = x2i_ensure_dynamic_smem((const void*)kernp, SMEM2P_BYTES);
       if (rc) return rc;
-      const int tiles = pm.tilesM * pm.tilesN, cus = x2i_num_cus();
-      hipLaunchKernelGGL(kernp, dim3(tiles < cus ? tiles : cus), dim3(256), SMEM2P_BYTES, stream, pm);
+      pm.q_rpb = a->batch;  // batch count (field otherwise unused without the QKV epilogue): one tile list over all items
+      const long long tiles = (long long)pm.tilesM * pm.tilesN * a->batch;
+      const int cus = x2i_num_cus();
+      hipLaunchKernelGGL(kernp, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pm);
     } else {
       hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(threads2), SMEM2_BYTES, stream, pm);
     }

@@ -3,7 +3,7 @@
 // tile (gen_gemm256w.py, X2I_GEMM256P_MAIN), so the epilogue of tile n (accumulators -> LDS staging -> whole-line stores) runs with
 // the operands of tile n+1 already landing, and tile n+1 starts multiplying straight out of registers.  LDS: 128 KiB operand ring +
 // 4 x 8 KiB per-wave staging = all 160 KiB; epilogues leave in 32-row chunks.  Same image / MFMA / k order as every other bf16
-// GEMM kernel here: bit-identical results (tested).  Launcher: gemm.hip (plain batch-1 launches with whole-line epilogues).
+// GEMM kernel here: bit-identical results (tested).  Launcher: gemm.hip (plain and batched launches with whole-line bf16 epilogues; the batch items' tiles form one list).
 #include "gemm_device.h"
 #include "gemm256w_loop.inc"
 
@@ -22,10 +22,14 @@ constexpr int P_STAGE_WAVE = 8192;
 // loaded once, up front, for the same reason (a load behind a store is waited for with the store).  Same arithmetic (explicit fmaf,
 // same rounding points) as epilogue_store_lds: bit-identical results.
 template <int ACT, bool RES, bool HASC2>
-__device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int m_wave, int n_wave, int lane, char* stage) {
+__device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
+                                                 char* stage) {
   const int mlane = lane & 15, ng = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
-  bf16_t* Cz = (bf16_t*)p.C;
+  bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
+  bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
   float bv[8][4], gv[8][4];
   static_for<8>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -38,19 +42,19 @@ __device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[
         bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
         bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
       }
-      if (RES && p.gate) {
-        const f32x4_t g4 = *(const f32x4_t*)(p.gate + n);
+      if (gz) {
+        const f32x4_t g4 = *(const f32x4_t*)(gz + n);
         gv[j][0] = g4[0]; gv[j][1] = g4[1]; gv[j][2] = g4[2]; gv[j][3] = g4[3];
       }
-      if (p.bias2) {
-        const f32x4_t t4 = *(const f32x4_t*)(p.bias2 + n);
+      if (b2) {
+        const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
         bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
       }
     }
   });
   __amdgpu_buffer_rsrc_t r_rsrc;
   if constexpr (RES)
-    r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
+    r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)z * p.r_bs), 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
   auto issue = [&](int q) {  // chunk q = h*4 + c  ->  rows m_wave + 32c .., columns n_wave + 64h ..
     if constexpr (RES) {
       const int h = q >> 2, c = q & 3;
@@ -121,7 +125,7 @@ __device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[
         });
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bf16_t* dst = (pass == 0) ? Cz : p.C2;
+      bf16_t* dst = (pass == 0) ? Cz : C2z;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + srow;
@@ -142,10 +146,13 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int T = p.tilesM * p.tilesN;
+  const int T = p.tilesM * p.tilesN;  // tiles per batch item; virtual block vb -> item z = vb / T, tile vb % T of that item
+  const int TT = T * p.q_rpb;         // (q_rpb carries the batch count for this kernel: the fused QKV epilogue never runs here)
   const int G = gridDim.x;
 
-  auto tile_of = [&](int bid, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
+  auto tile_of = [&](int vb, int& z, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
+    z = vb / T;
+    int bid = vb - z * T;
     const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int GM = p.gm;
@@ -158,16 +165,17 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   };
   const int khl = lane >> 5, r8 = (lane >> 2) & 7, cphys = lane & 3;
   const int kel = khl * 32 + ((cphys ^ (3 * (wave & 1))) << 3);  // group parity = wave parity (4 pieces per row-group step)
-  auto offsets = [&](int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {
+  auto offsets = [&](int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {  // (W is shared by the batch items: w_bs == 0)
+    const long long zoff = (long long)z * p.a_bs;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int row = (jj * 4 + wave) * 8 + r8;
-      va[jj] = (m0 + row < p.M) ? (uint32_t)(((long long)(m0 + row) * p.lda + kel) * 2) : 0x80000000u;
+      va[jj] = (m0 + row < p.M) ? (uint32_t)((zoff + (long long)(m0 + row) * p.lda + kel) * 2) : 0x80000000u;
       vw[jj] = (n0 + row < p.N) ? (uint32_t)(((long long)(n0 + row) * p.ldw + kel) * 2) : 0x80000000u;
     }
   };
 
-  const uint32_t a_bytes = (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
+  const uint32_t a_bytes = (uint32_t)(((long long)(p.q_rpb - 1) * p.a_bs + (long long)(p.M - 1) * p.lda + p.K) * 2);  // < 2 GB (launcher)
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
@@ -181,10 +189,10 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   char* stage = smem + P_STAGE_OFF + wave * P_STAGE_WAVE;
 
   int bid = blockIdx.x;
-  int m0, n0;
-  tile_of(bid, m0, n0);
+  int z, m0, n0;
+  tile_of(bid, z, m0, n0);
   uint32_t va[8], vw[8], na[8], nw[8];
-  offsets(m0, n0, va, vw);
+  offsets(z, m0, n0, va, vw);
   bf16x8_t fr[32];  // wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31
   uint32_t s_koff, s_it;
   asm volatile(X2I_GEMM256P_PRO
@@ -193,11 +201,11 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
                : "memory", "scc");
   for (;;) {
     const int nbid = bid + G;
-    const bool has_next = nbid < T;
-    int nm0 = 0, nn0 = 0;
+    const bool has_next = nbid < TT;
+    int nz = 0, nm0 = 0, nn0 = 0;
     if (has_next) {
-      tile_of(nbid, nm0, nn0);
-      offsets(nm0, nn0, na, nw);
+      tile_of(nbid, nz, nm0, nn0);
+      offsets(nz, nm0, nn0, na, nw);
     } else {
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) na[jj] = nw[jj] = 0x80000000u;  // behind the last tile: every piece out of range (zero fill, no fetch)
@@ -210,9 +218,9 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
                  : "memory", "scc");
     // ---- epilogue of (m0, n0): per-wave private staging, no workgroup barrier; the next tile's first two K-tiles are in flight
     const int m_wave = m0 + wm * 128, n_wave = n0 + wn * 128;
-    epilogue_chunked<ACT, RES, HASC2>(p, acc, m_wave, n_wave, lane, stage);
+    epilogue_chunked<ACT, RES, HASC2>(p, acc, z, m_wave, n_wave, lane, stage);
     if (!has_next) break;
-    bid = nbid; m0 = nm0; n0 = nn0;
+    bid = nbid; z = nz; m0 = nm0; n0 = nn0;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) va[jj] = na[jj], vw[jj] = nw[jj];
   }
