@@ -63,25 +63,23 @@ def gemm_roofline(B, iters=10):
         del A, W, out
     fl = sum(r[0] for r in res)
     tt = sum(r[1] for r in res)
-    # HBM-side traffic of the same two launches from the committed rocprofv3 PMC pass (tools/pmc_collect.sh; FETCH_SIZE
-    # doubled per the gfx950 correction, + WRITE_SIZE).  Only valid for the profiled batch (B=4 -> M=18432).
+    # HBM-side traffic of the same two launches from the committed rocprofv3 PMC passes over tools/roofline_probe.py (tools/pmc_roofline.sh:
+    # FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE, separate passes; per-launch means summed over every GEMM kernel the
+    # pair launches, i.e. the persistent 256^2 kernel and the peeled 128^2 tail).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r02d_pmc_gemm_attn.json")
+    pj = os.path.join(ROOT, "profiles", "r03_pmc_roofline.json")
     if B == 4 and os.path.exists(pj):
-        d = json.load(open(pj))
-        # the launcher peels the last partly filled round of 256^2 tiles into a 128^2 launch: four kernels for the two GEMMs
-        grids = ("gemm256l_bf16_kernel<1, false, false, false, false> grid=1695744", "gemm_bf16_kernel<1, false, false, false, false> grid=147456",
-                 "gemm256l_bf16_kernel<0, false, false, false, false> grid=393216", "gemm_bf16_kernel<0, false, false, false, false> grid=98304")
         try:
-            traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"] for k in grids)
-            src = ("profiles/r02d_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes at the L2<->fabric "
-                   "boundary for both GEMMs incl. their peeled 128x128 tail launches)")
-        except KeyError:
+            d = json.load(open(pj))
+            traffic = float(d["traffic_bytes_per_pair"])
+            src = "profiles/r03_pmc_roofline.json (%s)" % d.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
+        except (KeyError, ValueError):
             traffic = None
     alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K) in ((B * S, 4 * D, D), (B * S, D, 5 * D)))
     return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_BF16,
-                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256l_bf16_kernel",
-                shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out as launched, 1.39 + 1.74 TFLOP)" % (B * S))
+                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_bf16_kernel",
+                shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out shapes, 1.39 + 1.74 TFLOP; persistent "
+                       "256^2 kernel + peeled 128^2 tail)" % (B * S))
 
 
 def gemm_roofline_fp8(B, iters=10):
@@ -149,35 +147,61 @@ def _pick_cpu_threads():
     return best, n_max
 
 
+def _physical_cores():
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":")[0].strip(): l.split(":", 1)[1].strip() for l in out.splitlines() if ":" in l}
+        return int(kv["Core(s) per socket"]) * int(kv["Socket(s)"]), kv.get("Model name", "?")
+    except Exception:  # noqa: BLE001
+        return None, "?"
+
+
 def cpu_baseline():
-    """The CPU oracle (restated reference path, fp32, torch eager) on the host cores: ONE double-stream and ONE
-    single-stream FLUX block at full width on the full 1024x1024 sequence (512 text + 4096 image tokens, batch 1), scaled
-    by the block counts (19 / 38) to one denoise step and by 4 steps to images/s."""
+    """The CPU oracle (restated reference path, fp32, torch eager) on the host cores.  MEASURED: one whole denoise step at 512 x 512,
+    batch 1 -- 19 double-stream + 38 single-stream FLUX blocks at full width on 512 text + 1024 image tokens (21.5 TFLOP; SURVEY.md
+    section 8(d)); the 57 blocks share one double-block and one single-block weight set (same arithmetic and bytes per block; generating
+    11.9 B random fp32 parameters on the host would take longer than the measurement).  EXTRAPOLATED and labelled so: the 1024 x 1024
+    step the GPU line is quoted on (74.4 TFLOP: 1 + 1 blocks timed on 512 + 4096 tokens, x19 / x38)."""
     from oracle import flux as OF
     from oracle import primitives as P
     from oracle import sampler as OS
     threads, logical = _pick_cpu_threads()
+    phys, cpu_name = _physical_cores()
     cfg = dict(OF.DEFAULT_CFG)
     cfg.update(num_layers=1, num_single_layers=1)
     sd = OF.random_flux_state_dict(cfg, seed=0)
-    St, h2 = 512, 64
-    ids = torch.cat([torch.zeros(St, 3), OS.prepare_latent_image_ids(h2, h2)], 0)
-    rot = P.flux_pos_embed(ids)
-    hid, enc, temb = torch.randn(1, h2 * h2, 3072), torch.randn(1, St, 3072), torch.randn(1, 3072)
-    with torch.no_grad():
-        t0 = time.time()
-        e, h = OF.double_block(sd, "transformer_blocks.0", hid, enc, temb, rot, 24)
-        t_d = time.time() - t0
-        j = torch.cat([e, h], 1)
-        t0 = time.time()
-        OF.single_block(sd, "single_transformer_blocks.0", j, temb, rot, 24)
-        t_s = time.time() - t0
-    step = 19 * t_d + 38 * t_s  # seconds per denoise step, 1024x1024, batch 1
-    return dict(value=1.0 / (4 * step), unit="images/s", cores=threads, kind="port",
-                sample="CPU oracle fp32 (torch eager, %d threads = fastest of a thread sweep; %d logical CPUs visible): 1 double + "
-                       "1 single FLUX block at D=3072 on 512 txt + 4096 img tokens, batch 1 (%.2fs + %.2fs); x19 / x38 blocks "
-                       "-> %.1f s per denoise step; 4 steps per image" % (threads, logical, t_d, t_s, step),
-                ms_per_denoise_step=step * 1e3)
+    St = 512
+
+    def blocks(h2, n_double, n_single):
+        ids = torch.cat([torch.zeros(St, 3), OS.prepare_latent_image_ids(h2, h2)], 0)
+        rot = P.flux_pos_embed(ids)
+        hid, enc, temb = torch.randn(1, h2 * h2, 3072), torch.randn(1, St, 3072), torch.randn(1, 3072)
+        with torch.no_grad():
+            t0 = time.time()
+            for _ in range(n_double):
+                enc, hid = OF.double_block(sd, "transformer_blocks.0", hid, enc, temb, rot, 24)
+            t_d = time.time() - t0
+            j = torch.cat([enc, hid], 1)
+            t0 = time.time()
+            for _ in range(n_single):
+                j = OF.single_block(sd, "single_transformer_blocks.0", j, temb, rot, 24)
+            t_s = time.time() - t0
+        return t_d, t_s
+
+    d512, s512 = blocks(32, 19, 38)          # measured: a whole 512^2 step
+    step512 = d512 + s512
+    d1k, s1k = blocks(64, 1, 1)              # 1 + 1 blocks at 1024^2, extrapolated below
+    step1k = 19 * d1k + 38 * s1k
+    return dict(value=1.0 / (4 * step512), unit="images/s (512x512, 4 steps, batch 1: MEASURED whole step)", cores=threads, kind="port",
+                physical_cores=phys, logical_cpus=logical, cpu=cpu_name,
+                sample="CPU oracle fp32 (torch eager, %d threads = fastest of a thread sweep; %s physical cores, %d logical CPUs visible): "
+                       "19 double + 38 single FLUX blocks at D=3072 on 512 txt + 1024 img tokens, batch 1, timed once = %.1f s per "
+                       "512x512 denoise step (21.5 TFLOP); 4 steps per image" % (threads, phys, logical, step512),
+                ms_per_denoise_step=step512 * 1e3,
+                extrapolated_1024=dict(value=1.0 / (4 * step1k), unit="images/s", ms_per_denoise_step=step1k * 1e3,
+                                       note="1 double + 1 single block timed on 512 txt + 4096 img tokens (%.2f s + %.2f s), x19 / x38: "
+                                            "the workload of the GPU line; an extrapolation, not a measurement" % (d1k, s1k)))
 
 
 def main():
@@ -199,6 +223,7 @@ def main():
                          "output projections (97 %% of the GEMM FLOPs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fp8-lines", action="store_true", help="skip the extra fp8_mlp / fp8_all measurements attached to the bf16 line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,7 +252,7 @@ def main():
         from x2i_amd.lightcontrol import ControlNeXtModel, FluxTransformer2DModel as LCFlux
         if N == 4:
             N = 20
-        model = LCFlux(guidance_embeds=True, device=dev).init_random_(seed=1234 + rank)
+        model = LCFlux(guidance_embeds=True, device=dev).init_random_(seed=1234)  # every rank holds the SAME weight replica
         nets = []
         for i in range(19):
             net = ControlNeXtModel(device=dev)
@@ -244,7 +269,7 @@ def main():
         pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True), control_nets=nets)
         hint = (torch.rand((B, 3, args.size, args.size), device=dev) * 2 - 1).bfloat16()
     else:
-        model = FluxTransformer2DModel(device=dev).init_random_(seed=1234 + rank)
+        model = FluxTransformer2DModel(device=dev).init_random_(seed=1234)  # every rank holds the SAME weight replica
         pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
     if args.dtype == "fp8":
         model.enable_fp8(args.fp8_mode)
@@ -316,6 +341,24 @@ def main():
             line["roofline"] = gemm_roofline_fp8(B)
         else:
             line["roofline"] = gemm_roofline(B)
+        if args.dtype == "bf16" and world == 1 and args.config == 2 and not args.no_fp8_lines:
+            # the opt-in e4m3 configurations in the same driver-timed record (the headline above stays bf16 = the reference's arithmetic):
+            # 1 warm-up + 3 timed passes each; stated tolerances in tests/test_fp8_gpu.py / test_fullscale_parity_gpu.py
+            for mode in ("mlp", "all"):
+                model.enable_fp8(mode)
+                one_pass()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    one_pass()
+                torch.cuda.synchronize()
+                ms8 = (time.perf_counter() - t1) / 3 * 1e3
+                line["fp8_" + mode] = {"images_s": B * 1e3 / ms8, "ms_per_denoise_step": ms8 / N, "passes": 3,
+                                       "model_tflops_per_gpu": fl * N / (ms8 * 1e-3) / 1e12,
+                                       "gemm_flops_on_e4m3": 0.72 if mode == "mlp" else 0.97}
+            r8 = gemm_roofline_fp8(B)
+            line["fp8_mlp"]["roofline"] = line["fp8_all"]["roofline"] = {k: r8[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "shapes")}
+            model.enable_fp8(None)
         if not args.no_cpu_baseline and world == 1 and args.config == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

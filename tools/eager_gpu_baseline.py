@@ -41,9 +41,15 @@ def main():
         return m(hidden_states=hidden, encoder_hidden_states=enc, pooled_projections=pooled, timestep=t, img_ids=img_ids,
                  txt_ids=txt_ids, guidance=None, return_dict=False)[0]
 
+    # torch 2.10.0+rocm7.0 on this image faults ("Write access to a read-only page") inside the eager double-stream block at B = 4
+    # (also with TORCH_BLAS_PREFER_HIPBLASLT=0; B <= 2 and the single-stream blocks are fine; profiles/r03g_*): the eager path is
+    # therefore run in chunks of at most 2 samples, back to back -- its per-sample cost does not depend on the chunking
+    chunk = 2 if B > 2 and "--eager-whole-batch" not in sys.argv else B
+
     def eager():
         with torch.no_grad():
-            return OF.flux_forward(sd, cfg, hidden, enc, pooled, t, img_ids, txt_ids)
+            return torch.cat([OF.flux_forward(sd, cfg, hidden[i:i + chunk], enc[i:i + chunk], pooled[i:i + chunk], t[i:i + chunk], img_ids, txt_ids)
+                              for i in range(0, B, chunk)], 0)
 
     def timed(f, iters):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,7 +60,15 @@ def main():
         torch.cuda.synchronize()
         return s.elapsed_time(e) / iters
 
-    o, r = ours(), eager()
+    def stage(msg):
+        torch.cuda.synchronize()
+        print("[eager_gpu_baseline] " + msg, file=sys.stderr, flush=True)
+
+    stage("model + inputs ready")
+    o = ours()
+    stage("x2i forward done")
+    r = eager()
+    stage("eager forward done")
     err = ((o.float() - r.float()).norm() / r.float().norm()).item()
     for f in (ours, eager):
         for _ in range(2):
@@ -69,7 +83,7 @@ def main():
     print(json.dumps({"workload": f"one denoise step, B={B}, 1024^2, {nl}+{ns} blocks, bf16, same weights/inputs",
                       "x2i_ms": round(med(to), 2), "eager_torch_rocm_ms": round(med(te), 2), "speedup": round(med(te) / med(to), 3),
                       "x2i_TFLOPs": round(flop / med(to) / 1e9, 1), "eager_TFLOPs": round(flop / med(te) / 1e9, 1),
-                      "rel_l2_x2i_vs_eager_bf16": err, "torch": torch.__version__, "device": torch.cuda.get_device_name(0)}))
+                      "rel_l2_x2i_vs_eager_bf16": err, "eager_chunk": chunk, "torch": torch.__version__, "device": torch.cuda.get_device_name(0)}))
 
 
 if __name__ == "__main__":

@@ -248,7 +248,8 @@ class FluxPipeline:
             body(prompt_embeds, pooled_prompt_embeds, latents, hint)
             return FluxPipelineOutput(latents) if return_dict else (latents,)
 
-        key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None)
+        key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None,
+               getattr(self.transformer, "_fp8_mode", None))  # a graph captured on the bf16 path must not serve the e4m3 path
         entry = self._graphs.get(key)
         if entry is None:
             static = dict(pe=prompt_embeds.clone(), pooled=pooled_prompt_embeds.clone(), lat=latents.clone(),
