@@ -43,6 +43,7 @@ X2IOptions make_options() {
   o.gemm_split_tail = env_int("X2I_GEMM_NOSPLIT", 0) ? 0 : 1;
   o.gemm_w4 = env_int("X2I_GEMM_W4", 1);
   o.gemm_persist = env_int("X2I_GEMM_PERSIST", 1);
+  o.gemm_streamk = env_int("X2I_GEMM_STREAMK", 1);
   o.conv256 = env_int("X2I_CONV256", 1);
   o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
   o.conv5_variant = env_int("X2I_CONV5_VARIANT", 0);
@@ -87,6 +88,68 @@ int x2i_num_cus() {
   return cus[dev];
 }
 
+namespace {
+struct SkWorkspace {
+  float* slabs = nullptr;
+  unsigned* flags = nullptr;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t last_done = nullptr;
+  bool failed = false;
+};
+std::mutex g_sk_mu;
+SkWorkspace g_sk[64];
+}  // namespace
+
+bool x2i_streamk_workspace(hipStream_t stream, float** slabs, unsigned** flags) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  SkWorkspace& w = g_sk[dev];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  if (!w.slabs) {
+    if (capturing || w.failed) return false;  // no allocation inside a capture: this launch keeps whole tiles (same results)
+    const size_t slab_bytes = (size_t)x2i_gemm_sk_max_tiles() * x2i_gemm_sk_slab_bytes();
+    if (hipMalloc((void**)&w.slabs, slab_bytes) != hipSuccess || hipMalloc((void**)&w.flags, 4096) != hipSuccess ||
+        hipMemset(w.flags, 0, 4096) != hipSuccess || hipEventCreateWithFlags(&w.last_done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      w.slabs = nullptr; w.failed = true;
+      return false;
+    }
+  }
+  // One workspace per device: a launch on another stream waits for the previous user (never needed by the single-stream product
+  // path; inside a capture no cross-stream wait can be recorded -- include/x2i.h states the rule for concurrent streams).
+  if (!capturing) {
+    if (w.last_stream != stream && w.last_stream != nullptr) (void)hipStreamWaitEvent(stream, w.last_done, 0);
+    w.last_stream = stream;
+  }
+  *slabs = w.slabs;
+  *flags = w.flags;
+  return true;
+}
+
+void x2i_streamk_mark_used(hipStream_t stream) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return;
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  SkWorkspace& w = g_sk[dev];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+  if (w.last_done) (void)hipEventRecord(w.last_done, stream);
+}
+
+int x2i_streamk_error_marker() {
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !g_sk[dev].flags) return 0;
+  unsigned v = 0;
+  if (hipMemcpy(&v, g_sk[dev].flags + x2i_gemm_sk_max_tiles(), 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)v;
+}
+
 extern "C" {
 
 int x2i_abi_version(void) { return X2I_ABI_VERSION; }
@@ -94,7 +157,7 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
   X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate)
 #endif
@@ -116,6 +179,10 @@ int x2i_set_option(const char* name, int64_t value) {
 int x2i_get_option(const char* name, int64_t* value) {
   if (!name || !value) return x2i_set_error(X2I_ERR_ARG, "get_option: null pointer");
   int* ip;
+  if (!strcmp(name, "gemm_sk_error")) {  // read-only: 1 = a stream-K segment gave up waiting for its predecessor (synchronising read)
+    *value = x2i_streamk_error_marker();
+    return X2I_OK;
+  }
   long long* lp = opt_slot(x2i_options(), name, &ip);
   if (ip) *value = *ip;
   else if (lp) *value = *lp;

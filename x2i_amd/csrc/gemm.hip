@@ -45,6 +45,9 @@ constexpr double NAIVE_MAX_FLOP = 5.0e10;
 
 }  // namespace
 
+int x2i_gemm_sk_max_tiles() { return SK_MAX_TILES; }
+long long x2i_gemm_sk_slab_bytes() { return SK_SLAB_BYTES; }
+
 static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream);
 static int check_qkv_desc(const x2i_gemm_args* a, const x2i_qkv_desc* qd, const char* who);
 
@@ -78,6 +81,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   p.f_sa = p.f_sw = nullptr; p.f_sa_bs = 0; p.f_alpha = p.f_oinv = 1.f; p.f_out8 = 0;
+  p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr;
   if (qd) {
     p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps;
     p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
@@ -139,10 +143,34 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     const int tm_all = (a->M + BM2 - 1) / BM2, tn = (a->N + BN2 - 1) / BN2;
     const long long per_row = (long long)tn * a->batch;
     const long long full_rounds = tiles256 / 256, rem = tiles256 % 256;
+    // persistent form: plain and batched GEMMs whose epilogue leaves as whole bf16 lines (the fused QKV epilogue and f32 outputs stay
+    // on the one-tile-per-workgroup kernel); needs >= 3 K-tiles (the first one starts the accumulators, the last two prefetch the
+    // next unit)
+    kern_t kernp = nullptr;
+    if (threads2 == 256 && opt.gemm_persist && !qd && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
+        (a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 &&
+        ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
+        (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))
+      kernp = pick_gemm256p(p.act, res, f32, c2);
+    // stream-K: with at least one full round in front, the tiles of a partly filled last round are cut along K and dealt out over all
+    // workgroups (chained partial accumulators: the same summation order, bit-identical results) instead of being peeled into a
+    // 128^2 launch.  Shares stay below one tile (share + 6 <= nk) and segments at or above 6 K-tiles.
+    const int cus = x2i_num_cus();
+    const int nkt = a->K / BK;
+    bool sk = false;
+    float* sk_slabs = nullptr;
+    unsigned* sk_flags = nullptr;
+    if (kernp && opt.gemm_streamk && force == 0 && tiles256 > cus && cus <= SK_MAX_TILES && nkt >= 16) {
+      // ... and only when the segments of a tile can run at different places of the workgroups' tile lists (segments per tile
+      // = cus / r <= whole tiles per workgroup + 1): with fewer whole tiles the chain of hand-offs serialises (measured: M = 2048,
+      // N = 9216, 288 tiles -> 8-segment chains behind ONE whole tile ran at half the speed of the peeled form)
+      const long long r = tiles256 % cus, S = tiles256 / cus;
+      if (r > 0 && r * nkt / cus + 6 <= nkt && r * nkt >= 6 && cus <= r * (S + 1)) sk = x2i_streamk_workspace(stream, &sk_slabs, &sk_flags);
+    }
     int tm_main = tm_all;
     // (re-measured in round 2, tools/tail_probe.py: peeling pays up to a 3/8-full last round at any depth, and for a half-full one
     // only behind >= 8 full rounds; a fuller last round is faster left in the one launch.  Either way the results are bit-identical.)
-    if (force == 0 && !conv && full_rounds >= 1 && rem > 0 && (rem <= 96 || (rem <= 128 && full_rounds >= 8)) && opt.gemm_split_tail) {
+    if (!sk && force == 0 && !conv && full_rounds >= 1 && rem > 0 && (rem <= 96 || (rem <= 128 && full_rounds >= 8)) && opt.gemm_split_tail) {
       const long long tm_fit = (full_rounds * 256) / per_row;
       if (tm_fit >= 1 && tm_fit < tm_all) tm_main = (int)tm_fit;
     }
@@ -158,21 +186,14 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     }
     pm.M = (tm_main < tm_all) ? tm_main * BM2 : a->M;
     pm.tilesM = tm_main; pm.tilesN = tn;
-    // persistent form: plain batch-1 GEMMs whose epilogue leaves as whole lines (the fused QKV epilogue and f32 outputs stay on the
-    // one-tile-per-workgroup kernel); needs >= 3 K-tiles (the first one starts the accumulators, the last two prefetch the next tile)
-    kern_t kernp = nullptr;
-    if (threads2 == 256 && opt.gemm_persist && !qd && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
-        (a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 &&
-        ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
-        (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))
-      kernp = pick_gemm256p(p.act, res, f32, c2);
     if (kernp) {
       rc = x2i_ensure_dynamic_smem((const void*)kernp, SMEM2P_BYTES);
       if (rc) return rc;
-      pm.q_rpb = a->batch;  // batch count (field otherwise unused without the QKV epilogue): one tile list over all items
+      pm.nbatch = a->batch;  // one tile list over all batch items
+      pm.sk_on = sk ? 1 : 0; pm.sk_slabs = sk_slabs; pm.sk_flags = sk_flags;
       const long long tiles = (long long)pm.tilesM * pm.tilesN * a->batch;
-      const int cus = x2i_num_cus();
       hipLaunchKernelGGL(kernp, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pm);
+      if (sk) x2i_streamk_mark_used(stream);
     } else {
       hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(threads2), SMEM2_BYTES, stream, pm);
     }
@@ -285,6 +306,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   }
   p.f_sa = f->a_scale; p.f_sa_bs = f->a_scale_batch_stride; p.f_sw = f->w_scale; p.f_alpha = f->alpha; p.f_oinv = f->out_inv_scale;
   p.f_out8 = out8 ? 1 : 0;
+  p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr;
   const int tm = (a->M + BM2 - 1) / BM2, tn = (a->N + BN2 - 1) / BN2;
   p.tilesM = tm; p.tilesN = tn;
   const X2IOptions& opt = x2i_options();

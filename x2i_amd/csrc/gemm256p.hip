@@ -139,6 +139,14 @@ __device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[
   });
 }
 
+// One unit of a workgroup's list: K-tiles [k0, k0 + len) of the output tile with virtual block id vb.  Whole tiles have k0 = 0,
+// len = nk; the tiles of the last, partly filled round are cut along K into segments handed from workgroup to workgroup ("stream-K",
+// chained: the next segment CONTINUES the accumulators of the previous one, so every output is summed in exactly the order of an
+// undivided tile -- bit-identical results, no reduction of partial sums).
+struct Unit {
+  int vb, k0, len, slab;  // slab = index of the split tile (partial-accumulator slab and progress flag); -1: whole tile
+};
+
 template <int ACT, bool RES, bool HASC2>
 __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A image 32 KiB | W image 32 KiB][4 waves x 8 KiB staging]
@@ -147,8 +155,9 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int T = p.tilesM * p.tilesN;  // tiles per batch item; virtual block vb -> item z = vb / T, tile vb % T of that item
-  const int TT = T * p.q_rpb;         // (q_rpb carries the batch count for this kernel: the fused QKV epilogue never runs here)
-  const int G = gridDim.x;
+  const int TT = T * p.nbatch;
+  const int G = gridDim.x, w = blockIdx.x;
+  const int nk = p.K / BK;
 
   auto tile_of = [&](int vb, int& z, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
     z = vb / T;
@@ -175,7 +184,52 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
     }
   };
 
-  const uint32_t a_bytes = (uint32_t)(((long long)(p.q_rpb - 1) * p.a_bs + (long long)(p.M - 1) * p.lda + p.K) * 2);  // < 2 GB (launcher)
+  // ---- this workgroup's unit list: S whole tiles (vb = w + s*G) and, with stream-K, up to two segments of the last round's tiles
+  int S = TT / G;
+  auto hasXlen = [](const Unit& u) { return u.len > 0; };
+  Unit segH = {0, 0, 0, -1}, segX = {0, 0, 0, -1};  // head segment (k0 = 0, runs first) / continuing segment (k0 > 0)
+  int posX = 0;                                     // whole tiles in front of segX
+  if (p.sk_on) {
+    const int r = TT - S * G;                       // tiles of the last round: K-tile range [0, r*nk) is dealt out over Gp workgroups
+    const long long R = (long long)r * nk;
+    const int Gp = (int)min((long long)G, R / 6);    // segments of at least 6 K-tiles
+    if (w < Gp) {
+      auto snap = [&](long long b) {                // no segment shorter than 3 K-tiles: move a cut that close to a tile edge onto it
+        const int m = (int)(b % nk);
+        return (m != 0 && m < 3) ? b - m : (m > nk - 3 ? b + (nk - m) : b);
+      };
+      const long long lo = snap(R * w / Gp), hi = snap(R * (w + 1) / Gp);
+      if (hi > lo) {
+        const int e0 = (int)(lo / nk), e1 = (int)((hi - 1) / nk);
+        const int k0 = (int)(lo - (long long)e0 * nk);
+        const Unit first = {S * G + e0, k0, (e1 > e0 ? nk : (int)(hi - (long long)e0 * nk)) - k0, e0};
+        if (k0 == 0) segH = first; else segX = first;
+        if (e1 > e0) segH = Unit{S * G + e1, 0, (int)(hi - (long long)e1 * nk), e1};  // (the launcher keeps shares below one tile)
+        if (segH.len == nk) segH.slab = -1;        // an undivided tile after all
+        // a continuing segment runs behind a share of the whole tiles that grows with its place in the tile's chain (the closing
+        // segment last), so that its predecessor has normally published before it is reached
+        posX = hasXlen(segX) ? min(S, (int)((long long)S * segX.k0 / max(1, nk - segX.len))) : 0;
+      }
+    }
+  } else if (w < TT - S * G) {
+    S += 1;  // no splitting: the last round's tiles are whole tiles of the first workgroups
+  }
+  const int hasH = segH.len > 0, hasX = segX.len > 0;
+  const int n_units = S + hasH + hasX;
+  auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };  // (workgroup-uniform by construction; makes it provable)
+  auto unit = [&](int i) -> Unit {
+    Unit u{w + (i - hasH) * G, 0, nk, -1};
+    if (i >= n_units) u = Unit{-1, 0, 0, -1};
+    else if (hasH && i == 0) u = segH;
+    else if (hasX) {
+      const int j = i - hasH;
+      if (j == posX) u = segX;
+      else if (j > posX) u.vb -= G;
+    }
+    return Unit{uni(u.vb), uni(u.k0), uni(u.len), uni(u.slab)};
+  };
+
+  const uint32_t a_bytes = (uint32_t)(((long long)(p.nbatch - 1) * p.a_bs + (long long)(p.M - 1) * p.lda + p.K) * 2);  // < 2 GB (launcher)
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
@@ -185,42 +239,89 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   uint32_t la = (uint32_t)(uintptr_t)smem + wm * 8 * 2048 + frag;
   uint32_t lw = (uint32_t)(uintptr_t)smem + 32768 + wn * 8 * 2048 + frag;
   uint32_t dma = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 1024);
-  const int nk = p.K / BK;
   char* stage = smem + P_STAGE_OFF + wave * P_STAGE_WAVE;
+  const uint32_t slab_vo = (uint32_t)tid * 16;  // slab layout [64 accumulator tiles][256 threads][16 B]
 
-  int bid = blockIdx.x;
+  auto slab_rsrc = [&](int slab) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)p.sk_slabs + (unsigned long long)slab * SK_SLAB_BYTES;
+    const unsigned long long au = ((unsigned long long)(unsigned)uni((int)(a >> 32)) << 32) | (unsigned)uni((int)(a & 0xffffffffu));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)au, 0, (uint32_t)SK_SLAB_BYTES, 0x00020000);
+  };
+  if (n_units == 0) return;  // (workgroup-uniform)
+  Unit cur = unit(0);
   int z, m0, n0;
-  tile_of(bid, z, m0, n0);
+  tile_of(cur.vb, z, m0, n0);
   uint32_t va[8], vw[8], na[8], nw[8];
   offsets(z, m0, n0, va, vw);
   bf16x8_t fr[32];  // wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31
-  uint32_t s_koff, s_it;
+  uint32_t s_koff, s_it, s_so;
+  int k0b = cur.k0 * (BK * 2);
   asm volatile(X2I_GEMM256P_PRO
                : X2I_GEMM256P_OPS_FRAG0_OUT(fr), [koff] "=&s"(s_koff)
-               : X2I_GEMM256W_OPS_VOFF(va, vw), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc)
+               : X2I_GEMM256W_OPS_VOFF(va, vw), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [k0b] "s"(k0b)
                : "memory", "scc");
-  for (;;) {
-    const int nbid = bid + G;
-    const bool has_next = nbid < TT;
+  for (int ui = 0;; ++ui) {
+    const Unit nxt = unit(ui + 1);
+    const bool has_next = nxt.vb >= 0;
     int nz = 0, nm0 = 0, nn0 = 0;
     if (has_next) {
-      tile_of(nbid, nz, nm0, nn0);
+      tile_of(nxt.vb, nz, nm0, nn0);
       offsets(nz, nm0, nn0, na, nw);
     } else {
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) na[jj] = nw[jj] = 0x80000000u;  // behind the last tile: every piece out of range (zero fill, no fetch)
+      for (int jj = 0; jj < 8; ++jj) na[jj] = nw[jj] = 0x80000000u;  // behind the last unit: every piece out of range (zero fill, no fetch)
     }
-    f32x4_t acc[2][4][2][4];  // written from zero by the first K-tile (C = 0 operand): no clearing pass
-    asm volatile(X2I_GEMM256P_MAIN_Z
-                 : X2I_GEMM256P_OPS_ACC_OUT(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
-                   [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
-                 : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nk] "s"(nk)
+    const int nk0b = nxt.k0 * (BK * 2), len = cur.len;
+    f32x4_t acc[2][4][2][4];
+    const int fromp = min(cur.k0, 1);  // (integer arithmetic, not a comparison: hipcc materialises an i1 in a VGPR, which cannot feed "s")
+    if (fromp) {
+      // continue a tile: wait until the predecessor has published K-tiles [0, k0) (flag == k0) -- bounded, so that a lost
+      // predecessor leaves a marker instead of a hung GPU
+      unsigned* flag = p.sk_flags + cur.slab;
+      if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)cur.k0) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > (1 << 22)) {
+            __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+    // ONE statement pair for both kinds of unit (see gen_gemm256w.py): LOAD_PARTIAL fetches the predecessor's accumulators or does
+    // nothing; MAIN continues from them or starts from zero (first K-tile with C = 0, no clearing pass)
+    __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(cur.slab < 0 ? 0 : cur.slab);
+    asm volatile(X2I_GEMM256P_LOAD_PARTIAL
+                 : X2I_GEMM256P_OPS_ACC_OUT(acc), [so] "=&s"(s_so)
+                 : [vo] "v"(slab_vo), [rs] "s"(s_rsrc), [fromp] "s"(fromp)
                  : "memory", "scc");
-    // ---- epilogue of (m0, n0): per-wave private staging, no workgroup barrier; the next tile's first two K-tiles are in flight
-    const int m_wave = m0 + wm * 128, n_wave = n0 + wn * 128;
-    epilogue_chunked<ACT, RES, HASC2>(p, acc, z, m_wave, n_wave, lane, stage);
+    const int zs = 1 - fromp;
+    asm volatile(X2I_GEMM256P_MAIN
+                 : X2I_GEMM256P_OPS_ACC_IO(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
+                   [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
+                 : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nk] "s"(len),
+                   [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
+                 : "memory", "scc");
+    if (cur.k0 + cur.len < nk) {
+      // hand the accumulators to the next segment of this tile: write-through stores, drained inside the statement; the flag
+      // (K-tiles accumulated so far) goes out behind a workgroup barrier
+      __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(cur.slab);
+      asm volatile(X2I_GEMM256P_STORE_PARTIAL
+                   : [so] "=&s"(s_so)
+                   : X2I_GEMM256P_OPS_ACC_IN(acc), [vo] "v"(slab_vo), [rs] "s"(s_rsrc)
+                   : "memory", "scc");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + cur.slab, (unsigned)(cur.k0 + cur.len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // ---- epilogue of (z, m0, n0): per-wave private staging, no workgroup barrier; the next unit's first two K-tiles are in flight
+      if (cur.k0 > 0 && tid == 0) __hip_atomic_store(p.sk_flags + cur.slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tile closed: flag back to 0
+      epilogue_chunked<ACT, RES, HASC2>(p, acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+    }
     if (!has_next) break;
-    bid = nbid; z = nz; m0 = nm0; n0 = nn0;
+    cur = nxt; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) va[jj] = na[jj], vw[jj] = nw[jj];
   }

@@ -37,7 +37,16 @@ struct GemmP {
   const float* f_sw;
   float f_alpha, f_oinv;
   int f_out8;
+  // persistent kernel (gemm256p.hip): nbatch = batch items in the tile list; sk_on = 1: the tiles of the last, partly filled round
+  // are split along K over the workgroups (chained partial accumulators: sk_slabs = [tile][64][256][16 B] f32, sk_flags[tile] = K-tiles
+  // of that tile accumulated so far, sk_flags[SK_ERR_SLOT] = give-up marker)
+  int nbatch, sk_on;
+  float* sk_slabs;
+  unsigned* sk_flags;
 };
+constexpr int SK_MAX_TILES = 256;               // split tiles per launch (< number of CUs)
+constexpr int SK_ERR_SLOT = SK_MAX_TILES;       // sk_flags[SK_ERR_SLOT] != 0: a segment gave up waiting for its predecessor
+constexpr long long SK_SLAB_BYTES = 256LL * 256 * 4;
 
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
                                            uint32_t koff_bytes, int wave) {

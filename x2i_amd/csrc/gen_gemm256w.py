@@ -94,8 +94,8 @@ def emit_event(ev, st):
     if kind == "TL":
         if mode == "W":  # one-tile kernel: fetch tile min(t + 2, nk - 1)
             return [["s_add_u32 %[tl], %[tl], 1", "s_min_u32 %[tmp], %[tl], %[nkm1]", "s_lshl_b32 %[koff], %[tmp], 7"][ev[1]]]
-        if mode in ("B1", "B2"):  # last two K-tiles of an output tile: fetch K-tiles 0 / 1 of the NEXT output tile
-            return [f"s_mov_b32 %[koff], {0 if mode == 'B1' else 128}"] if ev[1] == 0 else []
+        if mode in ("B1", "B2"):  # last two K-tiles of a unit: fetch the first two K-tiles of the NEXT unit (byte offset nk0b of its row)
+            return (["s_mov_b32 %[koff], %[nk0b]"] if mode == "B1" else ["s_add_u32 %[koff], %[nk0b], 128"]) if ev[1] == 0 else []
         return []  # mode "A": koff advances behind the last piece (XD)
     if kind == "M0W":
         return [f"s_add_u32 m0, %[dma], {32768 + ev[1] * 4096}"]
@@ -238,12 +238,12 @@ def generate_persistent(aux_a="", aux_w=""):
     slots = default_slots()
     check(slots)
     st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A")
-    P = ["s_nop 4", "s_mov_b32 %[koff], 0"]
+    P = ["s_nop 4", "s_mov_b32 %[koff], %[k0b]"]
     for jj in range(8):
         P += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
     for jj in range(8):
         P += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
-    P += ["s_mov_b32 %[koff], 128"]
+    P += ["s_add_u32 %[koff], %[k0b], 128"]
     for jj in range(8):
         P += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
         st["vm"].append(("W", -1, jj))
@@ -266,17 +266,32 @@ def generate_persistent(aux_a="", aux_w=""):
             assert bodies[mode] == b
         bodies[mode] = b
     assert all(c == counts[0] for c in counts), counts
-    # MAIN_C: continue from the accumulators handed in ("+a"; nk >= 2)
-    MC = ["s_nop 4", "s_mov_b32 %[koff], 256", "s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[it], 0", "s_cbranch_scc0 2f", "1:"]
-    MC += bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
-    # MAIN_Z: start from zero ("=&a"; nk >= 3): the first iteration is a copy of body A whose k-half 0 has C = 0; its loop test falls
-    # through to the last two iterations when nk == 3
+    # MAIN: one statement for both starts ("+a" accumulators).  zs != 0: start from zero -- the first iteration is a copy of body A
+    # whose k-half 0 takes C = 0, so the incoming accumulator values are never read (len >= 3); zs == 0: continue from the
+    # accumulators handed in (len >= 2).  One statement, so that the accumulators keep ONE register assignment around it (two
+    # statements on the two sides of a C++ branch made hipcc spill the whole accumulator file at the join).
     st["iter"], st["ds"], st["mode"] = 5, [], "A"
     a0 = body(slots, st, zero=True)
-    MZ = ["s_nop 4", "s_mov_b32 %[koff], 256", "s_sub_u32 %[it], %[nk], 2"] + a0 + ["s_cbranch_scc0 2f", "1:"]
-    MZ += bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
+    MC = ["s_nop 4", "s_add_u32 %[koff], %[k0b], 256", "s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[zs], 0", "s_cbranch_scc1 5f",
+          "s_cmp_lg_u32 %[it], 0", "s_cbranch_scc0 2f", "s_branch 1f", "5:"]
+    MC += a0 + ["s_cbranch_scc0 2f", "1:"] + bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
+    MZ = None
     D = ["s_waitcnt vmcnt(0)", "s_barrier"]
     return P, MC, MZ, D, counts[0]
+
+
+def generate_partial_io():
+    """Stream-K segment hand-off: the 64 accumulator tiles of a wave go to / come from a 256 KiB slab [64 tiles][256 threads][16 B]
+    straight from the accumulator file (no VGPR round trip).  Stores are write-through (sc1) and drained before the statement ends
+    (the flag that publishes them is stored behind a workgroup barrier); loads are sc1 (served past the CU's L1)."""
+    ST = ["s_nop 4", "s_mov_b32 %[so], 0"]
+    LD = ["s_nop 4", "s_mov_b32 %[so], 0", "s_cmp_lg_u32 %[fromp], 0", "s_cbranch_scc0 3f"]  # fromp == 0: nothing to load (accumulators undefined)
+    for n in range(64):
+        ST += [f"buffer_store_dwordx4 %[c{n}], %[vo], %[rs], %[so] offen sc1", "s_add_u32 %[so], %[so], 4096"]
+        LD += [f"buffer_load_dwordx4 %[c{n}], %[vo], %[rs], %[so] offen sc1", "s_add_u32 %[so], %[so], 4096"]
+    ST += ["s_waitcnt vmcnt(0)"]
+    LD += ["s_waitcnt vmcnt(0)", "3:"]
+    return ST, LD
 
 
 OPERANDS_DOC = """// operands of X2I_GEMM256W_LOOP (all named):
@@ -304,8 +319,11 @@ def main():
         txt.append("")
     P, MC, MZ, D, vm = generate_persistent()
     txt.append("// persistent (seamless) form -- additional operands: wa0..7 / aa0..7 are \"+v\" (live between the statements), na0..7 / nw0..7 \"v\" = the NEXT")
-    txt.append("// output tile's piece offsets (0x80000000 everywhere behind the last tile); nk >= 2")
-    for name, L in (("X2I_GEMM256P_PRO", P), ("X2I_GEMM256P_MAIN_C", MC), ("X2I_GEMM256P_MAIN_Z", MZ), ("X2I_GEMM256P_DRAIN", D)):
+    txt.append("// output tile's piece offsets (0x80000000 everywhere behind the last tile); nk >= 2;")
+    txt.append("// k0b / nk0b \"s\" = byte offset (128 per K-tile) of this / the next unit's first K-tile within a row (stream-K segments start at K-tile k0)")
+    ST, LD = generate_partial_io()
+    for name, L in (("X2I_GEMM256P_PRO", P), ("X2I_GEMM256P_MAIN", MC), ("X2I_GEMM256P_DRAIN", D),
+                    ("X2I_GEMM256P_STORE_PARTIAL", ST), ("X2I_GEMM256P_LOAD_PARTIAL", LD)):
         txt.append(f"// {name}: {len(L)} lines" + (f"; vmcnt W / A: {vm['W']} / {vm['A']}" if "MAIN" in name else ""))
         txt.append(f"#define {name} \\")
         txt += [f'  "{l}\\n" \\' for l in L[:-1]]
@@ -320,7 +338,7 @@ def main():
     vo = ", ".join(f'[va{n}] "v"(va[{n}])' for n in range(NF)) + ", " + ", ".join(f'[vw{n}] "v"(vw[{n}])' for n in range(NF))
     txt.append(f"#define X2I_GEMM256W_OPS_VOFF(va, vw) {vo}")
     txt.append("// persistent kernel: acc[h][c][r][jj] = rows 32c + 16r.., columns 64h + 16jj.. (the epilogue leaves in 32-row chunks)")
-    for con, tag in (("+a", "IO"), ("=&a", "OUT")):
+    for con, tag in (("+a", "IO"), ("=&a", "OUT"), ("a", "IN")):
         accp = ", ".join(f'[c{i * NF + j}] "{con}"(acc[{j >> 2}][{i >> 1}][{i & 1}][{j & 3}])' for i in range(NF) for j in range(NF))
         txt.append(f"#define X2I_GEMM256P_OPS_ACC_{tag}(acc) {accp}")
     for con, tag in (("+v", "IO"), ("=&v", "OUT")):

@@ -28,6 +28,8 @@ struct X2IOptions {
   int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
   int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
   int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
+  int gemm_streamk;       // 1 = the persistent kernel splits the tiles of a partly filled last round along K (chained partial accumulators,
+                          // bit-identical results; default); 0 = whole tiles only (+ the peeled 128^2 tail launch)          X2I_GEMM_STREAMK
   int gemm_persist;       // 1 = batch-1 launches with whole-line epilogues take the persistent form (gemm256p.hip, default)   X2I_GEMM_PERSIST
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
@@ -44,6 +46,13 @@ X2IOptions& x2i_options();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch
 int x2i_ensure_dynamic_smem(const void* kernel, int bytes);
 int x2i_num_cus();  // compute units of the current device (cached)
+// per-device workspace of the stream-K GEMM (partial-accumulator slabs + progress flags), allocated on first use outside stream
+// capture; returns false when it cannot be provided for this launch (first use inside a capture): the caller keeps whole tiles.
+bool x2i_streamk_workspace(hipStream_t stream, float** slabs, unsigned** flags);
+void x2i_streamk_mark_used(hipStream_t stream);  // call behind a launch that used the workspace
+int x2i_streamk_error_marker();
+int x2i_gemm_sk_max_tiles();                      // (gemm.hip: the constants of gemm_device.h)
+long long x2i_gemm_sk_slab_bytes();
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // float -> bf16, round-to-nearest-even (== torch .to(bfloat16)); hipcc lowers these casts to v_cvt_pk_bf16_f32 on gfx950
