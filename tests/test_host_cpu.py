@@ -223,6 +223,17 @@ def test_training_harness_arguments_and_schedules():
     assert abs(TD.lr_factor("cosine", 750, 500, 1000) - 0.5) < 1e-12 and abs(TD.lr_factor("cosine", 500, 500, 1000) - 1.0) < 1e-12
 
 
+def test_training_harness_finds_the_newest_checkpoint(tmp_path):
+    from x2i_amd import train_distill as TD
+    assert TD.latest_checkpoint(str(tmp_path)) == (0, None)
+    for d in ("500", "1500", "1000", "notes"):
+        (tmp_path / d).mkdir()
+    (tmp_path / "500" / "diffusion_pytorch_model.bin").write_bytes(b"x")
+    (tmp_path / "1000" / "diffusion_pytorch_model.bin").write_bytes(b"x")
+    step, path = TD.latest_checkpoint(str(tmp_path))      # 1500 has no model file: not a checkpoint
+    assert step == 1000 and path.endswith("1000/diffusion_pytorch_model.bin")
+
+
 def test_generated_gemm_loop_is_current():
     """csrc/gemm256w_loop.inc (the hand-scheduled K-loop of the 4-wave GEMM) is what csrc/gen_gemm256w.py emits: the generator asserts
     the register / buffer hazards of its schedule table and derives the wait counts, so a stale or hand-edited .inc fails here."""

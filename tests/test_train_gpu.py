@@ -484,6 +484,23 @@ def test_training_harness_synthetic_tiny_writes_loadable_checkpoints(tmp_path):
     assert pr.use_cnn and pr.conv.weight.shape == (1, 5, 5, 5)
 
 
+def test_training_harness_resumes_from_the_newest_checkpoint(tmp_path, capsys):
+    """re-launching into the same output_dir continues from the highest-numbered checkpoint (train/train_qwenvl.py:404-409,
+    :535) instead of restarting at step 0 and overwriting <output_dir>/2, /4 ... with a fresh run."""
+    from x2i_amd import train_distill as TD
+    common = ["--synthetic", "--tiny", "--batch_size", "2", "--checkpointing_steps", "2", "--learning_rate", "1e-3", "--output_dir", str(tmp_path),
+              "--seed", "1"]
+    first = TD.main(common + ["--max_train_steps", "4"])
+    assert len(first) == 4
+    w4 = torch.load(tmp_path / "4" / "diffusion_pytorch_model.bin")
+    again = TD.main(common + ["--max_train_steps", "6"])
+    assert len(again) == 2                                  # steps 5 and 6 only
+    assert "resuming from" in capsys.readouterr().out
+    assert (tmp_path / "6" / "diffusion_pytorch_model.bin").exists()
+    w4b = torch.load(tmp_path / "4" / "diffusion_pytorch_model.bin")
+    assert all(torch.equal(w4[k], w4b[k]) for k in w4)     # the earlier checkpoint was not rewritten
+
+
 def test_distillation_loss_kernel_vs_reference_golden(ops):
     """x2i_kd_loss_bf16 against the golden produced by EXECUTING the reference's statements (train/train_qwenvl.py normalize and the
     kl_div loops, tests/golden/make_golden.py gen_distill): the summed loss and the gradient with respect to every student tensor."""
@@ -538,3 +555,77 @@ def test_graphed_step_equals_eager_step():
         for pe, pg in zip(tr_e.params, tr_g.params):
             assert torch.equal(pe, pg), i
     assert gs.graph is not None
+
+
+def test_graphed_step_gradient_accumulation_and_shape_change():
+    """(1) the first calls run with optimizer_step=False and NO trainer.step() in between (gradient accumulation 2), so the
+    conv-table cache filled by the eager warm-up is still there when the graph is captured -- the capture must record the pack
+    anyway, or replays after the first optimizer step read a table packed from the old conv weights; (2) a batch-shape change re-warms
+    eagerly before the next capture.  Losses and parameters must follow the eager step bit for bit throughout."""
+    from oracle import sampler as OS
+    from x2i_amd.proj import Proj7Exp
+    from x2i_amd.train import DistillBackward, GraphedDistillStep, ProjectorTrainer, distill_step
+
+    def setup():
+        m, _, _ = _tiny()
+        pr = Proj7Exp(in_channels=5, input_dim=128, output_dim0=32, output_dim1=64, use_t5=False, use_scale=False, use_cnn=True, device=DEV).init_random_(7)
+        return ProjectorTrainer(pr, lr=5e-3), DistillBackward(m)
+    St, h2, w2 = 24, 6, 8
+    ids, tids = OS.prepare_latent_image_ids(h2, w2).to(DEV), torch.zeros(St, 3, device=DEV)
+
+    def batch(i, B):
+        gen = torch.Generator().manual_seed(300 + i)
+        rn = lambda *s: torch.randn(s, generator=gen)  # noqa: E731
+        return (bf(rn(B, 5, St, 128) * 2).to(DEV), bf(rn(B, h2 * w2, 64)).to(DEV), torch.linspace(0.2, 0.8, B).to(DEV),
+                [bf(rn(B, 2, h2 * w2, 256)).to(DEV), bf(rn(B, 2, St, 256)).to(DEV), bf(rn(B, 2, St + h2 * w2, 256)).to(DEV)])
+    tr_e, ch_e = setup()
+    tr_g, ch_g = setup()
+    gs = GraphedDistillStep(tr_g, ch_g, tids, ids)
+    for i, B in enumerate([2, 2, 2, 2, 2, 2, 3, 3, 3, 3]):
+        x, lat, ts, teacher = batch(i, B)
+        le = distill_step(tr_e, ch_e, x, lat, ts, teacher, tids, ids, optimizer_step=False)
+        lg = gs(x, lat, ts, teacher, optimizer_step=False)
+        assert torch.equal(le, lg), i
+        if i % 2 == 1:  # an optimizer step every second micro-step
+            tr_e.step()
+            tr_g.step()
+            for pe, pg in zip(tr_e.params, tr_g.params):
+                assert torch.equal(pe, pg), i
+    assert gs.graph is not None and gs.static["shapes"][0][0] == 3
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 24, 1536), (1, 24, 2800)])
+def test_ping_pong_attention_kernel_lse_output_vs_logsumexp(B, H, S):
+    """x2i_attention_lse_bf16 at a size that takes the 8-wave ping-pong kernel (B * H * ceil(S / 256) >= 256 workgroups):
+    its log2-sum-exp output against torch.logsumexp directly (S = 2800: a ragged last key tile, padded query rows get the +inf marker),
+    and its attention output bit for bit against x2i_attention_bf16 and against the 4-wave kernel's statistics."""
+    from x2i_amd import _lib, ops
+    assert B * H * ((S + 255) // 256) >= 256
+    Spad = ops.pad128(S)
+    scale = 1.0 / 128 ** 0.5
+    gq = torch.Generator(device=DEV).manual_seed(11)
+    Q = torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16)
+    K = torch.zeros_like(Q)
+    VT = torch.zeros((B, H, 128, Spad), device=DEV, dtype=torch.bfloat16)
+    Q[:, :, :S] = (torch.randn((B, H, S, 128), device=DEV, generator=gq) * 1.5).bfloat16()
+    K[:, :, :S] = (torch.randn((B, H, S, 128), device=DEV, generator=gq) * 1.5).bfloat16()
+    VT[:, :, :, :S] = torch.randn((B, H, 128, S), device=DEV, generator=gq).bfloat16()
+    o_plain = torch.empty((B, S, H * 128), device=DEV, dtype=torch.bfloat16)
+    o_lse = torch.empty_like(o_plain)
+    lse = torch.zeros((B, H, Spad), device=DEV)
+    old = _lib.set_option("attn_variant", 0)
+    try:
+        ops.attention(Q, K, VT, o_plain, B, H, S, Spad, H * 128, S * H * 128, scale)
+        ops.attention_lse(Q, K, VT, o_lse, lse, B, H, S, Spad, H * 128, S * H * 128, scale)
+        _lib.set_option("attn_variant", 4)  # the 4-wave kernel on the same problem
+        o4 = torch.empty_like(o_plain)
+        lse4 = torch.zeros_like(lse)
+        ops.attention_lse(Q, K, VT, o4, lse4, B, H, S, Spad, H * 128, S * H * 128, scale)
+    finally:
+        _lib.set_option("attn_variant", old)
+    assert torch.equal(o_plain, o_lse)
+    ref = torch.logsumexp(scale * Q[:, :, :S].float() @ K[:, :, :S].float().transpose(-1, -2), dim=-1) * 1.4426950408889634
+    assert rel_l2(lse[:, :, :S], ref) < 1e-4
+    assert float((lse[:, :, :S] - ref).abs().max()) < 2e-2
+    assert bool((lse[:, :, S:] > 1e29).all())
+    assert torch.equal(o4, o_lse) and float((lse4[:, :, :S] - lse[:, :, :S]).abs().max()) < 1e-4

@@ -60,6 +60,16 @@ def load_projector_checkpoint(path, device="cuda", in_channels=None):
     return proj.eval()
 
 
+def load_projector_state_dict(proj, path):
+    """Load a projector `.bin` (optionally `module.`-prefixed / ComfyUI-wrapped) into an existing module, strictly (resume path of the
+    distillation harness; train/train_qwenvl.py:404-409)."""
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd and "config" in sd:
+        sd = sd["state_dict"]
+    proj.load_state_dict(_strip(sd), strict=True)
+    return proj
+
+
 def save_projector_checkpoint(proj, path, comfyui=False, config=None):
     sd = {k: v.detach().cpu() for k, v in proj.state_dict().items()}
     torch.save({"config": config, "state_dict": sd} if comfyui else sd, path)

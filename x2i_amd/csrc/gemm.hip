@@ -111,6 +111,9 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     if (kern_t kw = pick_gemm256w(p.act, res, f32, c2)) kern2 = kw, threads2 = 256;
   }
 #ifdef X2I_ABLATION
+  if (!conv && opt.gemm_w4 > 1 && p.act == X2I_ACT_NONE && !res && !f32 && !c2) {  // A/B schedules of the 4-wave K-loop
+    if (kern_t kv = pick_gemm256w_var(opt.gemm_w4 - 1)) kern2 = kv, threads2 = 256;
+  }
   // measurement-only library: the k-half-unit form (gemm_lform = 0) and its ablation variants replace the product kernel
   if (!conv && (opt.gemm_ablate || !opt.gemm_lform)) kern2 = pick_gemm256u(p.act, res, f32, c2, opt.gemm_ablate), threads2 = 512;
 #endif
@@ -147,7 +150,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     // on the one-tile-per-workgroup kernel); needs >= 3 K-tiles (the first one starts the accumulators, the last two prefetch the
     // next unit)
     kern_t kernp = nullptr;
-    if (threads2 == 256 && opt.gemm_persist && !qd && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
+    if (threads2 == 256 && opt.gemm_persist && opt.gemm_w4 == 1 && !qd && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
         (a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 &&
         ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
         (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))

@@ -462,6 +462,7 @@ kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop,
 constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION
+kern_t pick_gemm256w_var(int var);  // A/B schedules of the 4-wave K-loop (option gemm_w4 = 1 + var), plain epilogue only
 kern_t pick_gemm256u(int act, bool res, bool f32, bool c2, int abl);  // k-half-unit form + measurement-only variants
 #endif
 

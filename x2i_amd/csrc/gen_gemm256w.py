@@ -38,7 +38,8 @@ def acc(i, j):
 #   ("VM", what):            s_waitcnt vmcnt(n) so that the NEXT tile's pieces of operand `what` ("W", "A") have landed
 #   ("BAR",):                s_barrier
 #   ("CNT", n):              loop counter (0: decrement, 1: compare)
-def default_slots():
+def default_slots(variant=0):
+    """variant 0 = the product schedule; 3 = one barrier for both operands of the next tile (measurement builds only)."""
     s = {}
 
     def put(k, *ev):
@@ -57,17 +58,29 @@ def default_slots():
     put(45, ("LGK", "A1")); put(46, ("BAR",))
     put(47, ("M0W", 5)); put(48, ("DW", 5)); put(50, ("M0W", 6)); put(51, ("DW", 6)); put(53, ("M0W", 7)); put(54, ("DW", 7))
     put(56, ("M0A", 0)); put(57, ("DA", 0)); put(59, ("M0A", 1)); put(60, ("DA", 1))
-    put(62, ("VM", "W")); put(63, ("BAR",))
-    for j in range(8):
-        put(64 + 2 * j, ("R0W", j))
-    k = 80
-    for jj in range(2, 7):
-        put(k, ("M0A", jj)); put(k + 1, ("DA", jj))
-        k += 3
-    put(96, ("VM", "A")); put(97, ("BAR",))
-    for i in range(8):
-        put(98 + 2 * i, ("R0A", i))
-    put(114, ("M0A", 7)); put(115, ("DA", 7)); put(116, ("XD",))
+    if variant == 3:
+        put(62, ("VM", "A")); put(63, ("BAR",))      # the next tile's A pieces are younger than its W pieces: one wait covers both
+        for j in range(8):
+            put(64 + 2 * j, ("R0W", j))
+        for i in range(8):
+            put(80 + 2 * i, ("R0A", i))
+        k = 96
+        for jj in range(2, 8):
+            put(k, ("M0A", jj)); put(k + 1, ("DA", jj))
+            k += 3
+        put(115, ("XD",))
+    else:
+        put(62, ("VM", "W")); put(63, ("BAR",))
+        for j in range(8):
+            put(64 + 2 * j, ("R0W", j))
+        k = 80
+        for jj in range(2, 7):
+            put(k, ("M0A", jj)); put(k + 1, ("DA", jj))
+            k += 3
+        put(96, ("VM", "A")); put(97, ("BAR",))
+        for i in range(8):
+            put(98 + 2 * i, ("R0A", i))
+        put(114, ("M0A", 7)); put(115, ("DA", 7)); put(116, ("XD",))
     put(121, ("CNT", 0)); put(122, ("CNT", 1))
     put(125, ("LGK", "all"))
     return s
@@ -104,11 +117,11 @@ def emit_event(ev, st):
     if kind == "DW":
         st["vm"].append(("W", st["iter"], ev[1]))
         v = "nw" if mode in ("B1", "B2") else "vw"
-        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[rw], %[koff] offen lds" + st["aux_w"]]
+        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[rw], %[koff] offen" + st["aux_w"] + " lds"]
     if kind == "DA":
         st["vm"].append(("A", st["iter"], ev[1]))
         v = "na" if mode in ("B1", "B2") else "va"
-        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[ra], %[koff] offen lds" + st["aux_a"]]
+        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[ra], %[koff] offen" + st["aux_a"] + " lds"]
     if kind == "XD":
         return ["s_xor_b32 %[dma], %[dma], 0x10000"] + (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" else [])
     if kind == "BAR":
@@ -171,11 +184,14 @@ def check(slots):
     barpos = sorted(p for e, p in pos.items() if e[0] == "BAR")
     # (BAR events are identical tuples: recover their positions from the slot table)
     barpos = sorted((k, n) for k in slots for n, ev in enumerate(slots[k]) if ev == ("BAR",))
-    assert len(barpos) == 4
+    assert len(barpos) in (3, 4)
     assert pos[("LGK", "W1")] < barpos[0] < min(pos[("DW", j)] for j in range(8))
     assert pos[("LGK", "A1")] < barpos[1] < min(pos[("DA", j)] for j in range(8))
-    assert pos[("VM", "W")] < barpos[2] < min(pos[("R0W", j)] for j in range(8))
-    assert pos[("VM", "A")] < barpos[3] < min(pos[("R0A", j)] for j in range(8))
+    if len(barpos) == 4:
+        assert pos[("VM", "W")] < barpos[2] < min(pos[("R0W", j)] for j in range(8))
+        assert pos[("VM", "A")] < barpos[3] < min(pos[("R0A", j)] for j in range(8))
+    else:  # one wait on the (younger) A pieces + one barrier in front of both fragment sets
+        assert ("VM", "W") not in pos and pos[("VM", "A")] < barpos[2] < min(min(pos[("R0W", j)], pos[("R0A", j)]) for j in range(8))
     # M0 must be written at least one instruction (here: an MFMA) before the piece that uses it, and not be overwritten in between
     m0w = sorted((pos[e], e) for e in pos if e[0] in ("M0W", "M0A", "DW", "DA"))
     for (p0, e0), (p1, e1) in zip(m0w[::2], m0w[1::2]):
@@ -187,8 +203,8 @@ def check(slots):
     del bars
 
 
-def generate(aux_a="", aux_w=""):
-    slots = default_slots()
+def generate(aux_a="", aux_w="", variant=0):
+    slots = default_slots(variant)
     check(slots)
     st = dict(ds=[], vm=[], iter=0, aux_a=aux_a, aux_w=aux_w, vm_n={})
     L = []
@@ -197,16 +213,16 @@ def generate(aux_a="", aux_w=""):
     L.append("s_mov_b32 %[koff], 0")
     # ---- prologue: tile 0 -> buffer 0 (any order), tile 1 (clamped to the last tile) -> buffer 1 in the loop's order (W, then A)
     for jj in range(8):
-        L += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+        L += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
     for jj in range(8):
-        L += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+        L += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
     L += ["s_min_u32 %[tl], %[nkm1], 1", "s_lshl_b32 %[koff], %[tl], 7"]
     st["iter"] = -1
     for jj in range(8):
-        L += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+        L += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
         st["vm"].append(("W", -1, jj))
     for jj in range(8):
-        L += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+        L += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
         st["vm"].append(("A", -1, jj))
     L += ["s_mov_b32 %[tl], 1", "s_mov_b32 %[it], %[nk]"]
     L += ["s_waitcnt vmcnt(16)", "s_barrier"]
@@ -224,6 +240,7 @@ def generate(aux_a="", aux_w=""):
     st["ds"] = []
     b1 = body(slots, st)
     assert b0 == b1 and n0 == st["vm_n"], "the wait counts of the first and of a steady-state iteration differ"
+    st["vm_n"].setdefault("W", st["vm_n"]["A"])
     L.append("1:")
     L += b0
     L.append("s_cbranch_scc1 1b")
@@ -240,15 +257,15 @@ def generate_persistent(aux_a="", aux_w=""):
     st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A")
     P = ["s_nop 4", "s_mov_b32 %[koff], %[k0b]"]
     for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+        P += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
     for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+        P += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
     P += ["s_add_u32 %[koff], %[k0b], 128"]
     for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen lds" + aux_w]
+        P += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
         st["vm"].append(("W", -1, jj))
     for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen lds" + aux_a]
+        P += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
         st["vm"].append(("A", -1, jj))
     P += ["s_waitcnt vmcnt(16)", "s_barrier"]
     for j in range(8):
@@ -308,10 +325,13 @@ OPERANDS_DOC = """// operands of X2I_GEMM256W_LOOP (all named):
 
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm256w_loop.inc")
-    variants = {"X2I_GEMM256W_LOOP": ("", "")}
+    # _V1.._V3 are A/B variants compiled only into the measurement library (-DX2I_ABLATION): non-temporal A / W pieces, one barrier
+    # for both operands of the next tile
+    variants = {"X2I_GEMM256W_LOOP": ("", "", 0), "X2I_GEMM256W_LOOP_V1": (" nt", "", 0), "X2I_GEMM256W_LOOP_V2": ("", " nt", 0),
+                "X2I_GEMM256W_LOOP_V3": ("", "", 3)}
     txt = ["// GENERATED by gen_gemm256w.py -- do not edit; the schedule table lives in the generator.", OPERANDS_DOC]
-    for name, (aa, aw) in variants.items():
-        L, vm = generate(aa, aw)
+    for name, (aa, aw, var) in variants.items():
+        L, vm = generate(aa, aw, var)
         txt.append(f"// {name}: {len(L)} lines; vmcnt before the next tile's W / A fragments are read: {vm['W']} / {vm['A']}")
         txt.append(f"#define {name} \\")
         txt += [f'  "{l}\\n" \\' for l in L[:-1]]

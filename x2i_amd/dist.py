@@ -25,6 +25,14 @@ def init_from_env(backend=None, device=None):
     return rank, world
 
 
+def barrier_and_destroy():
+    """Leave the job together: world barrier, then destroy_process_group on every rank (a rank that returns early -- e.g. a teacher rank
+    with nothing to do -- may host the rendezvous store the others still need for their first collective)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def shard_range(n, rank, world):
     """Contiguous split of n samples; the first n % world ranks get one extra."""
     base, rem = divmod(n, world)

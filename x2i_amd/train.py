@@ -600,14 +600,22 @@ class GraphedDistillStep:
         self.calls += 1
         shapes = (tuple(text_embeddings.shape), tuple(latents.shape)) + tuple(tuple(t.shape) for t in teacher)
         if self.static is not None and self.static["shapes"] != shapes:
+            # a new batch shape: drop the graph AND run this step eagerly, so that every pooled buffer of the new shape exists before
+            # the next capture (buffers first allocated inside a capture live in the old graph's private pool -- ADVICE r2)
             self.graph, self.static = None, None
-        if self.calls == 1:
+            self.warm_shapes = None
+        if self.calls == 1 or getattr(self, "warm_shapes", None) != shapes:
             loss = self._body(text_embeddings, latents, timestep, teacher)   # eager warm-up step (a real step)
+            self.warm_shapes = shapes
         else:
             if self.graph is None:
                 self.static = dict(shapes=shapes, x=text_embeddings.clone(), lat=latents.clone(), ts=timestep.clone(),
                                    teacher=[t.clone() for t in teacher])
                 torch.cuda.synchronize()
+                # host-side weight caches must not be satisfied from an eager call: the capture has to RECORD the conv-table pack, or a
+                # replay after the next optimizer step would read a table packed from the old conv weights (freed memory) --
+                # e.g. when the warm-up call ran with optimizer_step=False and nothing had popped the cache
+                self.trainer.proj.__dict__.pop("_conv5x5_cache", None)
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     self.loss = self._body(self.static["x"], self.static["lat"], self.static["ts"], self.static["teacher"])
@@ -620,6 +628,9 @@ class GraphedDistillStep:
                     d.copy_(t)
             self.graph.replay()
             loss = self.loss
+            # the table packed inside the graph belongs to the graph's pool and is rewritten by every replay; an eager forward must
+            # not pick it up from the cache
+            self.trainer.proj.__dict__.pop("_conv5x5_cache", None)
         if optimizer_step:
             self.trainer.step()
         return loss

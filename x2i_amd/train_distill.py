@@ -75,6 +75,18 @@ def save_checkpoint(proj, output_dir, global_step):
     return path
 
 
+def latest_checkpoint(output_dir):
+    """(step, path) of the highest-numbered <output_dir>/<step>/diffusion_pytorch_model.bin, or (0, None): the reference resumes from it
+    and continues at global_step = that step (train/train_qwenvl.py:404-409, :535)."""
+    best, path = 0, None
+    if output_dir and os.path.isdir(output_dir):
+        for d in os.listdir(output_dir):
+            f = os.path.join(output_dir, d, "diffusion_pytorch_model.bin")
+            if d.isdigit() and os.path.isfile(f) and int(d) > best:
+                best, path = int(d), f
+    return best, path
+
+
 def synthetic_batch(bsz, device, gen, cfg, D, St, lat_hw, mllm_shape):
     """One batch with the reference's keys and (at full size) shapes, train/train_qwenvl.py:324-333."""
     Si = lat_hw * lat_hw
@@ -127,19 +139,37 @@ def run(args):
     img_ids = FluxPipeline._prepare_latent_image_ids(1, lat_hw, lat_hw, device, torch.float32)   # :552
     guidance = torch.full((args.batch_size,), 3.5, device=device)                               # :553-554
     is_teacher = groups is not None and groups.is_infer_rank
+    if groups is not None and not args.synthetic:
+        # the teacher pipeline behind send_to_infer_device / receive_from_infer_device is not part of this program (teacher tensors come
+        # pre-computed in --batch_files): refuse the layout instead of leaving GPUs idle without saying so
+        raise SystemExit("--local_infer_world_size > 0 is only wired for --synthetic runs (no teacher pipeline in this program)")
     if is_teacher:
-        # teacher ranks of a synthetic run have nothing to compute: the real job runs the frozen teacher pipeline here and hands its
-        # tensors to the trainers with x2i_amd.dist.receive_from_infer_device (core/pipeline/train_and_infer.py:106-122)
+        # teacher ranks of a synthetic run have nothing to compute; they leave WITH the trainers (rank 0 is a teacher and, under a plain
+        # env:// launch, hosts the store the trainers' first collective still needs)
+        xdist.barrier_and_destroy()
         return []
+    # resume (train/train_qwenvl.py:404-409): the newest checkpoint under output_dir continues at its step; AdamW moments restart
+    # (the reference's checkpoint holds the projector weights only)
     global_step, losses, graphed = 0, [], None
-    step = 0
+    last_step, last_path = latest_checkpoint(args.output_dir)
+    if last_path is not None:
+        from .checkpoints import load_projector_state_dict
+        load_projector_state_dict(proj, last_path)
+        global_step = last_step
+        trainer.step_count = last_step
+        if rank == 0 or (groups is not None and rank == groups.train_ranks[0]):
+            print(f"resuming from {last_path} at global_step {global_step}", flush=True)
+    step = global_step * args.gradient_accumulation_steps
+    ga = args.gradient_accumulation_steps
     while global_step < args.max_train_steps:
         if args.synthetic:
             batch = synthetic_batch(args.batch_size, device, gen, model.config, D, St, lat_hw, mllm)
         else:
             batch = torch.load(args.batch_files[step % len(args.batch_files)], map_location=device)
         sync = step % args.gradient_accumulation_steps == 0                                      # :560
-        trainer.lr = args.learning_rate * lr_factor(args.lr_scheduler, global_step, args.lr_warmup_steps, args.max_train_steps)
+        # the reference builds its scheduler with warm-up and total steps multiplied by the accumulation count and steps it once per
+        # optimizer step (train/train_qwenvl.py:476-481, :631): same factor sequence here
+        trainer.lr = args.learning_rate * lr_factor(args.lr_scheduler, global_step, args.lr_warmup_steps * ga, args.max_train_steps * ga)
         teacher = [batch["KD_teacher_tensor0"], batch["KD_teacher_tensor1"], batch["KD_teacher_tensor2"]]
         if args.use_graph:
             if graphed is None:
@@ -156,6 +186,8 @@ def run(args):
                 print(f"step {global_step}: step_loss {losses[-1]:.4f} lr {trainer.lr:.3e} grad_norm {float(trainer.last_norm[1]):.4e}", flush=True)
                 if global_step % args.checkpointing_steps == 0:
                     print("saving model to", save_checkpoint(proj, args.output_dir, global_step), flush=True)
+    if groups is not None:
+        xdist.barrier_and_destroy()
     return losses
 
 
