@@ -150,11 +150,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     // on the one-tile-per-workgroup kernel); needs >= 3 K-tiles (the first one starts the accumulators, the last two prefetch the
     // next unit)
     kern_t kernp = nullptr;
-    if (threads2 == 256 && opt.gemm_persist && opt.gemm_w4 == 1 && !qd && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
-        (a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 &&
+    if (threads2 == 256 && opt.gemm_persist && opt.gemm_w4 == 1 && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
+        (qd || ((a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0)) &&
         ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
         (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))
-      kernp = pick_gemm256p(p.act, res, f32, c2);
+      kernp = qd ? pick_gemm256p_qkv() : pick_gemm256p(p.act, res, f32, c2);
     // stream-K: with at least one full round in front, the tiles of a partly filled last round are cut along K and dealt out over all
     // workgroups (chained partial accumulators: the same summation order, bit-identical results) instead of being peeled into a
     // 128^2 launch.  Shares stay below one tile (share + 6 <= nk) and segments at or above 6 K-tiles.

@@ -139,6 +139,201 @@ __device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[
   });
 }
 
+// Fused QKV epilogue of one wave (x2i_gemm_qkv_bf16: q / k RMSNorm + RoPE + head split, V transposed) on the persistent kernel's
+// 8 KiB of private staging.  A wave's 128 x 128 outputs are 128 tokens of exactly ONE head of the q, k or v section (tile columns
+// never straddle a section; checked by the launcher).  Same arithmetic and rounding points as qkv_park / qkv_finish (gemm_device.h):
+// the tile is parked as bf16(acc + bias) and read back, so the results equal the one-tile kernels' bit for bit.
+//   q / k: eight 16-token chunks ([16 rows][256 B], 16-byte chunk ch of row r at ch ^ r; double-buffered); a pass = 4 tokens x 16
+//          lanes x 8 dims.  The fp32 cos / sin rows of chunk n+1 are requested BEFORE chunk n's stores are issued, so the wait for
+//          them never includes a store (a load queued behind a store is only known to have returned once the store has).
+//   v:     four 64-token x 64-dim chunks ([64 rows][128 B], chunk ch of row r at ch ^ ((r >> 3) ^ (r >> 1)) & 7: conflict-free for the
+//          row-wise 8-byte parks AND the column-wise 4-byte gathers); a lane gathers two adjacent dims of 8 consecutive tokens and
+//          writes two 16-byte token runs of V^T, 8 lanes cover a 128-byte line.
+__device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
+                                                     char* stage) {
+  // every per-lane offset below is cheap to recompute; hidden from loop-invariant code motion, or hipcc computes the lot once in front
+  // of the persistent loop and then spills it (73 registers, reloaded from scratch between this epilogue's stores)
+  asm volatile("" : "+v"(lane));
+  const int mlane = lane & 15, ng = lane >> 4;
+  const int Dm = p.q_H * 128;
+  const int sec = n_wave / Dm;  // 0 = q, 1 = k, 2 = v
+  const int head = (n_wave - sec * Dm) >> 7;
+  uint2 bvp[8];  // bias of this lane's 4 columns per 16-column block, kept as packed bf16 pairs (registers are scarce here)
+  static_for<8>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n_wave + j * 16 + ng * 4;
+    bvp[j] = (p.bias && n + 3 < p.N) ? *(const uint2*)(p.bias + n) : make_uint2(0u, 0u);
+  });
+  auto bias_of = [&](int j, int r) {
+    const uint32_t u = (r & 2) ? bvp[j].y : bvp[j].x;
+    return __uint_as_float((r & 1) ? (u & 0xffff0000u) : (u << 16));
+  };
+  auto token = [&](int m, int& b, int& st) {  // row m of batch item z -> sample b, position st of the joint sequence
+    const int mg = p.q_row0 + m;
+    b = z + mg / p.q_rpb;
+    st = p.q_tok_off + mg % p.q_rpb;
+  };
+  if (sec < 2) {
+    const int c = lane & 15, rsub = lane >> 4;  // 8-dim chunk of the head; row of the pass
+    float w[8];
+    {
+      const bf16x8_t wv = *(const bf16x8_t*)((sec ? p.q_nk : p.q_nq) + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]);
+    }
+    bf16_t* dstbase = sec ? p.q_K : p.q_Q;
+    f32x4_t cs[2][4];  // per pass of a half chunk: cos[0..3], cos[4..7], sin[0..3], sin[4..7] of this lane's 8 dims
+    auto load_cs = [&](int half) {  // half = 2 passes (8 tokens) of the 16-token chunks
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int m = m_wave + half * 8 + ps * 4 + rsub;
+        int b, st;
+        token(m < p.M ? m : 0, b, st);
+        const float* cp = p.q_cos + (long long)st * 128 + c * 8;
+        const float* sp = p.q_sin + (long long)st * 128 + c * 8;
+        cs[ps][0] = *(const f32x4_t*)cp; cs[ps][1] = *(const f32x4_t*)(cp + 4);
+        cs[ps][2] = *(const f32x4_t*)sp; cs[ps][3] = *(const f32x4_t*)(sp + 4);
+      }
+    };
+    asm volatile("" ::: "memory");
+    load_cs(0);
+    static_for<8>([&](auto qc) {
+      constexpr int q16 = decltype(qc)::value;
+      constexpr int c2 = q16 >> 1, rr = q16 & 1;
+      char* buf = stage + (q16 & 1) * 4096;
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<2>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        static_for<4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          float a[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c2][rr][j][r]));
+            a[r] = t + bias_of(h * 4 + j, r);
+          }
+          *(uint2*)(buf + mlane * 256 + (((h * 8 + j * 2 + (ng >> 1)) ^ mlane) << 4) + ((ng & 1) << 3)) =
+              make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      static_for<2>([&](auto hfc) {
+        constexpr int hf = decltype(hfc)::value;  // passes 2hf, 2hf + 1 of this chunk = half-chunk index 2 q16 + hf
+        bf16x8_t outv[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int row = hf * 8 + ps * 4 + rsub;
+          const bf16x8_t xv = *(const bf16x8_t*)(buf + row * 256 + ((c ^ row) << 4));
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[j]);
+          float ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this token
+          const float r = rsqrtf(ss * (1.f / 128.f) + p.q_eps);
+          const float csv[8] = {cs[ps][0][0], cs[ps][0][1], cs[ps][0][2], cs[ps][0][3], cs[ps][1][0], cs[ps][1][1], cs[ps][1][2], cs[ps][1][3]};
+          const float snv[8] = {cs[ps][2][0], cs[ps][2][1], cs[ps][2][2], cs[ps][2][3], cs[ps][3][0], cs[ps][3][1], cs[ps][3][2], cs[ps][3][3]};
+          float o8[8];
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
+            o8[j] = a * csv[j] - bb * snv[j];
+            o8[j + 1] = bb * csv[j + 1] + a * snv[j + 1];
+          }
+          union { bf16x8_t v8; uint32_t uu[4]; } pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pk.uu[j] = pack_bf16x2(o8[2 * j], o8[2 * j + 1]);
+          outv[ps] = pk.v8;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (2 * q16 + hf + 1 < 16) load_cs(2 * q16 + hf + 1);  // in front of this half's stores (see the header comment)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int m = m_wave + q16 * 16 + hf * 8 + ps * 4 + rsub;
+          if (m < p.M) {
+            int b, st;
+            token(m, b, st);
+            *(bf16x8_t*)(dstbase + (((long long)b * p.q_H + head) * p.q_Spad + st) * 128 + c * 8) = outv[ps];
+          }
+        }
+      });
+    });
+  } else {
+    const int ch_lo = lane & 7, dp_lo = lane >> 3;
+    const bool aligned = ((p.q_tok_off | p.q_rpb | p.q_row0 | p.M | p.q_Spad) & 7) == 0;
+    auto fsw = [](int row) { return ((row >> 3) ^ (row >> 1)) & 7; };
+    static_for<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int h = q >> 1, cp = q & 1;  // dims 64h .. 64h+63 of the head, tokens 64cp .. 64cp+63 of the wave
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<2>([&](auto cc) {
+        constexpr int c2 = 2 * cp + decltype(cc)::value;
+        static_for<2>([&](auto rc) {
+          constexpr int rr = decltype(rc)::value;
+          const int row = decltype(cc)::value * 32 + rr * 16 + mlane;
+          static_for<4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float t;
+              asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c2][rr][j][r]));
+              a[r] = t + bias_of(h * 4 + j, r);
+            }
+            *(uint2*)(stage + row * 128 + (((j * 2 + (ng >> 1)) ^ fsw(row)) << 4) + ((ng & 1) << 3)) =
+                make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+          });
+        });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int dp = it * 8 + dp_lo;  // dim pair of this 64-dim half
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int row = ch_lo * 8 + k;
+          v[k] = *(const uint32_t*)(stage + row * 128 + (((dp >> 2) ^ fsw(row)) << 4) + ((dp & 3) << 2));
+        }
+        const int m = m_wave + cp * 64 + ch_lo * 8;
+        if (m < p.M) {
+          const int d = h * 64 + dp * 2;
+          int b, st;
+          token(m, b, st);
+          bf16_t* row0 = p.q_VT + (((long long)b * p.q_H + head) * 128 + d) * p.q_Spad;
+          if (aligned) {
+            union { bf16x8_t v8; uint32_t uu[4]; } lo, hi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              lo.uu[k] = (v[2 * k] & 0xffffu) | (v[2 * k + 1] << 16);
+              hi.uu[k] = (v[2 * k] >> 16) | (v[2 * k + 1] & 0xffff0000u);
+            }
+            *(bf16x8_t*)(row0 + st) = lo.v8;
+            *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (m + k < p.M) {
+                int bk, sk;
+                token(m + k, bk, sk);
+                bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + head) * 128 + d) * p.q_Spad + sk;
+                rk[0] = (bf16_t)(v[k] & 0xffffu);
+                rk[p.q_Spad] = (bf16_t)(v[k] >> 16);
+              }
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // gathered before the next chunk is parked
+    });
+  }
+}
+
 // One unit of a workgroup's list: K-tiles [k0, k0 + len) of the output tile with virtual block id vb.  Whole tiles have k0 = 0,
 // len = nk; the tiles of the last, partly filled round are cut along K into segments handed from workgroup to workgroup ("stream-K",
 // chained: the next segment CONTINUES the accumulators of the previous one, so every output is summed in exactly the order of an
@@ -147,7 +342,7 @@ struct Unit {
   int vb, k0, len, slab;  // slab = index of the split tile (partial-accumulator slab and progress flag); -1: whole tile
 };
 
-template <int ACT, bool RES, bool HASC2>
+template <int ACT, bool RES, bool HASC2, bool QKV = false>
 __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A image 32 KiB | W image 32 KiB][4 waves x 8 KiB staging]
   const int tid = threadIdx.x;
@@ -318,7 +513,8 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
     } else {
       // ---- epilogue of (z, m0, n0): per-wave private staging, no workgroup barrier; the next unit's first two K-tiles are in flight
       if (cur.k0 > 0 && tid == 0) __hip_atomic_store(p.sk_flags + cur.slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tile closed: flag back to 0
-      epilogue_chunked<ACT, RES, HASC2>(p, acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      if constexpr (QKV) epilogue_qkv_chunked(p, acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      else epilogue_chunked<ACT, RES, HASC2>(p, acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
     }
     if (!has_next) break;
     cur = nxt; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
@@ -329,6 +525,8 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
 }
 
 }  // namespace
+
+kern_t pick_gemm256p_qkv() { return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true>; }
 
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2) {
   if (f32) return nullptr;
