@@ -184,10 +184,11 @@ def test_attention_forced_rescale_branch(ops):
     assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("B,H,S,S0", [(1, 1, 64, 0), (2, 2, 136, 40), (1, 2, 1152, 128), (1, 3, 700, 100), (2, 1, 2000, 0)])
 def test_attention_kernel_forms(ops, opt, variant, B, H, S, S0):
-    """attn_variant 4 = the 4-wave kernel, 5 / 6 = the 8-wave ping-pong kernel (attention_pp.hip) with / without defer-max, on
+    """attn_variant 4 = the 4-wave kernel, 5 / 6 = the 8-wave ping-pong kernel (attention_pp.hip) with / without defer-max, 9 = the
+    hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip: 1, 2, 3, 11, 18 and 32 key tiles, ragged last tiles), on
     ragged sequence lengths (S % 64 != 0, S % 256 != 0, fewer rows than one 256-row workgroup) and with the forced-rescale spike."""
     opt("attn_variant", variant)
     assert _attention_case(ops, B, H, S, S0, 200 + S) < 1e-2
@@ -211,6 +212,43 @@ def test_attention_ping_pong_equals_four_wave_kernel_closely(ops, opt):
         ops.attention(Q, K, VT, O, B, H, S, Spad, H * 128, S * H * 128, 1 / math.sqrt(128))
         outs.append(O)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_attention_hand_scheduled_kernel_on_the_model_shape(ops, opt):
+    """attention_w4.hip (default for launches that fill the chip) at the model's shape -- B = 2, 24 heads, S = 4608 -- against fp32
+    softmax(QK^T / sqrt(d)) V on sampled heads, against the 4-wave kernel within bf16 rounding of P (the two kernels take the defer-max
+    decision over different row groups, so they are close, not identical), its log2-sum-exp rows against torch.logsumexp, and twice
+    in a row bit for bit (no state leaks between launches)."""
+    import math
+    from x2i_amd import _lib
+    B, H, S = 2, 24, 4608
+    Spad = ops.pad128(S)
+    scale = 1 / math.sqrt(128)
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    Q = (torch.randn((B, H, Spad, 128), device=DEV, generator=gen) * 1.5).bfloat16()
+    K = (torch.randn((B, H, Spad, 128), device=DEV, generator=gen) * 1.5).bfloat16()
+    VT = torch.randn((B, H, 128, Spad), device=DEV, generator=gen).bfloat16()
+
+    def run(v, with_lse=False):
+        opt("attn_variant", v)
+        O = torch.empty((B, S, H * 128), device=DEV, dtype=torch.bfloat16)
+        if with_lse:
+            lse = torch.zeros((B, H, Spad), device=DEV)
+            ops.attention_lse(Q, K, VT, O, lse, B, H, S, Spad, H * 128, S * H * 128, scale)
+            return O, lse
+        ops.attention(Q, K, VT, O, B, H, S, Spad, H * 128, S * H * 128, scale)
+        return O
+    o9 = run(0)       # automatic choice = the hand-scheduled kernel at this size
+    o9b, lse = run(9, with_lse=True)
+    o4 = run(4)
+    assert torch.equal(o9, o9b)
+    assert rel_l2(o9, o4) < 4e-3
+    for (b, h) in ((0, 0), (1, 23), (1, 7)):
+        q, k, v = Q[b, h, :S].float(), K[b, h, :S].float(), VT[b, h, :, :S].float().t()
+        sc = scale * q @ k.t()
+        ref = torch.softmax(sc, -1) @ v
+        assert rel_l2(o9[b, :, h * 128:(h + 1) * 128], ref) < 1e-2
+        assert rel_l2(lse[b, h, :S], torch.logsumexp(sc, -1) * 1.4426950408889634) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ norms / small linears

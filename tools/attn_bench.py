@@ -28,8 +28,9 @@ def main():
     rnd = lambda *sh: torch.randn(sh, device="cuda").bfloat16()  # noqa: E731
     Q, K_, VT = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16)
-    names = {4: "4-wave", 5: "ping-pong", 7: "ping-pong, DMA in vector phase", 8: "ping-pong, 4-deep rings + fragment prefetch"}
-    for var in (5, 8, 7, 4, 5, 8):
+    names = {4: "4-wave", 5: "ping-pong", 7: "ping-pong, DMA in vector phase", 8: "ping-pong, 4-deep rings + fragment prefetch",
+             9: "hand-scheduled, one wave per SIMD (attention_w4.hip)"}
+    for var in (9, 8, 4, 9, 8, 9):
         _lib.set_option("attn_variant", var)
         t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention[{names[var]}] B={B}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")

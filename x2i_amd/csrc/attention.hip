@@ -320,7 +320,13 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   const float scale_log2 = scale * 1.4426950408889634f;
   const X2IOptions& opt = x2i_options();
   const int var = opt.attn_variant;  // 0 = automatic; A/B: 1 = 8 lock-step waves, 2 = no defer-max, 3 = both, 4 = 4-wave kernel, 5 / 6 = ping-pong schedule 0 (defer-max / none), 7 / 8 = ping-pong schedules 1 / 2
-  // the 8-wave ping-pong kernel (attention_pp.hip) serves sequences long enough to fill the chip with 256-row workgroups
+  // sequences long enough to fill the chip with 256-row workgroups: the hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip;
+  // variant 9 forces it, 5..8 select the 8-wave ping-pong kernel it replaced as the default)
+  if (!out8 && ((var == 0 && (long long)((S + 255) / 256) * H * B >= 256) || var == 9)) {
+    const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, lse);
+    if (rc != X2I_ERR_STATE) return rc;
+  }
+  // the 8-wave ping-pong kernel (attention_pp.hip)
   if ((var == 0 && (long long)((S + 255) / 256) * H * B >= 256) || var == 5 || var == 6 || var == 7 || var == 8) {
     const int rc = x2i_launch_attention_pp(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, out8, oinv, var == 6 ? 0 : 8, lse);
     if (rc != X2I_ERR_STATE) return rc;  // X2I_ERR_STATE: shape / alignment not served by that kernel -> fall through
