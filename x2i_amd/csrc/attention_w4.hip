@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
   // (integer arithmetic, not a comparison: an i1 would be materialised in a VGPR and cannot feed an "s" operand)
   const uint32_t lsef = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)lse >> 32) | (uint32_t)(uintptr_t)lse);
   const float thr = 8.0f;  // defer-max threshold, exp2 domain (as attention.hip)
-  uint32_t s_tk, s_tv, s_so, s_fl;
+  uint32_t s_tk, s_tv, s_so, s_so2, s_fl;
   unsigned long long s_cnd, s_exs;
   asm volatile(X2I_ATTN_W4_TEXT
                : [ka0] "+v"(ka[0]), [ka1] "+v"(ka[1]), [ka2] "+v"(ka[2]), [ka3] "+v"(ka[3]), [ka4] "+v"(ka[4]), [ka5] "+v"(ka[5]),
                  [ka6] "+v"(ka[6]), [ka7] "+v"(ka[7]), [va0] "+v"(va[0]), [va1] "+v"(va[1]), [va2] "+v"(va[2]), [va3] "+v"(va[3]),
-                 [oo] "+v"(oo), [kdst] "+s"(kdst), [vdst] "+s"(vdst), [cnt] "+s"(cnt), [tk] "=&s"(s_tk), [tv] "=&s"(s_tv), [so] "=&s"(s_so),
+                 [oo] "+v"(oo), [kdst] "+s"(kdst), [vdst] "+s"(vdst), [cnt] "+s"(cnt), [tk] "=&s"(s_tk), [tv] "=&s"(s_tv), [so] "=&s"(s_so), [so2] "=&s"(s_so2),
                  [fl] "=&s"(s_fl), [cnd] "=&s"(s_cnd), [exs] "=&s"(s_exs)
                : [kd0] "v"(kd[0]), [kd1] "v"(kd[1]), [kd2] "v"(kd[2]), [kd3] "v"(kd[3]), [vd0] "v"(vd[0]), [vd1] "v"(vd[1]), [vd2] "v"(vd[2]),
                  [vd3] "v"(vd[3]), [qo0] "v"(qo0), [qo1] "v"(qo1), [lo] "v"(lo), [qv] "v"(q), [lim] "v"(lim), [hi] "v"(hi), [kr] "s"(k_rsrc),

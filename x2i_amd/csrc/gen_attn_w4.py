@@ -23,8 +23,8 @@ half-wave exchange, 16-byte stores, log-sum-exp) are all inside the one statemen
 import os
 import sys
 
-LEAD = 3            # fragment reads are issued this many units (= one fragment, two MFMAs) ahead of their use
-RING = 16           # fragment ring slots (4 accumulator registers each); divides the 16 / 32 units of every iteration kind
+LEAD = int(os.environ.get("X2I_ATTN_LEAD", "3"))   # fragment reads are issued this many units (= one fragment, two MFMAs) ahead of their use
+RING = 8            # fragment ring slots (4 accumulator registers each)
 NEG_BIG = "0xf149f2ca"   # -1.0e30f
 
 # ------------------------------------------------------------------------------------------------ register map
@@ -54,7 +54,9 @@ PF = valloc(64, 4)        # P[set][u][kt][qb][w]
 TMP = valloc(12, 4)
 M_RUN, L_RUN, M_USE, MX, MX2, ALPHA, PSUM = (valloc(2) for _ in range(7))
 NEGBIG = valloc(1)
+ONES = valloc(4, 4)       # bf16 1.0 x 8: the A operand that makes the matrix pipe produce the row sums of P
 OA = aalloc(128, 16)      # O[db][qb][r]
+LA = aalloc(32, 16)       # L[qb][r]: row sums of P (every register of a lane holds the sum of ITS query row), scaled like O
 QF = aalloc(64, 4)        # Q[qb][ds][w]
 FR = aalloc(RING * 4, 4)  # fragment ring
 
@@ -71,6 +73,11 @@ def P(st, u, kt, qb, w=None):
 
 def O(db, qb, r=None):
     b = OA + (db * 2 + qb) * 16
+    return f"a[{b}:{b + 15}]" if r is None else f"a{b + r}"
+
+
+def LS(qb, r=None):
+    b = LA + qb * 16
     return f"a[{b}:{b + 15}]" if r is None else f"a{b + r}"
 
 
@@ -126,23 +133,24 @@ def softmax_stream(st, masked):
     L.append(f"v_max_f32 v{MX2}, v{MX2}, v{MX2 + 1}")
     L.append(f"v_cmp_lt_f32 %[cnd], %[thr], v{MX2}")                             # some row of this wave grew by more than THR = 8 ?
     L.append(("DECIDE",))
-    for qb in range(2):
-        L.append(f"v_mov_b32 v{PSUM + qb}, 0")
-    # p = exp2(s * c - m); bf16 pairs -> P fragment (sub-tile u, k-step kt) = registers 8kt .. 8kt+7 of S[u]; row sums
+    # p = exp2(s * c - m); bf16 pairs -> P fragment (sub-tile u, k-step kt) = registers 8kt .. 8kt+7 of S[u].  The row sums come from
+    # the matrix pipe (ones x P^T beside the PV products).  The three steps of a value are issued as a software pipeline -- fma(k),
+    # exp(k - 2), cvt of the pair behind (k - 4) -- so that the quarter-rate exponentials are spread evenly over the MFMA gaps
+    # instead of arriving eight in a row (a burst of transcendentals outlasts the gap and starves the matrix pipe)
+    seq = []
     for u in range(2):
         for kt in range(2):
             for qb in range(2):
-                regs = [S(st, u, qb, kt * 8 + k) for k in range(8)]
-                for x in regs:
-                    L.append(f"v_fma_f32 {x}, {x}, %[sc], -v{M_USE + qb}")
-                for x in regs:
-                    L.append(f"v_exp_f32 {x}, {x}")
-                for k in range(0, 8, 2):
-                    L.append(f"v_cvt_pk_bf16_f32 {P(st, u, kt, qb, k // 2)}, {regs[k]}, {regs[k + 1]}")
-                for x in regs:
-                    L.append(f"v_add_f32 v{PSUM + qb}, v{PSUM + qb}, {x}")
-    for qb in range(2):
-        L.append(f"v_add_f32 v{L_RUN + qb}, v{L_RUN + qb}, v{PSUM + qb}")      # (l_run was scaled by alpha on the rescale path)
+                for k in range(8):
+                    seq.append((S(st, u, qb, kt * 8 + k), qb, P(st, u, kt, qb, k // 2) if k & 1 else None, S(st, u, qb, kt * 8 + k - 1) if k & 1 else None))
+    n = len(seq)
+    for k in range(n + 4):
+        if k < n:
+            L.append(f"v_fma_f32 {seq[k][0]}, {seq[k][0]}, %[sc], -v{M_USE + seq[k][1]}")
+        if 0 <= k - 2 < n:
+            L.append(f"v_exp_f32 {seq[k - 2][0]}, {seq[k - 2][0]}")
+        if 0 <= k - 4 < n and seq[k - 4][2] is not None:
+            L.append(f"v_cvt_pk_bf16_f32 {seq[k - 4][2]}, {seq[k - 4][3]}, {seq[k - 4][0]}")
     return L
 
 
@@ -153,9 +161,6 @@ def decide(uid):
         L += [f"v_sub_f32 v{ALPHA + qb}, v{M_RUN + qb}, v{MX + qb}", f"v_mov_b32 v{M_RUN + qb}, v{MX + qb}"]
     for qb in range(2):
         L += [f"v_exp_f32 v{ALPHA + qb}, v{ALPHA + qb}"]
-    L += ["s_nop 1"]
-    for qb in range(2):
-        L += [f"v_mul_f32 v{L_RUN + qb}, v{L_RUN + qb}, v{ALPHA + qb}"]
     L += ["s_mov_b32 %[fl], 1", f".Lkeep{uid}_%=:"]
     for qb in range(2):
         L += [f"v_mov_b32 v{M_USE + qb}, v{M_RUN + qb}"]
@@ -171,6 +176,11 @@ def o_rescale(uid):
                 L += [f"v_accvgpr_read_b32 {T(k)}, {O(db, qb, r0 + k)}" for k in range(4)]
                 L += [f"v_mul_f32 {T(k)}, {T(k)}, v{ALPHA + qb}" for k in range(4)]
                 L += [f"v_accvgpr_write_b32 {O(db, qb, r0 + k)}, {T(k)}" for k in range(4)]
+    for qb in range(2):
+        for r0 in range(0, 16, 4):
+            L += [f"v_accvgpr_read_b32 {T(k)}, {LS(qb, r0 + k)}" for k in range(4)]
+            L += [f"v_mul_f32 {T(k)}, {T(k)}, v{ALPHA + qb}" for k in range(4)]
+            L += [f"v_accvgpr_write_b32 {LS(qb, r0 + k)}, {T(k)}" for k in range(4)]
     L += ["s_mov_b32 %[fl], 0", "s_nop 3", f".Lnors{uid}_%=:"]
     return L
 
@@ -187,11 +197,14 @@ def unit_list(has_qk, has_pv):
             out.append(ku[i])
         if vu:
             out.append(vu[i])
+            if i % 4 == 3:
+                out.append(("L", i // 4, 0))   # L[qb] += ones x P^T(u, kt): no fragment to read
     return out
 
 
 def frag_read(unit, slot):
     kind, a, b = unit
+    assert kind != "L"
     if kind == "K":   # d-step ds = a (address register per ds: the swizzle is an XOR), sub-tile u = b (+ 32 rows x 256 B)
         return f"ds_read_b128 {F(slot)}, %[ka{a}]" + (f" offset:{b * 8192}" if b else "")
     return f"ds_read_b128 {F(slot)}, %[va{a}]" + (f" offset:{b * 4096}" if b else "")   # (u, kt) = a, d-block db = b (+ 32 rows x 128 B)
@@ -202,26 +215,45 @@ def unit_mfmas(unit, slot, s_dst, p_src):
     if kind == "K":
         ds, u = a, b
         return [f"v_mfma_f32_32x32x16_bf16 {S(s_dst, u, qb)}, {F(slot)}, {Q(qb, ds)}, " + ("0" if ds == 0 else S(s_dst, u, qb)) for qb in range(2)]
+    if kind == "L":
+        g = a
+        return [f"v_mfma_f32_32x32x16_bf16 {LS(qb)}, v[{ONES}:{ONES + 3}], {P(p_src, g >> 1, g & 1, qb)}, {LS(qb)}" for qb in range(2)]
     g, db = a, b
     return [f"v_mfma_f32_32x32x16_bf16 {O(db, qb)}, {F(slot)}, {P(p_src, g >> 1, g & 1, qb)}, {O(db, qb)}" for qb in range(2)]
 
 
-def sync_block(uid):
-    """Ring hand-over: every fragment read of this iteration has been issued above.  Wait for them and for this wave's pieces of the
-    tiles the NEXT iteration reads, barrier; the slots this iteration read are free: flip the fragment addresses to the other slots
-    and fetch K(tile %[tk]) / V(tile %[tv]) into the freed ones (skipped behind the last tile)."""
+def sync_wait():
+    """Ring hand-over, part 1: every fragment read of this iteration has been issued (and had time to return) above.  Wait for them
+    and for this wave's pieces of the tiles the NEXT iteration reads, barrier; the slots this iteration read are free: flip the
+    fragment addresses to the other slots."""
     L = ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    if os.environ.get("X2I_ATTN_ABL") == "nobar":      # measurement only (wrong results): what the per-tile barrier costs
+        L = ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    if os.environ.get("X2I_ATTN_ABL") == "nosync":     # measurement only: neither the waits nor the barrier
+        L = []
     L += [f"v_xor_b32 %[ka{ds}], 0x4000, %[ka{ds}]" for ds in range(8)]
     L += [f"v_xor_b32 %[va{g}], 0x4000, %[va{g}]" for g in range(4)]
-    L += ["s_cmp_lt_u32 %[tk], %[nt]", f"s_cbranch_scc0 .Lnok{uid}_%=", "s_lshl_b32 %[so], %[tk], 14"]   # 64 keys x 256 B per K tile
-    for j in range(4):
-        L += [f"s_add_u32 m0, %[kdst], {j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
-    L += [f".Lnok{uid}_%=:", "s_cmp_lt_u32 %[tv], %[nt]", f"s_cbranch_scc0 .Lnov{uid}_%=", "s_lshl_b32 %[so], %[tv], 7"]  # 64 keys x 2 B per row
-    for j in range(4):
-        L += [f"s_add_u32 m0, %[vdst], {j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vd{j}], %[vr], %[so] offen lds"]
-    L += [f".Lnov{uid}_%=:", "s_xor_b32 %[kdst], %[kdst], 0x4000", "s_xor_b32 %[vdst], %[vdst], 0x4000", "s_add_u32 %[tk], %[tk], 1",
-          "s_add_u32 %[tv], %[tv], 1"]
     return L
+
+
+def sync_dma():
+    """Part 2, as (M0 write, piece) pairs to be spread between the iteration's last MFMAs: K(tile %[tk]) / V(tile %[tv]) into the freed
+    slots.  Unconditional: behind the last tile the pieces read rows at or past the sequence end (zero rows / zero fill past the
+    buffer end), are never consumed, and cost three tiles per workgroup."""
+    pre = ["s_lshl_b32 %[so], %[tk], 14", "s_lshl_b32 %[so2], %[tv], 7"]     # 64 keys x 256 B per K tile; 64 keys x 2 B per V^T row
+    pairs = [(f"s_add_u32 m0, %[kdst], {j * 4096}", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds") for j in range(4)]
+    pairs += [(f"s_add_u32 m0, %[vdst], {j * 4096}", f"buffer_load_dwordx4 %[vd{j}], %[vr], %[so2] offen lds") for j in range(4)]
+    post = ["s_xor_b32 %[kdst], %[kdst], 0x4000", "s_xor_b32 %[vdst], %[vdst], 0x4000", "s_add_u32 %[tk], %[tk], 1", "s_add_u32 %[tv], %[tv], 1"]
+    return pre, pairs, post
+
+
+def sync_block(uid):
+    """The whole hand-over without MFMAs to hide it (prologue only)."""
+    pre, pairs, post = sync_dma()
+    L = sync_wait() + pre
+    for m0, ld in pairs:
+        L += [m0, "s_nop 0", ld]
+    return L + post
 
 
 _uid = [0]
@@ -229,21 +261,47 @@ VALU_DELAY = 4      # MFMAs at the head of an iteration that carry no softmax in
                     # previous iteration's last MFMAs, and nothing interlocks a VALU read against an MFMA still in the pipe
 
 
-class DsQueue:
-    """Outstanding fragment reads, oldest first: a use waits with lgkmcnt(number of younger reads)."""
+class Stream:
+    """Fragment bookkeeping of one unit list: ring slots are dealt to the units that read a fragment, in order; reads are issued
+    ahead of their use and a use waits with lgkmcnt(number of younger reads)."""
 
-    def __init__(self, preread):
-        self.q = list(preread)
+    def __init__(self, us, preread):
+        self.us = us
+        self.fidx = []
+        f = 0
+        for u in us:
+            self.fidx.append(f if u[0] != "L" else None)
+            f += u[0] != "L"
+        self.nfrag = f
+        self.q = [i for i in range(min(preread, f))]     # outstanding reads (fragment indices), oldest first
+        self.next = min(preread, f)                      # next fragment index to read
+        self.funits = [k for k, u in enumerate(us) if u[0] != "L"]
 
-    def issue(self, L, unit, slot):
-        L.append(frag_read(unit, slot))
-        self.q.append(slot)
+    def read_upto_unit(self, L, unit_limit):
+        """issue the reads of every fragment unit with unit index < unit_limit"""
+        while self.next < self.nfrag and self.funits[self.next] < unit_limit:
+            L.append(frag_read(self.us[self.funits[self.next]], self.next))
+            self.q.append(self.next)
+            self.next += 1
 
-    def wait_for(self, L, slot):
-        if slot in self.q:
-            pos = self.q.index(slot)
-            L.append(f"s_waitcnt lgkmcnt({len(self.q) - 1 - pos})")
+    def wait(self, L, k):
+        f = self.fidx[k]
+        if f is not None and f in self.q:
+            pos = self.q.index(f)
+            if os.environ.get("X2I_ATTN_ABL") != "nolgk":   # (measurement only: no waits on the fragment reads)
+                L.append(f"s_waitcnt lgkmcnt({len(self.q) - 1 - pos})")
             self.q = self.q[pos + 1:]
+
+    def mfmas(self, k, s_dst, p_src):
+        return unit_mfmas(self.us[k], self.fidx[k] if self.fidx[k] is not None else 0, s_dst, p_src)
+
+
+def prereads(kind):
+    us = unit_list(*kind)
+    st = Stream(us, 0)
+    L = []
+    st.read_upto_unit(L, st.funits[LEAD - 1] + 1 if st.nfrag >= LEAD else len(us))
+    return L
 
 
 def iteration(st, has_qk, has_pv, softmax, masked, next_kinds):
@@ -257,46 +315,79 @@ def iteration(st, has_qk, has_pv, softmax, masked, next_kinds):
     va = []   # elements: one instruction, or a list that must stay contiguous (a scalar branch and the code it jumps over)
     for ins in (softmax_stream(st, masked) if softmax else []):
         va.append(decide(uid) if isinstance(ins, tuple) else ins)
+    if os.environ.get("X2I_ATTN_ABL") == "novalu":      # measurement only: the MFMA / LDS / DMA stream alone
+        va = []
     L = []
     vi = 0
 
-    def fill(count):
+    def cost(e):
+        if isinstance(e, list):
+            return len(e)
+        return 4 if e.startswith("v_exp") else 1     # a transcendental occupies the VALU about four times as long
+
+    total_cost = sum(cost(e) for e in va)
+    spent = [0]
+
+    def fill_to(target_cost):
         nonlocal vi
-        for _ in range(count):
-            if vi < len(va):
-                if isinstance(va[vi], list):
-                    L.extend(va[vi])
-                else:
-                    L.append(va[vi])
-                vi += 1
-    split = max(0, n - LEAD)              # units in front of the hand-over: the read of the last unit is issued with unit split - 1
+        while vi < len(va) and spent[0] + cost(va[vi]) <= target_cost:
+            spent[0] += cost(va[vi])
+            if isinstance(va[vi], list):
+                L.extend(va[vi])
+            else:
+                L.append(va[vi])
+            vi += 1
+
+    def fill(count):
+        fill_to(10 ** 9) if count >= len(va) else None
+    split = max(0, n - LEAD)              # units in front of the hand-over
+    early = max(0, split - 3)             # from this unit on, every remaining read of the iteration is issued at once: the hand-over's
+                                          # lgkmcnt(0) then finds them returned instead of exposing one LDS round trip per iteration
     gaps = max(1, 2 * split - VALU_DELAY)
-    per_gap = -(-len(va) // gaps) if va else 0     # the VALU stream is finished in front of the hand-over
-    dq = DsQueue(range(min(LEAD, n)))
+    sm = Stream(us, LEAD)
     mf = 0
     for k in range(split):
-        if k + LEAD < n:
-            dq.issue(L, us[k + LEAD], k + LEAD)
-        dq.wait_for(L, k)
-        for m in unit_mfmas(us[k], k, st ^ 1, st ^ 1):
+        sm.read_upto_unit(L, n if k >= early else k + LEAD + 1)
+        sm.wait(L, k)
+        for m in sm.mfmas(k, st ^ 1, st ^ 1):
             L.append(m)
             mf += 1
             if mf > VALU_DELAY:
-                fill(per_gap)
+                g = mf - VALU_DELAY          # spread the VALU stream evenly by issue time: g / G of its cost is out after gap g
+                fill_to(g * total_cost // gaps)
     if n == 0:
         L += ["s_nop 15", "s_nop 15"]       # (no MFMA cover at all: the scores come from the prologue's last MFMAs)
     fill(len(va))
-    assert vi == len(va)
-    assert not dq.q or split == 0 or True
+    sm.read_upto_unit(L, n)
+    assert vi == len(va) and sm.next == sm.nfrag
     for ci, (cond, nxt, label) in enumerate(next_kinds):
         if cond:
             L += ["s_cmp_lg_u32 %[cnt], 0", f"s_cbranch_scc1 .Lalt{uid}_%="]
-        L += sync_block(f"{uid}x{ci}")      # (lgkmcnt(0) inside: every fragment of this iteration is in registers)
-        nus = unit_list(*nxt)
-        for j in range(min(LEAD, len(nus))):
-            L.append(frag_read(nus[j], j))
-        for k in range(split, n):
-            L += unit_mfmas(us[k], k, st ^ 1, st ^ 1)
+        L += sync_wait()                    # (lgkmcnt(0) inside: every fragment of this iteration is in registers)
+        L += prereads(nxt)
+        pre, pairs, post = sync_dma()
+        L += pre
+        tail_m = [m for k in range(split, n) for m in sm.mfmas(k, st ^ 1, st ^ 1)]
+        # pieces between the remaining MFMAs: M0 write, an MFMA (or a nop) in between, the piece
+        pi = 0
+        if pairs:
+            L.append(pairs[0][0])
+        for mi, m in enumerate(tail_m):
+            L.append(m)
+            share = (mi + 1) * len(pairs) // max(1, len(tail_m)) - pi
+            for _ in range(share):
+                L.append(pairs[pi][1])
+                pi += 1
+                if pi < len(pairs):
+                    L.append(pairs[pi][0])
+                    if _ + 1 < share:
+                        L.append("s_nop 0")
+        while pi < len(pairs):
+            L += ["s_nop 0", pairs[pi][1]]
+            pi += 1
+            if pi < len(pairs):
+                L.append(pairs[pi][0])
+        L += post
         if has_pv:
             L += o_rescale(f"{uid}x{ci}")
         else:
@@ -304,6 +395,20 @@ def iteration(st, has_qk, has_pv, softmax, masked, next_kinds):
         L.append(f"s_branch {label}")
         if cond:
             L.append(f".Lalt{uid}_%=:")
+    return L
+
+
+def solo(kind, s_dst, p_src, preread):
+    """A unit list on its own (prologue S(0), tail PV): reads LEAD ahead, no VALU stream."""
+    us = unit_list(*kind)
+    sm = Stream(us, LEAD if preread else 0)
+    L = []
+    if not preread:
+        sm.read_upto_unit(L, sm.funits[LEAD - 1] + 1)
+    for k in range(len(us)):
+        sm.read_upto_unit(L, k + LEAD + 1)
+        sm.wait(L, k)
+        L += sm.mfmas(k, s_dst, p_src)
     return L
 
 
@@ -316,6 +421,9 @@ def prologue():
     for db in range(4):
         for qb in range(2):
             L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(16)]
+    for qb in range(2):
+        L += [f"v_accvgpr_write_b32 {LS(qb, r)}, 0" for r in range(16)]
+    L += [f"v_mov_b32 v{ONES + k}, 0x3f803f80" for k in range(4)]
     # Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + 32 qb + li][16 ds + 8 hi .. + 8], loaded straight into the accumulator file
     for qb in range(2):
         for ds in range(8):
@@ -329,15 +437,7 @@ def prologue():
         L += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
     L += ["s_mov_b32 %[tk], 2", "s_mov_b32 %[tv], 0", "s_waitcnt vmcnt(0)", "s_barrier"]
     # S(0) = K(0) Q^T alone (score set 0)
-    us = unit_list(True, False)
-    for j in range(LEAD):
-        L.append(frag_read(us[j], j))
-    dq = DsQueue(range(LEAD))
-    for k in range(16):
-        if k + LEAD < 16:
-            dq.issue(L, us[k + LEAD], k + LEAD)
-        dq.wait_for(L, k)
-        L += unit_mfmas(us[k], k, 0, 0)
+    L += solo((True, False), 0, 0, False)
     return L
 
 
@@ -345,13 +445,10 @@ def epilogue():
     """O[q][d] = O^T[d][q] / l: lane (q = li, hi) holds d = 32 db + 8 (r >> 2) + 4 hi + (r & 3); a half-wave exchange turns two 8-byte
     fragments of neighbouring d-groups into one 16-byte store (as attention.hip); log2-sum-exp rows on request."""
     L = ["s_nop 15", "s_nop 15"]
+    for qb in range(2):   # row sums: every L register of a lane holds the sum over ALL keys of its query row (both half-waves fed the MFMA)
+        L += [f"v_accvgpr_read_b32 v{L_RUN + qb}, {LS(qb, 0)}"]
     for qb in range(2):
-        L += [f"v_mov_b32 {T(qb)}, v{L_RUN + qb}"]
-    L += ["s_nop 1"]
-    for qb in range(2):
-        L += [f"v_permlane32_swap_b32 v{L_RUN + qb}, {T(qb)}"]
-    for qb in range(2):
-        L += [f"v_add_f32 v{L_RUN + qb}, v{L_RUN + qb}, {T(qb)}", f"v_rcp_f32 v{PSUM + qb}, v{L_RUN + qb}"]
+        L += [f"v_rcp_f32 v{PSUM + qb}, v{L_RUN + qb}"]
     # log2-sum-exp (x2i_attention_lse_bf16): m_run + log2(l) for q < S, +1e30 on the padding rows; lanes of the low half store
     L += ["s_cmp_lg_u32 %[lsef], 0", "s_cbranch_scc0 .Lnolse_%="]
     for qb in range(2):
@@ -399,8 +496,7 @@ def build():
     # hand-over behind S(0): frees K slot 0, fetches K(2) / V(0); the fragment addresses now point at the slots of tile 1
     L += sync_block("p0")
     L += ["s_cmp_eq_u32 %[nt], 1", "s_cbranch_scc1 .Lonly_%="]
-    fus = unit_list(True, False)
-    L += [frag_read(fus[j], j) for j in range(LEAD)]
+    L += prereads((True, False))
     # FIRST (score set 0): successor LAST(set 1) when nt == 2 (%[cnt] == 0), else MID(set 1)
     L += iteration(0, True, False, True, False, [(True, LASTK, ".Llast1_%="), (False, MIDK, ".Lmid1_%=")])
     for par in (1, 0):
@@ -414,15 +510,7 @@ def build():
     L += [".Lonly_%=:"]
     L += iteration(0, False, False, True, True, [(False, TAILK, ".Ltail0_%=")])
     for par in (1, 0):
-        L += [f".Ltail{par}_%=:"]
-        us = unit_list(False, True)
-        dq = DsQueue(range(LEAD))
-        for k in range(16):
-            if k + LEAD < 16:
-                dq.issue(L, us[k + LEAD], k + LEAD)
-            dq.wait_for(L, k)
-            L += unit_mfmas(us[k], k, 0, par)
-        L += ["s_branch .Lepi_%="]
+        L += [f".Ltail{par}_%=:"] + solo((False, True), 0, par, True) + ["s_branch .Lepi_%="]
     L += [".Lepi_%=:"] + epilogue()
     return L
 
