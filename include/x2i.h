@@ -189,6 +189,10 @@ typedef struct x2i_qkv_desc {
   void* VT;            /* bf16 [B,H,128,Spad] */
   int32_t H, Spad, tok_off, rows_per_sample;
   float eps;
+  float q_scale;       /* 0 or 1: none.  Otherwise Q is written as q * q_scale, the factor applied in f32 in front of the one bf16
+                        * rounding: a caller that passes softmax_scale * log2(e) here and scale = ln 2 to x2i_attention_* gets the same
+                        * attention with the score multiply gone from the kernels' inner loops (and none of the double rounding a
+                        * separate rescale of the bf16 Q would cost) */
 } x2i_qkv_desc;
 int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_stream_t stream);
 /* The same fused projection on e4m3 operands (x2i_fp8_desc as for x2i_gemm_fp8, out_fp8 = 0): A is the e4m3 LayerNorm output with

@@ -43,7 +43,7 @@ class QkvDesc(C.Structure):
     _fields_ = [("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
                 ("Q", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p),
                 ("H", C.c_int32), ("Spad", C.c_int32), ("tok_off", C.c_int32), ("rows_per_sample", C.c_int32),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("q_scale", C.c_float)]
 
 
 class Fp8Desc(C.Structure):

@@ -317,13 +317,17 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   if (out8 ? (ldo % 8 || o_bs % 8 || (((uintptr_t)O) & 7)) : (ldo % 4 || o_bs % 4 || (((uintptr_t)O) & 7)))
     return x2i_set_error(X2I_ERR_ALIGN, "attention: output rows must be 8-byte aligned");
   const size_t shm = 2 * (KTILE + VTILE);
-  const float scale_log2 = scale * 1.4426950408889634f;
+  float scale_log2 = scale * 1.4426950408889634f;
+  // scale = ln 2: the caller folded softmax_scale * log2(e) into Q (x2i_qkv_desc.q_scale); the exp2-domain multiplier is exactly 1
+  const bool unit = fabsf(scale_log2 - 1.f) < 1e-6f;
+  if (unit) scale_log2 = 1.f;
   const X2IOptions& opt = x2i_options();
   const int var = opt.attn_variant;  // 0 = automatic; A/B: 1 = 8 lock-step waves, 2 = no defer-max, 3 = both, 4 = 4-wave kernel, 5 / 6 = ping-pong schedule 0 (defer-max / none), 7 / 8 = ping-pong schedules 1 / 2
-  // sequences long enough to fill the chip with 256-row workgroups: the hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip;
-  // variant 9 forces it, 5..8 select the 8-wave ping-pong kernel it replaced as the default)
-  if (!out8 && ((var == 0 && (long long)((S + 255) / 256) * H * B >= 256) || var == 9)) {
-    const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, lse);
+  // sequences long enough to fill the chip with 256-row workgroups and a Q that already carries the scale: the hand-scheduled
+  // one-wave-per-SIMD kernel (attention_w4.hip), whose softmax has no multiply.  Variant 9 forces it for any scale (the kernel then
+  // rescales its bf16 Q fragments itself, at the price of a second rounding of Q); 5..8 select the 8-wave ping-pong kernel
+  if (!out8 && ((var == 0 && unit && (long long)((S + 255) / 256) * H * B >= 256) || var == 9)) {
+    const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse);
     if (rc != X2I_ERR_STATE) return rc;
   }
   // the 8-wave ping-pong kernel (attention_pp.hip)

@@ -12,7 +12,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                       bf16_t* __restrict__ O, int H, int S, int Spad, int ldo, long long o_bs, float scale_log2,
-                                                      int nbatch, float* __restrict__ lse) {
+                                                      int nbatch, float* __restrict__ lse, int prescale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
   for (int ds = 0; ds < 8; ++ds) ka[ds] = sbase + kvm * 256 + (((ds * 2 + hi) ^ (kvm & 15)) << 4);
 #pragma unroll
   for (int g = 0; g < 4; ++g) va[g] = sbase + 32768 + li * 128 + (((2 * g + hi) ^ ((li >> 1) & 7)) << 4);
-  uint32_t kdst = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
-  uint32_t vdst = __builtin_amdgcn_readfirstlane(sbase + 32768 + wave * 1024);
+  const uint32_t kdst = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
+  const uint32_t vdst = __builtin_amdgcn_readfirstlane(sbase + 32768 + wave * 1024);
 
   const int q = q0 + li;
   const uint32_t qo0 = (uint32_t)(min(q, Spad - 1) * 128 + hi * 8) * 2u;        // rows at or behind S are never stored: clamp the read
@@ -75,17 +75,16 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
   // (integer arithmetic, not a comparison: an i1 would be materialised in a VGPR and cannot feed an "s" operand)
   const uint32_t lsef = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)lse >> 32) | (uint32_t)(uintptr_t)lse);
   const float thr = 8.0f;  // defer-max threshold, exp2 domain (as attention.hip)
-  uint32_t s_tk, s_tv, s_so, s_so2, s_fl;
+  uint32_t s_so, s_so2, s_fl;
   unsigned long long s_cnd, s_exs;
   asm volatile(X2I_ATTN_W4_TEXT
-               : [ka0] "+v"(ka[0]), [ka1] "+v"(ka[1]), [ka2] "+v"(ka[2]), [ka3] "+v"(ka[3]), [ka4] "+v"(ka[4]), [ka5] "+v"(ka[5]),
-                 [ka6] "+v"(ka[6]), [ka7] "+v"(ka[7]), [va0] "+v"(va[0]), [va1] "+v"(va[1]), [va2] "+v"(va[2]), [va3] "+v"(va[3]),
-                 [oo] "+v"(oo), [kdst] "+s"(kdst), [vdst] "+s"(vdst), [cnt] "+s"(cnt), [tk] "=&s"(s_tk), [tv] "=&s"(s_tv), [so] "=&s"(s_so), [so2] "=&s"(s_so2),
+               : [oo] "+v"(oo), [cnt] "+s"(cnt), [so] "=&s"(s_so), [so2] "=&s"(s_so2),
                  [fl] "=&s"(s_fl), [cnd] "=&s"(s_cnd), [exs] "=&s"(s_exs)
-               : [kd0] "v"(kd[0]), [kd1] "v"(kd[1]), [kd2] "v"(kd[2]), [kd3] "v"(kd[3]), [vd0] "v"(vd[0]), [vd1] "v"(vd[1]), [vd2] "v"(vd[2]),
-                 [vd3] "v"(vd[3]), [qo0] "v"(qo0), [qo1] "v"(qo1), [lo] "v"(lo), [qv] "v"(q), [lim] "v"(lim), [hi] "v"(hi), [kr] "s"(k_rsrc),
+               : [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [ka4] "v"(ka[4]), [ka5] "v"(ka[5]), [ka6] "v"(ka[6]),
+                 [ka7] "v"(ka[7]), [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [kd0] "v"(kd[0]), [kd1] "v"(kd[1]), [kd2] "v"(kd[2]), [kd3] "v"(kd[3]), [vd0] "v"(vd[0]), [vd1] "v"(vd[1]), [vd2] "v"(vd[2]),
+                 [vd3] "v"(vd[3]), [kdst] "s"(kdst), [vdst] "s"(vdst), [qo0] "v"(qo0), [qo1] "v"(qo1), [lo] "v"(lo), [qv] "v"(q), [lim] "v"(lim), [hi] "v"(hi), [kr] "s"(k_rsrc),
                  [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2), [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt),
-                 [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr)
+                 [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale)
                : "memory", "vcc", "scc", X2I_ATTN_W4_CLOBBERS);
 }
 
@@ -93,12 +92,12 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
 
 // X2I_ERR_STATE: shape / alignment not served by this kernel (the caller falls back to the other forms)
 int x2i_launch_attention_w4(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
-                            float scale_log2, hipStream_t stream, float* lse) {
+                            float scale_log2, int prescale, hipStream_t stream, float* lse) {
   if ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7) || (long long)S * ldo * 2 >= 0x7f000000LL) return X2I_ERR_STATE;
   const int rc = x2i_ensure_dynamic_smem((const void*)attn_w4_kernel, 65536);
   if (rc) return rc;
   dim3 grid(((S + 255) / 256) * H * B);
   hipLaunchKernelGGL(attn_w4_kernel, grid, dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S,
-                     Spad, ldo, o_bs, scale_log2, B, lse);
+                     Spad, ldo, o_bs, scale_log2, B, lse, prescale);
   return x2i_check_launch("attention");
 }

@@ -179,7 +179,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
     {
       const bf16x8_t wv = *(const bf16x8_t*)((sec ? p.q_nk : p.q_nq) + c * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]);
+      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]) * (sec ? 1.f : p.q_qs);
     }
     bf16_t* dstbase = sec ? p.q_K : p.q_Q;
     f32x4_t cs[2][4];  // per pass of a half chunk: cos[0..3], cos[4..7], sin[0..3], sin[4..7] of this lane's 8 dims

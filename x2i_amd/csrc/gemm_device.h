@@ -27,7 +27,7 @@ struct GemmP {
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0;
   int gm;
-  float q_eps;
+  float q_eps, q_qs;
   const bf16_t *q_nq, *q_nk;
   const float *q_cos, *q_sin;
   bf16_t *q_Q, *q_K, *q_VT;
@@ -363,7 +363,7 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
     {
       const bf16x8_t wv = *(const bf16x8_t*)((sec ? p.q_nk : p.q_nq) + c * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]);
+      for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]) * (sec ? 1.f : p.q_qs);
     }
     bf16_t* dstbase = sec ? p.q_K : p.q_Q;
 #pragma unroll 2

@@ -23,9 +23,10 @@ half-wave exchange, 16-byte stores, log-sum-exp) are all inside the one statemen
 import os
 import sys
 
-LEAD = int(os.environ.get("X2I_ATTN_LEAD", "3"))   # fragment reads are issued this many units (= one fragment, two MFMAs) ahead of their use
-RING = 8            # fragment ring slots (4 accumulator registers each)
+LEAD = int(os.environ.get("X2I_ATTN_LEAD", "4"))   # fragment reads are issued this many units (= one fragment, two MFMAs) ahead of their use
+RING = 16           # fragment ring slots (4 accumulator registers each)
 NEG_BIG = "0xf149f2ca"   # -1.0e30f
+ABL = os.environ.get("X2I_ATTN_ABL", "")            # measurement only (tools/r03_attn_abl.sh): nobar / nosync / nolgk / novalu give wrong results
 
 # ------------------------------------------------------------------------------------------------ register map
 _v, _a = 32, 0      # v0..v31 belong to the statement's operands
@@ -49,16 +50,18 @@ def aalloc(n, align=1):
     return b
 
 
-SA = valloc(128, 16)      # S[set][u][qb][r]
-PF = valloc(64, 4)        # P[set][u][kt][qb][w]
+SA = valloc(128, 16)      # S[set][u][qb][r]: scores MINUS the running row maximum (exp2 domain) -- see NEGM
+PF = valloc(32, 4)        # P[u][kt][qb][w]: ONE set; softmax(i) overwrites group g = (u, kt) behind the last PV MFMA that read P(i-1)[g]
+NEGM = valloc(32, 16)     # NEGM[qb][r]: minus the running row maximum, sixteen copies per query block = the C operand of the first
+                          # QK^T MFMA of a tile, so that the scores arrive with the maximum already subtracted
 TMP = valloc(12, 4)
-M_RUN, L_RUN, M_USE, MX, MX2, ALPHA, PSUM = (valloc(2) for _ in range(7))
+LSUM = valloc(4)          # [qb][2]: row sums of p (two accumulators per query block; this half-wave's 32 keys of every tile)
+MX, MX2, ALPHA, DELTA = (valloc(2) for _ in range(4))
 NEGBIG = valloc(1)
-ONES = valloc(4, 4)       # bf16 1.0 x 8: the A operand that makes the matrix pipe produce the row sums of P
 OA = aalloc(128, 16)      # O[db][qb][r]
-LA = aalloc(32, 16)       # L[qb][r]: row sums of P (every register of a lane holds the sum of ITS query row), scaled like O
-QF = aalloc(64, 4)        # Q[qb][ds][w]
+QF = aalloc(64, 4)        # Q[qb][ds][w], pre-multiplied by scale * log2(e)
 FR = aalloc(RING * 4, 4)  # fragment ring
+QTMP = SA + 64            # the raw Q fragments pass through score set 1 in the prologue
 
 
 def S(st, u, qb, r=None):
@@ -66,18 +69,18 @@ def S(st, u, qb, r=None):
     return f"v[{b}:{b + 15}]" if r is None else f"v{b + r}"
 
 
-def P(st, u, kt, qb, w=None):
-    b = PF + (((st * 2 + u) * 2 + kt) * 2 + qb) * 4
+def P(u, kt, qb, w=None):
+    b = PF + ((u * 2 + kt) * 2 + qb) * 4
     return f"v[{b}:{b + 3}]" if w is None else f"v{b + w}"
+
+
+def NM(qb, r=None):
+    b = NEGM + qb * 16
+    return f"v[{b}:{b + 15}]" if r is None else f"v{b + r}"
 
 
 def O(db, qb, r=None):
     b = OA + (db * 2 + qb) * 16
-    return f"a[{b}:{b + 15}]" if r is None else f"a{b + r}"
-
-
-def LS(qb, r=None):
-    b = LA + qb * 16
     return f"a[{b}:{b + 15}]" if r is None else f"a{b + r}"
 
 
@@ -96,9 +99,11 @@ def T(i):
 
 
 # ------------------------------------------------------------------------------------------------ softmax of one tile (VALU stream)
-def softmax_stream(st, masked):
-    """VALU instructions for the softmax of score set `st` (both 32-row query blocks of the wave): P fragments of set `st`, m_run / l_run;
-    raises %[fl] when a row maximum grew by more than the defer-max threshold (O is then rescaled at the end of the iteration)."""
+def softmax_pass1(st, masked, first, uid):
+    """Row maxima of score set `st` and the defer-max decision.  The scores already carry -m_run (NEGM was the C operand of their
+    first MFMA), so the common case is: max over the tile <= THR, nothing to do.  Otherwise (rare; scalar branch) the rows that grew
+    adopt the tile maximum: delta = max(tile max, 0), scores -= delta, NEGM -= delta, row sums *= alpha = exp2(-delta), and the flag
+    makes the end of the iteration scale O by alpha.  `first`: the scores are raw (C = 0) and every row adopts its maximum."""
     L = []
     if masked:
         # keys at or behind the sequence end.  Lane holds (tile-relative) key u*32 + 16*(r >> 3) + 8*hi + (r & 7); %[lim] = S - kv0 - 8*hi
@@ -127,43 +132,54 @@ def softmax_stream(st, masked):
         L.append(f"v_permlane32_swap_b32 v{MX + qb}, v{MX2 + qb}")             # the other 32 keys of a query row live in lane ^ 32
     for qb in range(2):
         L.append(f"v_max_f32 v{MX + qb}, v{MX + qb}, v{MX2 + qb}")
-        L.append(f"v_mul_f32 v{MX + qb}, %[sc], v{MX + qb}")                   # exp2 domain
-        L.append(f"v_max_f32 v{MX + qb}, v{M_RUN + qb}, v{MX + qb}")          # candidate new running max
-        L.append(f"v_sub_f32 v{MX2 + qb}, v{MX + qb}, v{M_RUN + qb}")
-    L.append(f"v_max_f32 v{MX2}, v{MX2}, v{MX2 + 1}")
-    L.append(f"v_cmp_lt_f32 %[cnd], %[thr], v{MX2}")                             # some row of this wave grew by more than THR = 8 ?
-    L.append(("DECIDE",))
-    # p = exp2(s * c - m); bf16 pairs -> P fragment (sub-tile u, k-step kt) = registers 8kt .. 8kt+7 of S[u].  The row sums come from
-    # the matrix pipe (ones x P^T beside the PV products).  The three steps of a value are issued as a software pipeline -- fma(k),
-    # exp(k - 2), cvt of the pair behind (k - 4) -- so that the quarter-rate exponentials are spread evenly over the MFMA gaps
-    # instead of arriving eight in a row (a burst of transcendentals outlasts the gap and starves the matrix pipe)
+    subs = [f"v_sub_f32 {S(st, u, qb, r)}, {S(st, u, qb, r)}, v{(MX if first else DELTA) + qb}" for u in range(2) for qb in range(2) for r in range(16)]
+    if first:
+        for qb in range(2):
+            L.append(f"v_sub_f32 {NM(qb, 0)}, 0, v{MX + qb}")
+            L += [f"v_mov_b32 {NM(qb, r)}, {NM(qb, 0)}" for r in range(1, 16)]
+        L += subs
+        L += [f"v_mov_b32 v{LSUM + k}, 0" for k in range(4)]
+        return L
+    L.append(f"v_max_f32 {T(0)}, v{MX}, v{MX + 1}")
+    L.append(f"v_cmp_lt_f32 %[cnd], %[thr], {T(0)}")                           # some row of this wave grew by more than THR = 8 ?
+    D = ["s_nop 3", "s_cmp_lg_u64 %[cnd], 0", f"s_cbranch_scc0 .Lkeep{uid}_%="]
+    for qb in range(2):
+        D.append(f"v_max_f32 v{DELTA + qb}, 0, v{MX + qb}")
+    for qb in range(2):
+        D.append(f"v_exp_f32 v{ALPHA + qb}, -v{DELTA + qb}")
+    for qb in range(2):
+        D.append(f"v_sub_f32 {NM(qb, 0)}, {NM(qb, 0)}, v{DELTA + qb}")
+        D += [f"v_mov_b32 {NM(qb, r)}, {NM(qb, 0)}" for r in range(1, 16)]
+    D += subs
+    D += [f"v_mul_f32 v{LSUM + 2 * qb + k}, v{LSUM + 2 * qb + k}, v{ALPHA + qb}" for qb in range(2) for k in range(2)]
+    D += ["s_mov_b32 %[fl], 1", "s_nop 1", f".Lkeep{uid}_%=:"]
+    L.append(D)       # a list element stays contiguous (the branch must not skip interleaved MFMAs / reads)
+    return L
+
+
+def softmax_pass2(st):
+    """p = exp2(s'); row sums; bf16 pairs -> P fragment (sub-tile u, k-step kt) = registers 8kt .. 8kt+7 of S[u].  The steps of a value
+    run as a software pipeline -- exp(k), add(k - 2), cvt of the pair behind (k - 3) -- which also spreads the slower exponentials
+    evenly over the MFMA gaps.  A conversion is tagged with its group g: it may only be issued behind the PV MFMAs that read P[g]."""
     seq = []
     for u in range(2):
         for kt in range(2):
             for qb in range(2):
                 for k in range(8):
-                    seq.append((S(st, u, qb, kt * 8 + k), qb, P(st, u, kt, qb, k // 2) if k & 1 else None, S(st, u, qb, kt * 8 + k - 1) if k & 1 else None))
+                    seq.append((S(st, u, qb, kt * 8 + k), qb, u * 2 + kt, P(u, kt, qb, k // 2) if k & 1 else None,
+                                S(st, u, qb, kt * 8 + k - 1) if k & 1 else None))
+    L = []
     n = len(seq)
-    for k in range(n + 4):
+    for k in range(n + 3):
         if k < n:
-            L.append(f"v_fma_f32 {seq[k][0]}, {seq[k][0]}, %[sc], -v{M_USE + seq[k][1]}")
+            L.append(f"v_exp_f32 {seq[k][0]}, {seq[k][0]}")
         if 0 <= k - 2 < n:
-            L.append(f"v_exp_f32 {seq[k - 2][0]}, {seq[k - 2][0]}")
-        if 0 <= k - 4 < n and seq[k - 4][2] is not None:
-            L.append(f"v_cvt_pk_bf16_f32 {seq[k - 4][2]}, {seq[k - 4][3]}, {seq[k - 4][0]}")
-    return L
-
-
-def decide(uid):
-    """Scalar branch on the defer-max test.  Rare path: adopt the new maxima, alpha = exp2(m_old - m_new), scale l_run, raise the flag."""
-    L = ["s_nop 3", "s_cmp_lg_u64 %[cnd], 0", f"s_cbranch_scc0 .Lkeep{uid}_%="]
-    for qb in range(2):
-        L += [f"v_sub_f32 v{ALPHA + qb}, v{M_RUN + qb}, v{MX + qb}", f"v_mov_b32 v{M_RUN + qb}, v{MX + qb}"]
-    for qb in range(2):
-        L += [f"v_exp_f32 v{ALPHA + qb}, v{ALPHA + qb}"]
-    L += ["s_mov_b32 %[fl], 1", f".Lkeep{uid}_%=:"]
-    for qb in range(2):
-        L += [f"v_mov_b32 v{M_USE + qb}, v{M_RUN + qb}"]
+            e = seq[k - 2]
+            acc = LSUM + 2 * e[1] + ((k - 2) & 1)
+            L.append(f"v_add_f32 v{acc}, v{acc}, {e[0]}")
+        if 0 <= k - 3 < n and seq[k - 3][3] is not None:
+            e = seq[k - 3]
+            L.append(("CVT", e[2], f"v_cvt_pk_bf16_f32 {e[3]}, {e[4]}, {e[0]}"))
     return L
 
 
@@ -176,81 +192,66 @@ def o_rescale(uid):
                 L += [f"v_accvgpr_read_b32 {T(k)}, {O(db, qb, r0 + k)}" for k in range(4)]
                 L += [f"v_mul_f32 {T(k)}, {T(k)}, v{ALPHA + qb}" for k in range(4)]
                 L += [f"v_accvgpr_write_b32 {O(db, qb, r0 + k)}, {T(k)}" for k in range(4)]
-    for qb in range(2):
-        for r0 in range(0, 16, 4):
-            L += [f"v_accvgpr_read_b32 {T(k)}, {LS(qb, r0 + k)}" for k in range(4)]
-            L += [f"v_mul_f32 {T(k)}, {T(k)}, v{ALPHA + qb}" for k in range(4)]
-            L += [f"v_accvgpr_write_b32 {LS(qb, r0 + k)}, {T(k)}" for k in range(4)]
     L += ["s_mov_b32 %[fl], 0", "s_nop 3", f".Lnors{uid}_%=:"]
     return L
 
 
 # ------------------------------------------------------------------------------------------------ MFMA / LDS stream
 def unit_list(has_qk, has_pv):
-    """Fragment-sized units of an iteration, K and V units alternating.  ("K", ds, u): S[u][qb] += K(u, ds) Q[qb][ds];
-    ("V", g, db) with g = (u, kt): O[db][qb] += V^T(db, u, kt) P[u][kt][qb]."""
+    """Fragment-sized units of an iteration.  ("K", ds, u): S[u][qb] += K(u, ds) Q[qb][ds]; ("V", g, db) with g = (u, kt):
+    O[db][qb] += V^T(db, u, kt) P[u][kt][qb].  The PV units come EARLY (P(i-1) is complete when the iteration starts, and its
+    registers are wanted back for P(i)); the QK units late (the first of them reads NEGM, which the defer-max decision may change)."""
     ku = [("K", ds, u) for ds in range(8) for u in range(2)] if has_qk else []
     vu = [("V", g, db) for g in range(4) for db in range(4)] if has_pv else []
-    out = []
-    for i in range(16):
-        if ku:
-            out.append(ku[i])
-        if vu:
-            out.append(vu[i])
-            if i % 4 == 3:
-                out.append(("L", i // 4, 0))   # L[qb] += ones x P^T(u, kt): no fragment to read
-    return out
+    if not (ku and vu):
+        return ku + vu
+    out = vu[:8]
+    for i in range(8):
+        out += [vu[8 + i], ku[i]]
+    return out + ku[8:]
 
 
-def frag_read(unit, slot):
+def frag_read(unit, slot, par):
+    """`par`: ring slot of the tile (K and V^T rings are two slots of 16 KiB: the slot is an immediate, both parities are emitted)."""
     kind, a, b = unit
-    assert kind != "L"
     if kind == "K":   # d-step ds = a (address register per ds: the swizzle is an XOR), sub-tile u = b (+ 32 rows x 256 B)
-        return f"ds_read_b128 {F(slot)}, %[ka{a}]" + (f" offset:{b * 8192}" if b else "")
-    return f"ds_read_b128 {F(slot)}, %[va{a}]" + (f" offset:{b * 4096}" if b else "")   # (u, kt) = a, d-block db = b (+ 32 rows x 128 B)
+        return f"ds_read_b128 {F(slot)}, %[ka{a}] offset:{b * 8192 + par * 0x4000}"
+    return f"ds_read_b128 {F(slot)}, %[va{a}] offset:{b * 4096 + par * 0x4000}"   # (u, kt) = a, d-block db = b (+ 32 rows x 128 B)
 
 
-def unit_mfmas(unit, slot, s_dst, p_src):
+def unit_mfmas(unit, slot, s_dst, c_init):
     kind, a, b = unit
     if kind == "K":
         ds, u = a, b
-        return [f"v_mfma_f32_32x32x16_bf16 {S(s_dst, u, qb)}, {F(slot)}, {Q(qb, ds)}, " + ("0" if ds == 0 else S(s_dst, u, qb)) for qb in range(2)]
-    if kind == "L":
-        g = a
-        return [f"v_mfma_f32_32x32x16_bf16 {LS(qb)}, v[{ONES}:{ONES + 3}], {P(p_src, g >> 1, g & 1, qb)}, {LS(qb)}" for qb in range(2)]
+        return [f"v_mfma_f32_32x32x16_bf16 {S(s_dst, u, qb)}, {F(slot)}, {Q(qb, ds)}, " +
+                ((NM(qb) if c_init else "0") if ds == 0 else S(s_dst, u, qb)) for qb in range(2)]
     g, db = a, b
-    return [f"v_mfma_f32_32x32x16_bf16 {O(db, qb)}, {F(slot)}, {P(p_src, g >> 1, g & 1, qb)}, {O(db, qb)}" for qb in range(2)]
+    return [f"v_mfma_f32_32x32x16_bf16 {O(db, qb)}, {F(slot)}, {P(g >> 1, g & 1, qb)}, {O(db, qb)}" for qb in range(2)]
 
 
 def sync_wait():
     """Ring hand-over, part 1: every fragment read of this iteration has been issued (and had time to return) above.  Wait for them
-    and for this wave's pieces of the tiles the NEXT iteration reads, barrier; the slots this iteration read are free: flip the
-    fragment addresses to the other slots."""
-    L = ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
-    if os.environ.get("X2I_ATTN_ABL") == "nobar":      # measurement only (wrong results): what the per-tile barrier costs
-        L = ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
-    if os.environ.get("X2I_ATTN_ABL") == "nosync":     # measurement only: neither the waits nor the barrier
-        L = []
-    L += [f"v_xor_b32 %[ka{ds}], 0x4000, %[ka{ds}]" for ds in range(8)]
-    L += [f"v_xor_b32 %[va{g}], 0x4000, %[va{g}]" for g in range(4)]
-    return L
+    and for this wave's pieces of the tiles the NEXT iteration reads, barrier; the slots this iteration read are free."""
+    if ABL == "nosync":
+        return []
+    return ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ([] if ABL == "nobar" else ["s_barrier"])
 
 
-def sync_dma():
-    """Part 2, as (M0 write, piece) pairs to be spread between the iteration's last MFMAs: K(tile %[tk]) / V(tile %[tv]) into the freed
-    slots.  Unconditional: behind the last tile the pieces read rows at or past the sequence end (zero rows / zero fill past the
-    buffer end), are never consumed, and cost three tiles per workgroup."""
-    pre = ["s_lshl_b32 %[so], %[tk], 14", "s_lshl_b32 %[so2], %[tv], 7"]     # 64 keys x 256 B per K tile; 64 keys x 2 B per V^T row
-    pairs = [(f"s_add_u32 m0, %[kdst], {j * 4096}", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds") for j in range(4)]
-    pairs += [(f"s_add_u32 m0, %[vdst], {j * 4096}", f"buffer_load_dwordx4 %[vd{j}], %[vr], %[so2] offen lds") for j in range(4)]
-    post = ["s_xor_b32 %[kdst], %[kdst], 0x4000", "s_xor_b32 %[vdst], %[vdst], 0x4000", "s_add_u32 %[tk], %[tk], 1", "s_add_u32 %[tv], %[tv], 1"]
-    return pre, pairs, post
+def sync_dma(par):
+    """Part 2, as (M0 write, piece) pairs to be spread between the iteration's last MFMAs: the next K tile (%[so] = its byte offset) and
+    the next V^T tile (%[so2]) into ring slot `par`, the one this iteration read.  Unconditional: behind the last tile the pieces read
+    rows at or past the sequence end (zero rows / zero fill past the buffer end), are never consumed, and cost three tiles per
+    workgroup."""
+    pairs = [(f"s_add_u32 m0, %[kdst], {par * 0x4000 + j * 4096}", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds") for j in range(4)]
+    pairs += [(f"s_add_u32 m0, %[vdst], {par * 0x4000 + j * 4096}", f"buffer_load_dwordx4 %[vd{j}], %[vr], %[so2] offen lds") for j in range(4)]
+    post = ["s_add_u32 %[so], %[so], 0x4000", "s_add_u32 %[so2], %[so2], 128"]   # 64 keys x 256 B per K tile; 64 keys x 2 B per V^T row
+    return pairs, post
 
 
-def sync_block(uid):
+def sync_block(par):
     """The whole hand-over without MFMAs to hide it (prologue only)."""
-    pre, pairs, post = sync_dma()
-    L = sync_wait() + pre
+    pairs, post = sync_dma(par)
+    L = sync_wait()
     for m0, ld in pairs:
         L += [m0, "s_nop 0", ld]
     return L + post
@@ -262,116 +263,131 @@ VALU_DELAY = 4      # MFMAs at the head of an iteration that carry no softmax in
 
 
 class Stream:
-    """Fragment bookkeeping of one unit list: ring slots are dealt to the units that read a fragment, in order; reads are issued
-    ahead of their use and a use waits with lgkmcnt(number of younger reads)."""
+    """Fragment bookkeeping of one unit list: ring slots are dealt to the units in order; reads are issued ahead of their use, and
+    the uses wait in PAIRS (the even fragment waits for itself and its successor: one s_waitcnt per four MFMAs)."""
 
-    def __init__(self, us, preread):
-        self.us = us
-        self.fidx = []
-        f = 0
-        for u in us:
-            self.fidx.append(f if u[0] != "L" else None)
-            f += u[0] != "L"
-        self.nfrag = f
-        self.q = [i for i in range(min(preread, f))]     # outstanding reads (fragment indices), oldest first
-        self.next = min(preread, f)                      # next fragment index to read
-        self.funits = [k for k, u in enumerate(us) if u[0] != "L"]
+    def __init__(self, us, preread, par):
+        self.us, self.par = us, par
+        self.q = list(range(min(preread, len(us))))      # outstanding reads (unit indices), oldest first
+        self.next = min(preread, len(us))                # next unit to read
 
     def read_upto_unit(self, L, unit_limit):
-        """issue the reads of every fragment unit with unit index < unit_limit"""
-        while self.next < self.nfrag and self.funits[self.next] < unit_limit:
-            L.append(frag_read(self.us[self.funits[self.next]], self.next))
+        while self.next < min(unit_limit, len(self.us)):
+            L.append(frag_read(self.us[self.next], self.next, self.par))
             self.q.append(self.next)
             self.next += 1
+            assert len(self.q) <= 15
 
     def wait(self, L, k):
-        f = self.fidx[k]
-        if f is not None and f in self.q:
-            pos = self.q.index(f)
-            if os.environ.get("X2I_ATTN_ABL") != "nolgk":   # (measurement only: no waits on the fragment reads)
-                L.append(f"s_waitcnt lgkmcnt({len(self.q) - 1 - pos})")
-            self.q = self.q[pos + 1:]
+        if k not in self.q:
+            return
+        assert self.next > k
+        tgt = k + 1 if (k % 2 == 0 and (k + 1) in self.q) else k
+        pos = self.q.index(tgt)
+        if ABL != "nolgk":
+            L.append(f"s_waitcnt lgkmcnt({len(self.q) - 1 - pos})")
+        self.q = self.q[pos + 1:]
 
-    def mfmas(self, k, s_dst, p_src):
-        return unit_mfmas(self.us[k], self.fidx[k] if self.fidx[k] is not None else 0, s_dst, p_src)
+    def mfmas(self, k, s_dst, c_init):
+        return unit_mfmas(self.us[k], k, s_dst, c_init)
 
 
-def prereads(kind):
+def prereads(kind, par):
     us = unit_list(*kind)
-    st = Stream(us, 0)
+    st = Stream(us, 0, par)
     L = []
-    st.read_upto_unit(L, st.funits[LEAD - 1] + 1 if st.nfrag >= LEAD else len(us))
+    st.read_upto_unit(L, LEAD)
     return L
 
 
-def iteration(st, has_qk, has_pv, softmax, masked, next_kinds):
-    """One pipelined iteration: softmax of score set `st`, S(next) into set st ^ 1, O += V P with P of set st ^ 1.  The first LEAD
-    fragments arrive pre-read (ring slots 0 .. LEAD-1).  The iteration ends with the ring hand-over and the pre-reads of the next
-    iteration; `next_kinds` = [(conditional, (has_qk, has_pv), label)]: the first entry is taken when %[cnt] == 0."""
+def iteration(st, has_qk, has_pv, masked, first, next_kinds):
+    """One pipelined iteration i (st = i & 1): softmax of score set `st`, S(i+1) into set st ^ 1, O += V(i-1) P(i-1).  K(i+1) and
+    V(i-1) sit in ring slot st ^ 1.  The first LEAD fragments arrive pre-read (ring slots 0 .. LEAD-1).  The iteration ends with the
+    ring hand-over and the pre-reads of the next iteration; `next_kinds` = [(conditional, (has_qk, has_pv), label)]: the first entry
+    is taken when %[cnt] == 0."""
     _uid[0] += 1
     uid = _uid[0]
     us = unit_list(has_qk, has_pv)
     n = len(us)
-    va = []   # elements: one instruction, or a list that must stay contiguous (a scalar branch and the code it jumps over)
-    for ins in (softmax_stream(st, masked) if softmax else []):
-        va.append(decide(uid) if isinstance(ins, tuple) else ins)
-    if os.environ.get("X2I_ATTN_ABL") == "novalu":      # measurement only: the MFMA / LDS / DMA stream alone
-        va = []
+    par = st ^ 1
+    p1 = softmax_pass1(st, masked, first, uid)
+    p2 = softmax_pass2(st)
     L = []
+    if first or n == 0:
+        # no MFMA can cover the first tile's maxima: S(1)'s first MFMAs read NEGM, which this pass writes
+        L += ["s_nop 15", "s_nop 15"] + [x for e in p1 for x in (e if isinstance(e, list) else [e])] + ["s_nop 1"]
+        p1 = []
+    va = p1 + p2
+    if ABL == "novalu":      # measurement only: the MFMA / LDS / DMA stream alone
+        va = []
+    decide_at = max([k for k, e in enumerate(va) if isinstance(e, list)], default=-1)
     vi = 0
+
+    def text(e):
+        return e[2] if isinstance(e, tuple) else e
 
     def cost(e):
         if isinstance(e, list):
-            return len(e)
-        return 4 if e.startswith("v_exp") else 1     # a transcendental occupies the VALU about four times as long
+            return 3 * min(len(e), 8)
+        return 5 if text(e).startswith("v_exp") else 3     # a transcendental issues at about 5/3 of a plain VALU
 
     total_cost = sum(cost(e) for e in va)
     spent = [0]
+    pv_left = {g: (4 if has_pv else 0) for g in range(4)}     # V units of group g not yet issued: P[g] may not be overwritten before
+
+    def emit_next():
+        nonlocal vi
+        e = va[vi]
+        if isinstance(e, tuple) and pv_left[e[1]] > 0:
+            return False
+        spent[0] += cost(e)
+        if isinstance(e, list):
+            L.extend(e)
+        else:
+            L.append(text(e))
+        vi += 1
+        return True
 
     def fill_to(target_cost):
-        nonlocal vi
         while vi < len(va) and spent[0] + cost(va[vi]) <= target_cost:
-            spent[0] += cost(va[vi])
-            if isinstance(va[vi], list):
-                L.extend(va[vi])
-            else:
-                L.append(va[vi])
-            vi += 1
+            if not emit_next():
+                break
 
-    def fill(count):
-        fill_to(10 ** 9) if count >= len(va) else None
     split = max(0, n - LEAD)              # units in front of the hand-over
+    if has_pv and not has_qk:
+        split = n                         # (last tile: every PV unit in front of it -- the conversions of P wait for their group's reads)
     early = max(0, split - 3)             # from this unit on, every remaining read of the iteration is issued at once: the hand-over's
                                           # lgkmcnt(0) then finds them returned instead of exposing one LDS round trip per iteration
     gaps = max(1, 2 * split - VALU_DELAY)
-    sm = Stream(us, LEAD)
+    sm = Stream(us, LEAD, par)
     mf = 0
     for k in range(split):
         sm.read_upto_unit(L, n if k >= early else k + LEAD + 1)
         sm.wait(L, k)
-        for m in sm.mfmas(k, st ^ 1, st ^ 1):
+        if us[k][0] == "K" and us[k][1] == 0 and not first:
+            while vi <= decide_at:        # the first QK^T MFMAs read NEGM: the defer-max decision must be behind us
+                assert emit_next()
+        for m in sm.mfmas(k, st ^ 1, True):
             L.append(m)
             mf += 1
             if mf > VALU_DELAY:
-                g = mf - VALU_DELAY          # spread the VALU stream evenly by issue time: g / G of its cost is out after gap g
-                fill_to(g * total_cost // gaps)
-    if n == 0:
-        L += ["s_nop 15", "s_nop 15"]       # (no MFMA cover at all: the scores come from the prologue's last MFMAs)
-    fill(len(va))
+                fill_to((mf - VALU_DELAY) * total_cost // gaps)    # spread the VALU stream evenly by issue time
+        if us[k][0] == "V":
+            pv_left[us[k][1]] -= 1
+    assert all(v == 0 for v in pv_left.values()), "PV units behind the hand-over"
+    while vi < len(va):
+        assert emit_next(), "a P group is still being read"
     sm.read_upto_unit(L, n)
-    assert vi == len(va) and sm.next == sm.nfrag
     for ci, (cond, nxt, label) in enumerate(next_kinds):
         if cond:
             L += ["s_cmp_lg_u32 %[cnt], 0", f"s_cbranch_scc1 .Lalt{uid}_%="]
         L += sync_wait()                    # (lgkmcnt(0) inside: every fragment of this iteration is in registers)
-        L += prereads(nxt)
-        pre, pairs, post = sync_dma()
-        L += pre
-        tail_m = [m for k in range(split, n) for m in sm.mfmas(k, st ^ 1, st ^ 1)]
+        L += prereads(nxt, st)              # the next iteration reads ring slot st
+        pairs, post = sync_dma(par)
+        tail_m = [m for k in range(split, n) for m in sm.mfmas(k, st ^ 1, True)]
         # pieces between the remaining MFMAs: M0 write, an MFMA (or a nop) in between, the piece
         pi = 0
-        if pairs:
-            L.append(pairs[0][0])
+        L.append(pairs[0][0])
         for mi, m in enumerate(tail_m):
             L.append(m)
             share = (mi + 1) * len(pairs) // max(1, len(tail_m)) - pi
@@ -390,44 +406,39 @@ def iteration(st, has_qk, has_pv, softmax, masked, next_kinds):
         L += post
         if has_pv:
             L += o_rescale(f"{uid}x{ci}")
-        else:
-            L += ["s_mov_b32 %[fl], 0"]     # O is still zero (first tile): nothing to rescale, and alpha(0) = 0 must never reach it
         L.append(f"s_branch {label}")
         if cond:
             L.append(f".Lalt{uid}_%=:")
     return L
 
 
-def solo(kind, s_dst, p_src, preread):
-    """A unit list on its own (prologue S(0), tail PV): reads LEAD ahead, no VALU stream."""
+def solo(kind, s_dst, par, preread):
+    """A unit list on its own (prologue S(0) with C = 0, tail PV): reads LEAD ahead, no VALU stream."""
     us = unit_list(*kind)
-    sm = Stream(us, LEAD if preread else 0)
+    sm = Stream(us, LEAD if preread else 0, par)
     L = []
     if not preread:
-        sm.read_upto_unit(L, sm.funits[LEAD - 1] + 1)
+        sm.read_upto_unit(L, LEAD)
     for k in range(len(us)):
         sm.read_upto_unit(L, k + LEAD + 1)
         sm.wait(L, k)
-        L += sm.mfmas(k, s_dst, p_src)
+        L += sm.mfmas(k, s_dst, False)
     return L
 
 
 def prologue():
     L = ["s_nop 4", f"v_mov_b32 v{NEGBIG}, {NEG_BIG}"]
     for qb in range(2):
-        L += [f"v_mov_b32 v{M_RUN + qb}, {NEG_BIG}", f"v_mov_b32 v{L_RUN + qb}, 0", f"v_mov_b32 v{M_USE + qb}, {NEG_BIG}",
-              f"v_mov_b32 v{ALPHA + qb}, 1.0"]
+        L += [f"v_mov_b32 v{ALPHA + qb}, 1.0"]
     L += ["s_mov_b32 %[fl], 0"]
     for db in range(4):
         for qb in range(2):
             L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(16)]
-    for qb in range(2):
-        L += [f"v_accvgpr_write_b32 {LS(qb, r)}, 0" for r in range(16)]
-    L += [f"v_mov_b32 v{ONES + k}, 0x3f803f80" for k in range(4)]
-    # Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + 32 qb + li][16 ds + 8 hi .. + 8], loaded straight into the accumulator file
+    # Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + 32 qb + li][16 ds + 8 hi .. + 8]
     for qb in range(2):
         for ds in range(8):
-            L.append(f"global_load_dwordx4 {Q(qb, ds)}, %[qo{qb}], %[qp] offset:{ds * 32}")
+            b = QTMP + (qb * 8 + ds) * 4
+            L.append(f"global_load_dwordx4 v[{b}:{b + 3}], %[qo{qb}], %[qp] offset:{ds * 32}")
     # K(0) -> slot 0, K(1) -> slot 1 (rows behind Spad read as zero)
     L += ["s_mov_b32 %[so], 0"]
     for j in range(4):
@@ -435,8 +446,20 @@ def prologue():
     L += ["s_mov_b32 %[so], 0x4000"]
     for j in range(4):
         L += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
-    L += ["s_mov_b32 %[tk], 2", "s_mov_b32 %[tv], 0", "s_waitcnt vmcnt(0)", "s_barrier"]
-    # S(0) = K(0) Q^T alone (score set 0)
+    L += ["s_mov_b32 %[so], 0x8000", "s_mov_b32 %[so2], 0"]
+    # under the K flight: Q fragments into the accumulator file.  %[pres] == 0: Q already carries scale * log2 e (x2i_qkv_desc.q_scale:
+    # applied in f32 by the producing epilogue); otherwise Q~ = bf16(Q * scale * log2 e) here (a second rounding of Q).  Either way
+    # the softmax needs no multiply: p = exp2(s') with s' = q~ . k - m
+    L += ["s_waitcnt vmcnt(8)", "s_cmp_lg_u32 %[pres], 0", "s_cbranch_scc1 .Lpres_%="]
+    L += [f"v_accvgpr_write_b32 a{QF + i}, v{QTMP + i}" for i in range(64)]
+    L += ["s_branch .Lqdone_%=", ".Lpres_%=:"]
+    for i in range(64):
+        L += [f"v_lshlrev_b32 {T(0)}, 16, v{QTMP + i}", f"v_and_b32 {T(1)}, 0xffff0000, v{QTMP + i}",
+              f"v_mul_f32 {T(0)}, %[sc], {T(0)}", f"v_mul_f32 {T(1)}, %[sc], {T(1)}",
+              f"v_cvt_pk_bf16_f32 {T(0)}, {T(0)}, {T(1)}", f"v_accvgpr_write_b32 a{QF + i}, {T(0)}"]
+    L += [".Lqdone_%=:"]
+    L += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    # S(0) = K(0) Q~^T alone (score set 0, raw: the first softmax subtracts its maxima itself)
     L += solo((True, False), 0, 0, False)
     return L
 
@@ -445,17 +468,24 @@ def epilogue():
     """O[q][d] = O^T[d][q] / l: lane (q = li, hi) holds d = 32 db + 8 (r >> 2) + 4 hi + (r & 3); a half-wave exchange turns two 8-byte
     fragments of neighbouring d-groups into one 16-byte store (as attention.hip); log2-sum-exp rows on request."""
     L = ["s_nop 15", "s_nop 15"]
-    for qb in range(2):   # row sums: every L register of a lane holds the sum over ALL keys of its query row (both half-waves fed the MFMA)
-        L += [f"v_accvgpr_read_b32 v{L_RUN + qb}, {LS(qb, 0)}"]
+    for qb in range(2):   # row sums: two accumulators, and the other 32 keys of every tile were summed by lane ^ 32
+        L += [f"v_add_f32 v{LSUM + 2 * qb}, v{LSUM + 2 * qb}, v{LSUM + 2 * qb + 1}"]
     for qb in range(2):
-        L += [f"v_rcp_f32 v{PSUM + qb}, v{L_RUN + qb}"]
+        L += [f"v_mov_b32 v{MX2 + qb}, v{LSUM + 2 * qb}"]
+    L += ["s_nop 1"]
+    for qb in range(2):
+        L += [f"v_permlane32_swap_b32 v{LSUM + 2 * qb}, v{MX2 + qb}"]
+    for qb in range(2):
+        L += [f"v_add_f32 v{MX + qb}, v{LSUM + 2 * qb}, v{MX2 + qb}"]
+    for qb in range(2):
+        L += [f"v_rcp_f32 v{ALPHA + qb}, v{MX + qb}"]
     # log2-sum-exp (x2i_attention_lse_bf16): m_run + log2(l) for q < S, +1e30 on the padding rows; lanes of the low half store
     L += ["s_cmp_lg_u32 %[lsef], 0", "s_cbranch_scc0 .Lnolse_%="]
     for qb in range(2):
-        L += [f"v_log_f32 {T(4 + qb)}, v{L_RUN + qb}"]
+        L += [f"v_log_f32 {T(4 + qb)}, v{MX + qb}"]
     L += ["s_nop 1"]
     for qb in range(2):
-        L += [f"v_add_f32 {T(4 + qb)}, {T(4 + qb)}, v{M_RUN + qb}",
+        L += [f"v_sub_f32 {T(4 + qb)}, {T(4 + qb)}, {NM(qb, 0)}",
               f"v_add_u32 {T(6)}, {32 * qb}, %[qv]",
               f"v_cmp_gt_i32 vcc, %[sS], {T(6)}",                          # q < S
               f"v_mov_b32 {T(7)}, 0x7149f2ca",                             # 1.0e30f
@@ -473,7 +503,7 @@ def epilogue():
         for db in range(4):
             for g in (0, 2):
                 L += [f"v_accvgpr_read_b32 {T(k)}, {O(db, qb, 4 * g + k)}" for k in range(8)]
-                L += [f"v_mul_f32 {T(k)}, {T(k)}, v{PSUM + qb}" for k in range(8)]
+                L += [f"v_mul_f32 {T(k)}, {T(k)}, v{ALPHA + qb}" for k in range(8)]
                 L += [f"v_cvt_pk_bf16_f32 {T(8)}, {T(0)}, {T(1)}", f"v_cvt_pk_bf16_f32 {T(9)}, {T(2)}, {T(3)}",
                       f"v_cvt_pk_bf16_f32 {T(10)}, {T(4)}, {T(5)}", f"v_cvt_pk_bf16_f32 {T(11)}, {T(6)}, {T(7)}", "s_nop 1",
                       f"v_permlane32_swap_b32 {T(8)}, {T(10)}", f"v_permlane32_swap_b32 {T(9)}, {T(11)}", "s_nop 1",
@@ -494,18 +524,18 @@ def build():
     L = prologue()
     MIDK, LASTK, TAILK = (True, True), (False, True), (False, True)
     # hand-over behind S(0): frees K slot 0, fetches K(2) / V(0); the fragment addresses now point at the slots of tile 1
-    L += sync_block("p0")
+    L += sync_block(0)
     L += ["s_cmp_eq_u32 %[nt], 1", "s_cbranch_scc1 .Lonly_%="]
-    L += prereads((True, False))
+    L += prereads((True, False), 1)
     # FIRST (score set 0): successor LAST(set 1) when nt == 2 (%[cnt] == 0), else MID(set 1)
-    L += iteration(0, True, False, True, False, [(True, LASTK, ".Llast1_%="), (False, MIDK, ".Lmid1_%=")])
+    L += iteration(0, True, False, False, True, [(True, LASTK, ".Llast1_%="), (False, MIDK, ".Lmid1_%=")])
     for par in (1, 0):
         o = par ^ 1
         L += [f".Lmid{par}_%=:", "s_sub_u32 %[cnt], %[cnt], 1"]
-        L += iteration(par, True, True, True, False, [(True, LASTK, f".Llast{o}_%="), (False, MIDK, f".Lmid{o}_%=")])
+        L += iteration(par, True, True, False, False, [(True, LASTK, f".Llast{o}_%="), (False, MIDK, f".Lmid{o}_%=")])
     for par in (1, 0):
         L += [f".Llast{par}_%=:"]
-        L += iteration(par, False, True, True, True, [(False, TAILK, f".Ltail{par}_%=")])
+        L += iteration(par, False, True, True, False, [(False, TAILK, f".Ltail{par}_%=")])
     # ONLY (nt == 1): softmax(0) masked, then the hand-over that waits for V(0)
     L += [".Lonly_%=:"]
     L += iteration(0, False, False, True, True, [(False, TAILK, ".Ltail0_%=")])
@@ -519,7 +549,7 @@ def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "attn_w4_loop.inc")
     L = build()
     txt = ["// GENERATED by gen_attn_w4.py -- do not edit; register map and schedule live in the generator.",
-           f"// register map: scores v{SA}..v{SA + 127}, P fragments v{PF}..v{PF + 63}, softmax state up to v{_v - 1};"
+           f"// register map: scores v{SA}..v{SA + 127}, P fragments v{PF}..v{PF + 31}, -max copies v{NEGM}..v{NEGM + 31}, softmax state up to v{_v - 1};"
            f" O a{OA}..a{OA + 127}, Q fragments a{QF}..a{QF + 63}, fragment ring a{FR}..a{FR + RING * 4 - 1}",
            f"// {len(L)} lines", "#define X2I_ATTN_W4_TEXT \\"]
     txt += [f'  "{l}\\n" \\' for l in L[:-1]]

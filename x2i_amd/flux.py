@@ -382,6 +382,10 @@ class FluxTransformer2DModel(nn.Module):
         fuse_qkv = self.fuse_qkv and D % 64 == 0
         fp8 = self._fp8
         fp8_all = fp8 is not None and self._fp8_mode == "all"
+        # with the fused QKV epilogues, softmax_scale * log2(e) rides in Q (one f32 multiply in front of the epilogue's bf16 rounding,
+        # x2i_qkv_desc.q_scale) and the attention kernels get scale = ln 2: their inner loops lose the score multiply
+        qs = scale * 1.4426950408889634 if (fuse_qkv or fp8_all) else 1.0
+        scale = scale / qs if qs != 1.0 else scale
         # forward hooks on block.attn (attention-distillation capture): materialise the attention outputs of every block
         taps = any(len(b.attn._forward_hooks) for b in self.transformer_blocks) or \
             any(len(b.attn._forward_hooks) for b in self.single_transformer_blocks)
@@ -403,9 +407,9 @@ class FluxTransformer2DModel(nn.Module):
                 wq, sq = fp8[p + ".qkv"]
                 ops.gemm_qkv_fp8(ws["NRM8"], wq, f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=Si, H=H,
                                  Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
-                                 a_scale=ws["RS"], a_scale_batch_stride=Si, w_scale=sq)
+                                 a_scale=ws["RS"], a_scale_batch_stride=Si, w_scale=sq, q_scale=qs)
                 ops.gemm_qkv(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], Q, K, VT, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
-                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D)
+                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D, q_scale=qs)
             else:
                 ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
             if fp8_all:
@@ -414,9 +418,9 @@ class FluxTransformer2DModel(nn.Module):
                 # q/k RMSNorm + RoPE + head split + V transpose ride in the QKV GEMM's epilogue (no [B*S, 3D] round trip)
                 ops.gemm_qkv(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
                              M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
-                             a_offset=St * D)
+                             a_offset=St * D, q_scale=qs)
                 ops.gemm_qkv(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], Q, K, VT, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
-                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D)
+                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D, q_scale=qs)
             else:
                 ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=QKV, M=Si, batch=B, a_batch_stride=S * D, lda=D,
                          a_offset=St * D, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
@@ -501,10 +505,10 @@ class FluxTransformer2DModel(nn.Module):
             if fp8_all:
                 wq, sq = fp8[p + ".qkv"]
                 ops.gemm_qkv_fp8(ws["NRM8"], wq, bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
-                                 Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=ws["RS"], w_scale=sq)
+                                 Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=ws["RS"], w_scale=sq, q_scale=qs)
             elif fuse_qkv:
                 ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
-                             Spad=Spad, tok_off=0, rows_per_sample=S)
+                             Spad=Spad, tok_off=0, rows_per_sample=S, q_scale=qs)
             else:
                 ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)
             if fp8 is None:

@@ -88,7 +88,7 @@ def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=No
 
 
 def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1, a_batch_stride=0,
-             lda=None, a_offset=0, eps=1e-6):
+             lda=None, a_offset=0, eps=1e-6, q_scale=1.0):
     """QKV projection with RMSNorm(q,k) + RoPE + head split + V transpose fused into the epilogue: rows of A (row m of batch
     item z = joint token tok_off + m % rows_per_sample of sample z + m // rows_per_sample) go straight to Q/K [B,H,Spad,128]
     and VT [B,H,128,Spad]; the [M, 3*H*128] product is never written (include/x2i.h: x2i_gemm_qkv_bf16)."""
@@ -111,7 +111,7 @@ def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_
     q = QkvDesc()
     q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
-    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps = H, Spad, tok_off, rows_per_sample, eps
+    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
     check(lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), _stream()), "gemm_qkv")
 
 
@@ -409,7 +409,7 @@ def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_
 
 
 def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1,
-                 a_batch_stride=0, lda=None, a_offset=0, a_scale=None, a_scale_batch_stride=0, w_scale=None, alpha=1.0, eps=1e-6):
+                 a_batch_stride=0, lda=None, a_offset=0, a_scale=None, a_scale_batch_stride=0, w_scale=None, alpha=1.0, eps=1e-6, q_scale=1.0):
     """gemm_qkv on e4m3 operands (include/x2i.h: x2i_gemm_qkv_fp8): dequantised accumulators, then the same fused epilogue."""
     lib = _lib.load()
     _req(A8, FP8, "A8")
@@ -434,7 +434,7 @@ def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     q = QkvDesc()
     q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
-    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps = H, Spad, tok_off, rows_per_sample, eps
+    q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
     check(lib.x2i_gemm_qkv_fp8(C.byref(a), C.byref(f), C.byref(q), _stream()), "gemm_qkv_fp8")
 
 
