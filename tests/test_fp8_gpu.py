@@ -115,9 +115,12 @@ def test_ln_modulate_fp8_matches_bf16_kernel_and_torch():
     ops.ln_modulate_fp8(Xd, None, Y8, rs, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)  # bf16 output optional
 
 
-def test_attention_e4m3_output_equals_quantised_bf16_output():
+@pytest.mark.parametrize("variant", [0, 9])
+def test_attention_e4m3_output_equals_quantised_bf16_output(variant):
+    """variant 9: the hand-scheduled kernel's e4m3 epilogue (16 consecutive bytes per lane), 0: the automatic choice at this size"""
     import math
-    from x2i_amd import ops
+    from x2i_amd import _lib, ops
+    _lib.load().x2i_set_option(b"attn_variant", variant)
     B, H, S = 2, 4, 600
     Spad = ops.pad128(S)
     g = torch.Generator(device=DEV).manual_seed(3)
@@ -134,6 +137,11 @@ def test_attention_e4m3_output_equals_quantised_bf16_output():
     assert rel_l2(b8, a) < 3e-2  # one e4m3 rounding apart
     # e4m3(fp32 result) vs e4m3(bf16(result)): identical except where the bf16 rounding crosses an e4m3 boundary
     assert (b8 != a.to(FP8).float()).float().mean() < 0.03
+    # a static output scale that saturates: sat(o * 2000) clamps at +-448
+    ops.attention_e4m3out(Q, K, VT, O8, B, H, S, Spad, ld, S * ld, 1 / math.sqrt(128), out_inv_scale=2000.0)
+    want = (a * 2000).clamp(-448, 448)
+    assert float(O8.float().abs().max()) == 448.0 and rel_l2(O8[..., :H * 128].float(), want) < 3e-2
+    _lib.load().x2i_set_option(b"attn_variant", 0)
 
 
 @pytest.mark.parametrize("B,H,St,Si", [(2, 2, 256, 1024), (1, 4, 0, 1500), (2, 2, 200, 700)])

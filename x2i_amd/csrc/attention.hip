@@ -326,8 +326,8 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   // sequences long enough to fill the chip with 256-row workgroups and a Q that already carries the scale: the hand-scheduled
   // one-wave-per-SIMD kernel (attention_w4.hip), whose softmax has no multiply.  Variant 9 forces it for any scale (the kernel then
   // rescales its bf16 Q fragments itself, at the price of a second rounding of Q); 5..8 select the 8-wave ping-pong kernel
-  if (!out8 && ((var == 0 && unit && (long long)((S + 255) / 256) * H * B >= 256) || var == 9)) {
-    const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse);
+  if ((var == 0 && unit && (long long)((S + 255) / 256) * H * B >= 256) || var == 9) {
+    const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse, out8, oinv);
     if (rc != X2I_ERR_STATE) return rc;
   }
   // the 8-wave ping-pong kernel (attention_pp.hip)

@@ -12,7 +12,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                       bf16_t* __restrict__ O, int H, int S, int Spad, int ldo, long long o_bs, float scale_log2,
-                                                      int nbatch, float* __restrict__ lse, int prescale) {
+                                                      int nbatch, float* __restrict__ lse, int prescale, int out8, float oinv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,14 +64,15 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
   const int q = q0 + li;
   const uint32_t qo0 = (uint32_t)(min(q, Spad - 1) * 128 + hi * 8) * 2u;        // rows at or behind S are never stored: clamp the read
   const uint32_t qo1 = (uint32_t)(min(q + 32, Spad - 1) * 128 + hi * 8) * 2u;
-  uint32_t oo = (uint32_t)(((long long)q * ldo + hi * 8) * 2);
+  // bf16: 16 bytes per lane and d-group pair (ldo in elements); e4m3: 16 bytes per lane and 32-wide d block (ldo in bytes)
+  uint32_t oo = out8 ? (uint32_t)((long long)q * ldo + hi * 16) : (uint32_t)(((long long)q * ldo + hi * 8) * 2);
   const uint32_t lo = (uint32_t)q * 4u;
-  const bf16_t* Ob = O + (long long)b * o_bs + h * 128;
+  const char* Ob = (const char*)O + ((long long)b * o_bs + h * 128) * (out8 ? 1 : 2);
   const float* Lb = lse ? lse + bh * Spad : nullptr;
   const int nt = (S + 63) / 64;
   const int lim = S - (nt - 1) * 64 - 8 * hi;
   uint32_t cnt = (uint32_t)(nt > 2 ? nt - 2 : 0);
-  const uint32_t ostep = (uint32_t)ldo * 64u;  // 32 rows
+  const uint32_t ostep = (uint32_t)ldo * (out8 ? 32u : 64u);  // 32 rows
   // (integer arithmetic, not a comparison: an i1 would be materialised in a VGPR and cannot feed an "s" operand)
   const uint32_t lsef = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)lse >> 32) | (uint32_t)(uintptr_t)lse);
   const float thr = 8.0f;  // defer-max threshold, exp2 domain (as attention.hip)
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
                  [ka7] "v"(ka[7]), [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]), [kd0] "v"(kd[0]), [kd1] "v"(kd[1]), [kd2] "v"(kd[2]), [kd3] "v"(kd[3]), [vd0] "v"(vd[0]), [vd1] "v"(vd[1]), [vd2] "v"(vd[2]),
                  [vd3] "v"(vd[3]), [kdst] "s"(kdst), [vdst] "s"(vdst), [qo0] "v"(qo0), [qo1] "v"(qo1), [lo] "v"(lo), [qv] "v"(q), [lim] "v"(lim), [hi] "v"(hi), [kr] "s"(k_rsrc),
                  [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2), [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt),
-                 [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale)
+                 [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale), [o8] "s"(out8), [oinv] "s"(oinv), [n448] "s"(-448.0f)
                : "memory", "vcc", "scc", X2I_ATTN_W4_CLOBBERS);
 }
 
@@ -92,12 +93,14 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
 
 // X2I_ERR_STATE: shape / alignment not served by this kernel (the caller falls back to the other forms)
 int x2i_launch_attention_w4(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
-                            float scale_log2, int prescale, hipStream_t stream, float* lse) {
-  if ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7) || (long long)S * ldo * 2 >= 0x7f000000LL) return X2I_ERR_STATE;
+                            float scale_log2, int prescale, hipStream_t stream, float* lse, int out8, float oinv) {
+  // 16-byte row stores; 32-bit store offsets.  (ldo / o_bs: elements for bf16, bytes for e4m3)
+  if ((((uintptr_t)O) & 15) || (ldo & (out8 ? 15 : 7)) || (o_bs & (out8 ? 15 : 7)) || (long long)S * ldo * (out8 ? 1 : 2) >= 0x7f000000LL)
+    return X2I_ERR_STATE;
   const int rc = x2i_ensure_dynamic_smem((const void*)attn_w4_kernel, 65536);
   if (rc) return rc;
   dim3 grid(((S + 255) / 256) * H * B);
   hipLaunchKernelGGL(attn_w4_kernel, grid, dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S,
-                     Spad, ldo, o_bs, scale_log2, B, lse, prescale);
+                     Spad, ldo, o_bs, scale_log2, B, lse, prescale, out8, oinv);
   return x2i_check_launch("attention");
 }

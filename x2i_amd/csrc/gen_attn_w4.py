@@ -26,7 +26,9 @@ import sys
 LEAD = int(os.environ.get("X2I_ATTN_LEAD", "4"))   # fragment reads are issued this many units (= one fragment, two MFMAs) ahead of their use
 RING = 16           # fragment ring slots (4 accumulator registers each)
 NEG_BIG = "0xf149f2ca"   # -1.0e30f
-ABL = os.environ.get("X2I_ATTN_ABL", "")            # measurement only (tools/r03_attn_abl.sh): nobar / nosync / nolgk / novalu give wrong results
+ABL = os.environ.get("X2I_ATTN_ABL", "")
+if ABL == "none":
+    ABL = ""            # measurement only (tools/r03_attn_abl.sh): nobar / nosync / nolgk / novalu give wrong results
 
 # ------------------------------------------------------------------------------------------------ register map
 _v, _a = 32, 0      # v0..v31 belong to the statement's operands
@@ -258,7 +260,7 @@ def sync_block(par):
 
 
 _uid = [0]
-VALU_DELAY = 4      # MFMAs at the head of an iteration that carry no softmax instruction: the scores the softmax reads were written by the
+VALU_DELAY = int(os.environ.get("X2I_ATTN_VDELAY", "4"))      # MFMAs at the head of an iteration that carry no softmax instruction: the scores the softmax reads were written by the
                     # previous iteration's last MFMAs, and nothing interlocks a VALU read against an MFMA still in the pipe
 
 
@@ -300,7 +302,54 @@ def prereads(kind, par):
     return L
 
 
+def issue_cost(line):
+    """Relative issue time of one instruction beside the MFMAs (plain VALU = 3)."""
+    op = line.split()[0]
+    if op.startswith("v_exp"):
+        return 5          # a transcendental issues at about 5/3 of a plain VALU
+    if op.endswith(":") or op == "s_nop":
+        return 0
+    if op.startswith("s_"):
+        return 2
+    return 3
+
+
 def iteration(st, has_qk, has_pv, masked, first, next_kinds):
+    """The iteration with its softmax stream BALANCED against everything else the gaps carry: a dry run without the softmax gives
+    the issue time of the reads / waits / DMA pieces behind each MFMA; the VALU stream then fills every gap up to a common level
+    (water-filling), so that no gap outlasts its MFMA while others idle."""
+    n2 = 2 * len(unit_list(has_qk, has_pv))
+    dry = _iteration(st, has_qk, has_pv, masked, first, next_kinds, None, True)
+    others, g = [0] * (n2 + 1), 0
+    for line in dry[0]:
+        if line.startswith("v_mfma"):
+            g += 1
+            if g > n2:
+                break
+        elif g:
+            others[g] += issue_cost(line)
+        if line.startswith("s_branch") and g == n2:
+            break
+    total = dry[1]
+    elig = [g for g in range(1, n2 + 1) if g > VALU_DELAY]
+    targets = None
+    if elig and total:
+        lo, hi = 0.0, float(total + max(others) + 1)
+        for _ in range(60):
+            c = (lo + hi) / 2
+            if sum(max(0.0, c - others[g]) for g in elig) < total:
+                lo = c
+            else:
+                hi = c
+        targets, acc = [0] * (n2 + 1), 0.0
+        for g in range(1, n2 + 1):
+            if g in elig:
+                acc += max(0.0, hi - others[g])
+            targets[g] = int(acc + 0.5)
+    return _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, False)[0]
+
+
+def _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, dry):
     """One pipelined iteration i (st = i & 1): softmax of score set `st`, S(i+1) into set st ^ 1, O += V(i-1) P(i-1).  K(i+1) and
     V(i-1) sit in ring slot st ^ 1.  The first LEAD fragments arrive pre-read (ring slots 0 .. LEAD-1).  The iteration ends with the
     ring hand-over and the pre-reads of the next iteration; `next_kinds` = [(conditional, (has_qk, has_pv), label)]: the first entry
@@ -318,7 +367,8 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
         L += ["s_nop 15", "s_nop 15"] + [x for e in p1 for x in (e if isinstance(e, list) else [e])] + ["s_nop 1"]
         p1 = []
     va = p1 + p2
-    if ABL == "novalu":      # measurement only: the MFMA / LDS / DMA stream alone
+    total_cost = sum(3 * min(len(e), 8) if isinstance(e, list) else issue_cost(e[2] if isinstance(e, tuple) else e) for e in va)
+    if ABL == "novalu" or dry:      # (novalu: measurement only: the MFMA / LDS / DMA stream alone)
         va = []
     decide_at = max([k for k, e in enumerate(va) if isinstance(e, list)], default=-1)
     vi = 0
@@ -327,11 +377,13 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
         return e[2] if isinstance(e, tuple) else e
 
     def cost(e):
-        if isinstance(e, list):
-            return 3 * min(len(e), 8)
-        return 5 if text(e).startswith("v_exp") else 3     # a transcendental issues at about 5/3 of a plain VALU
+        return 3 * min(len(e), 8) if isinstance(e, list) else issue_cost(text(e))
 
-    total_cost = sum(cost(e) for e in va)
+    def target(mf_):
+        if targets is not None:
+            return targets[min(mf_, len(targets) - 1)]
+        return (mf_ - VALU_DELAY) * total_cost // gaps
+
     spent = [0]
     pv_left = {g: (4 if has_pv else 0) for g in range(4)}     # V units of group g not yet issued: P[g] may not be overwritten before
 
@@ -358,7 +410,7 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
         split = n                         # (last tile: every PV unit in front of it -- the conversions of P wait for their group's reads)
     early = max(0, split - 3)             # from this unit on, every remaining read of the iteration is issued at once: the hand-over's
                                           # lgkmcnt(0) then finds them returned instead of exposing one LDS round trip per iteration
-    gaps = max(1, 2 * split - VALU_DELAY)
+    gaps = max(1, 2 * n - VALU_DELAY)     # the softmax stream runs over the whole iteration, the MFMAs behind the hand-over included
     sm = Stream(us, LEAD, par)
     mf = 0
     for k in range(split):
@@ -371,14 +423,14 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
             L.append(m)
             mf += 1
             if mf > VALU_DELAY:
-                fill_to((mf - VALU_DELAY) * total_cost // gaps)    # spread the VALU stream evenly by issue time
+                fill_to(target(mf))
         if us[k][0] == "V":
             pv_left[us[k][1]] -= 1
     assert all(v == 0 for v in pv_left.values()), "PV units behind the hand-over"
-    while vi < len(va):
-        assert emit_next(), "a P group is still being read"
     sm.read_upto_unit(L, n)
+    vi_split, spent_split, mf_split = vi, spent[0], mf
     for ci, (cond, nxt, label) in enumerate(next_kinds):
+        vi, spent[0], mf = vi_split, spent_split, mf_split       # (each successor's copy of the tail carries the same rest of the stream)
         if cond:
             L += ["s_cmp_lg_u32 %[cnt], 0", f"s_cbranch_scc1 .Lalt{uid}_%="]
         L += sync_wait()                    # (lgkmcnt(0) inside: every fragment of this iteration is in registers)
@@ -390,6 +442,8 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
         L.append(pairs[0][0])
         for mi, m in enumerate(tail_m):
             L.append(m)
+            mf += 1
+            fill_to(target(mf))
             share = (mi + 1) * len(pairs) // max(1, len(tail_m)) - pi
             for _ in range(share):
                 L.append(pairs[pi][1])
@@ -404,12 +458,14 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
             if pi < len(pairs):
                 L.append(pairs[pi][0])
         L += post
+        while vi < len(va):
+            assert emit_next(), "a P group is still being read"
         if has_pv:
             L += o_rescale(f"{uid}x{ci}")
         L.append(f"s_branch {label}")
         if cond:
             L.append(f".Lalt{uid}_%=:")
-    return L
+    return L, total_cost
 
 
 def solo(kind, s_dst, par, preread):
@@ -495,7 +551,7 @@ def epilogue():
               "s_nop 3", "s_and_b64 vcc, vcc, %[cnd]", "s_and_saveexec_b64 %[exs], vcc",
               f"global_store_dword %[lo], {T(4 + qb)}, %[lp] offset:{128 * qb}",
               "s_mov_b64 exec, %[exs]"]
-    L += [".Lnolse_%=:"]
+    L += [".Lnolse_%=:", "s_cmp_lg_u32 %[o8], 0", "s_cbranch_scc1 .Le4m3_%="]
     for qb in range(2):
         L += [f"v_add_u32 {T(8)}, {32 * qb}, %[qv]", f"v_cmp_gt_i32 vcc, %[sS], {T(8)}", "s_nop 3", "s_and_saveexec_b64 %[exs], vcc"]
         if qb == 1:
@@ -509,6 +565,28 @@ def epilogue():
                       f"v_permlane32_swap_b32 {T(8)}, {T(10)}", f"v_permlane32_swap_b32 {T(9)}, {T(11)}", "s_nop 1",
                       f"global_store_dwordx4 %[oo], v[{TMP + 8}:{TMP + 11}], %[op] offset:{db * 64 + g * 16}", "s_nop 1"]
         L += ["s_mov_b64 exec, %[exs]"]
+    L += ["s_branch .Ldone_%=", ".Le4m3_%=:"]
+    # e4m3 output (x2i_attention_e4m3out): sat(o / l * out_inv_scale); a lane's four 4-byte groups (d = 8 g + 4 hi + 0..3 of the
+    # 32-wide block) and its partner's become 16 consecutive bytes per lane: the low half stores d 0..15, the high half d 16..31
+    E = lambda i: f"v{SA + i}"       # (the score registers are free now)
+    L += [f"v_mov_b32 {E(24)}, 0x43e00000"]                                    # 448.0
+    for qb in range(2):
+        L += [f"v_mul_f32 v{ALPHA + qb}, %[oinv], v{ALPHA + qb}"]
+    for qb in range(2):
+        L += [f"v_add_u32 {T(8)}, {32 * qb}, %[qv]", f"v_cmp_gt_i32 vcc, %[sS], {T(8)}", "s_nop 3", "s_and_saveexec_b64 %[exs], vcc"]
+        if qb == 1:
+            L += [f"v_add_u32 %[oo], %[ostep], %[oo]"]
+        for db in range(4):
+            L += [f"v_accvgpr_read_b32 {E(k)}, {O(db, qb, k)}" for k in range(16)]
+            L += [f"v_mul_f32 {E(k)}, {E(k)}, v{ALPHA + qb}" for k in range(16)]
+            L += [f"v_med3_f32 {E(k)}, {E(k)}, %[n448], {E(24)}" for k in range(16)]
+            for g, r in ((0, 16), (2, 17), (1, 18), (3, 19)):                 # registers 16..19 = groups 0, 2, 1, 3
+                L += [f"v_cvt_pk_fp8_f32 {E(r)}, {E(4 * g)}, {E(4 * g + 1)}",
+                      f"v_cvt_pk_fp8_f32 {E(r)}, {E(4 * g + 2)}, {E(4 * g + 3)} op_sel:[0,0,1]"]
+            L += ["s_nop 1", f"v_permlane32_swap_b32 {E(16)}, {E(17)}", f"v_permlane32_swap_b32 {E(18)}, {E(19)}", "s_nop 1",
+                  f"global_store_dwordx4 %[oo], v[{SA + 16}:{SA + 19}], %[op] offset:{db * 32}", "s_nop 1"]
+        L += ["s_mov_b64 exec, %[exs]"]
+    L += [".Ldone_%=:"]
     L += ["s_waitcnt vmcnt(0)"]
     return L
 

@@ -24,7 +24,7 @@ int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* 
                             long long o_bs, float scale_log2, hipStream_t stream, int out8, float oinv, int thr, float* lse);
 // hand-scheduled one-wave-per-SIMD form (attention_w4.hip, generated K-tile loop); X2I_ERR_STATE = not served (alignment)
 int x2i_launch_attention_w4(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
-                            float scale_log2, int prescale, hipStream_t stream, float* lse);
+                            float scale_log2, int prescale, hipStream_t stream, float* lse, int out8, float oinv);
 int x2i_launch_qkv_split(const void* qkv0, const void* qkv1, int ld0, int ld1, int B, int S, int S0, int H,
                          const void* nq0, const void* nk0, const void* nq1, const void* nk1, const float* cosp,
                          const float* sinp, void* Q, void* K, void* VT, int Spad, float eps, hipStream_t stream);
