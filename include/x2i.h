@@ -49,8 +49,15 @@ const char* x2i_last_error(void);
 
 /* A/B and tuning switches.  Defaults are the product configuration; each option is initialised ONCE (first use) from the
  * environment variable X2I_<NAME> and afterwards only changes through x2i_set_option -- nothing on the launch path reads
- * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1), "gemm_w4" (1: 4-wave
- * hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output tiles), "conv256" (1), "attn_variant" (0), "conv5_variant" (0), "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
+ * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
+ * "gemm_w4" (1: 4-wave hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output
+ * tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
+ * through a per-device workspace -- bit-identical to the one-tile kernel.  ONE workspace per device: two GEMM launches that both
+ * take this path must not run concurrently on different streams of one device; a caller that overlaps GEMMs across streams sets 0,
+ * which restores the peeled 128^2 tail launch), "gemm_sk_error" (read-only: non-zero after a chained segment gave up waiting for its
+ * predecessor -- never observed; the result of that launch is then undefined), "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
+ * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale), "conv5_variant" (0),
+ * "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
  * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
  * return X2I_ERR_ARG.  Every setting selects between
  * kernels with identical results (bit-identical where the tests say so); the measurement-only kernels ("wrong results by
@@ -152,7 +159,10 @@ int x2i_groupnorm_nhwc_bf16(const void* x, void* y, int32_t B, int64_t HW, int32
  * FluxAttnProcessor2_0; reference call sites lightcontrol_flux.py:92-95,173-177).
  * Q,K: bf16 [B,H,Spad,128]; VT: bf16 [B,H,128,Spad] (V pre-transposed by x2i_qkv_split); rows/cols >= S are
  * zero padding (Spad % 128 == 0).  O: bf16 token-major, O[b][s][h*128 + d] with row stride ldo and batch
- * stride o_batch_stride (elements) -- i.e. `transpose(1,2).reshape(B,-1,H*128)` is free. */
+ * stride o_batch_stride (elements) -- i.e. `transpose(1,2).reshape(B,-1,H*128)` is free.
+ * `scale` multiplies the scores (1/sqrt(128) for the reference's call).  scale == ln 2 declares that Q already carries
+ * softmax_scale * log2(e) (x2i_qkv_desc.q_scale): the exp2-domain multiplier is then exactly 1, and launches of >= 256 workgroups
+ * take the hand-scheduled kernel whose softmax has no multiply (csrc/attention_w4.hip); same result within the stated tolerance. */
 int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
                        int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
 

@@ -243,3 +243,16 @@ def test_generated_gemm_loop_is_current():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gen = os.path.join(here, "x2i_amd", "csrc", "gen_gemm256w.py")
     assert subprocess.run([sys.executable, gen, "--check"]).returncode == 0
+
+
+def test_generated_attention_statement_is_current():
+    """csrc/attn_w4_loop.inc (the hand-scheduled attention kernel body) is what csrc/gen_attn_w4.py emits with its default switches
+    (no measurement ablation, product fragment lead): the generator asserts its own hazards (a P group is not converted over before
+    the last MFMA that reads it, the defer-max decision precedes the MFMAs that read the -max copies, ring occupancy)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = os.path.join(here, "x2i_amd", "csrc", "gen_attn_w4.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("X2I_ATTN_")}
+    assert subprocess.run([sys.executable, gen, "--check"], env=env).returncode == 0

@@ -4,21 +4,27 @@
 Organisation (head_dim 128, bf16, exp2-domain online softmax with defer-max -- the math of attention.hip): ONE wave per SIMD, four
 waves per workgroup, 64 query rows per wave (two 32-row blocks qb), 64-key tiles.  Per tile and wave 64 `v_mfma_f32_32x32x16_bf16`
 (2048 matrix-pipe cycles): 32 for S^T = K Q^T and 32 for O^T += V^T P^T.  The stream is software-pipelined over THREE tiles so that
-the matrix pipe never waits for the vector unit -- iteration i issues the MFMAs of S(i+1) and of the PV product of tile i-1 while the
-VALU computes the softmax of tile i in the gaps between them (4-5 other instructions per MFMA):
+the matrix pipe never waits for the vector unit -- iteration i issues the MFMAs of the PV product of tile i-1 and of S(i+1) while
+the VALU computes the softmax of tile i in the gaps between them (4.3 other instructions per MFMA on average):
 
-    MFMA   S(i+1) = K(i+1) Q^T     O += V(i-1) P(i-1)        (independent of the softmax in flight)
-    VALU   softmax(i): row max, defer-max decision, p = exp2(s * c - m), row sums, P(i) as bf16 pairs
+    MFMA   O += V(i-1) P(i-1) (first: P's registers are wanted back)      S'(i+1) = K(i+1) Q~^T - m   (C operand of the first MFMA = -m)
+    VALU   softmax(i): row max of s' and the defer-max decision (rare path: re-base), p = exp2(s'), row sums, P(i) as bf16 pairs
     LDS    fragments of K(i+1) / V(i-1): one ds_read_b128 per two MFMAs, LEAD units ahead, straight into accumulator registers
     DMA    K(i+3), V(i+1) into the ring slots iteration i has finished reading (2-deep rings, one barrier per iteration)
 
-Register files are laid out by hand (an asm operand cannot be indexed into a 16-register tuple): O accumulators (128), the Q
-fragments (64) and the K / V fragment ring (64) live in the ACCUMULATOR file -- MFMA A / B operands may come from there, `ds_read` and
-`global_load` can target it -- which leaves the 256 architectural VGPRs for two score sets (128), two P sets (64) and the softmax
-state.  The compiler only sees the statement's operands (v0..v31) and a clobber list; prologue, loop and epilogue (normalise, pack,
-half-wave exchange, 16-byte stores, log-sum-exp) are all inside the one statement.
+The softmax has no multiply: Q~ carries softmax_scale * log2(e) (from the producing QKV epilogue, x2i_qkv_desc.q_scale, or rescaled
+in the prologue when %[pres] != 0), and the running maximum is subtracted by the matrix pipe (sixteen copies of -m per query block
+are the C operand of a tile's first MFMA).  With defer-max (threshold 8) m changes rarely; the rare path re-bases the scores in
+flight, the copies and the row sums, and raises the flag that scales O at the end of the iteration.
 
-`python gen_attn_w4.py` rewrites attn_w4_loop.inc (committed; tests/test_host_cpu.py regenerates and compares).
+Register files are laid out by hand (an asm operand cannot be indexed into a 16-register tuple): O accumulators (128), the Q
+fragments (64) and the K / V fragment ring (64) live in the ACCUMULATOR file -- MFMA A / B operands may come from there, `ds_read`
+can target it -- which leaves the 256 architectural VGPRs for two score sets (128), one P set (32), the -m copies (32) and the
+softmax state.  The compiler only sees the statement's operands (v0..v31) and a clobber list; prologue, loop and epilogue
+(normalise, pack, half-wave exchange, 16-byte stores as bf16 or e4m3, log-sum-exp) are all inside the one statement.
+
+`python gen_attn_w4.py` rewrites attn_w4_loop.inc (committed; tests/test_host_cpu.py regenerates and compares).  Environment switches
+X2I_ATTN_ABL / X2I_ATTN_LEAD / X2I_ATTN_VDELAY exist for tools/r03_attn_abl.sh only (measurement; some give wrong results).
 """
 import os
 import sys
