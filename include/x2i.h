@@ -54,7 +54,8 @@ const char* x2i_last_error(void);
  * tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
  * through a per-device workspace -- bit-identical to the one-tile kernel.  ONE workspace per device: two GEMM launches that both
  * take this path must not run concurrently on different streams of one device; a caller that overlaps GEMMs across streams sets 0,
- * which restores the peeled 128^2 tail launch), "gemm_sk_error" (read-only: non-zero after a chained segment gave up waiting for its
+ * which restores the peeled 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
+ * "gemm_sk_error" (read-only: non-zero after a chained segment gave up waiting for its
  * predecessor -- never observed; the result of that launch is then undefined), "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
  * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale), "conv5_variant" (0),
  * "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
@@ -205,6 +206,15 @@ typedef struct x2i_qkv_desc {
                         * separate rescale of the bf16 Q would cost) */
 } x2i_qkv_desc;
 int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_stream_t stream);
+/* Two GEMMs of the same kind -- the image-stream and the text-stream linear of a double-stream block (lightcontrol_flux.py:173-200:
+ * to_q|k|v / add_q|k|v_proj, to_out[0] / to_add_out, ff / ff_context): same layer type, different weights, 8 : 1 in rows -- as ONE
+ * launch of the persistent kernel: problem 1's output tiles ride in the rounds of problem 0 instead of under-filling a launch of
+ * their own.  Every output tile is computed exactly as by x2i_gemm_bf16 / x2i_gemm_qkv_bf16 (bit-identical).  Grouped when both
+ * problems have the same K, activation and residual kind and are served by the persistent kernel; otherwise (and with option
+ * "gemm_pair" = 0) the two launches are issued one after the other, so the call is always valid where the two calls are. */
+int x2i_gemm_pair_bf16(const x2i_gemm_args* args0, const x2i_gemm_args* args1, x2i_stream_t stream);
+int x2i_gemm_qkv_pair_bf16(const x2i_gemm_args* args0, const x2i_qkv_desc* qkv0, const x2i_gemm_args* args1, const x2i_qkv_desc* qkv1,
+                           x2i_stream_t stream);
 /* The same fused projection on e4m3 operands (x2i_fp8_desc as for x2i_gemm_fp8, out_fp8 = 0): A is the e4m3 LayerNorm output with
  * its row scales, W the quantised to_q|to_k|to_v weight.  The accumulators are dequantised before the shared RMSNorm / RoPE
  * epilogue, so Q / K / V^T are bf16 as above.  Needs H*128 % 256 == 0 and the x2i_gemm_fp8 alignment rules. */

@@ -58,6 +58,8 @@ SIGNATURES = {
     "x2i_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "x2i_conv2d_nhwc_bf16": [C.POINTER(GemmArgs), C.POINTER(ConvDesc), _vp],
     "x2i_gemm_qkv_bf16": [C.POINTER(GemmArgs), C.POINTER(QkvDesc), _vp],
+    "x2i_gemm_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(GemmArgs), _vp],
+    "x2i_gemm_qkv_pair_bf16": [C.POINTER(GemmArgs), C.POINTER(QkvDesc), C.POINTER(GemmArgs), C.POINTER(QkvDesc), _vp],
     "x2i_gemm_fp8": [C.POINTER(GemmArgs), C.POINTER(Fp8Desc), _vp],
     "x2i_gemm_qkv_fp8": [C.POINTER(GemmArgs), C.POINTER(Fp8Desc), C.POINTER(QkvDesc), _vp],
     "x2i_quantize_rows_fp8": [_vp, _i64, _i32, _i64, _vp, _i64, _vp, _f32, _vp],

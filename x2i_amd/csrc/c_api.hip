@@ -44,6 +44,7 @@ X2IOptions make_options() {
   o.gemm_w4 = env_int("X2I_GEMM_W4", 1);
   o.gemm_persist = env_int("X2I_GEMM_PERSIST", 1);
   o.gemm_streamk = env_int("X2I_GEMM_STREAMK", 1);
+  o.gemm_pair = env_int("X2I_GEMM_PAIR", 1);
   o.conv256 = env_int("X2I_CONV256", 1);
   o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
   o.conv5_variant = env_int("X2I_CONV5_VARIANT", 0);
@@ -157,7 +158,7 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
   X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate)
 #endif
@@ -227,6 +228,14 @@ int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x
   return x2i_launch_gemm_conv(args, conv, (hipStream_t)stream);
 }
 
+int x2i_gemm_pair_bf16(const x2i_gemm_args* args0, const x2i_gemm_args* args1, x2i_stream_t stream) {
+  return x2i_launch_gemm_pair(args0, nullptr, args1, nullptr, (hipStream_t)stream);
+}
+int x2i_gemm_qkv_pair_bf16(const x2i_gemm_args* args0, const x2i_qkv_desc* qkv0, const x2i_gemm_args* args1, const x2i_qkv_desc* qkv1,
+                           x2i_stream_t stream) {
+  if (!qkv0 || !qkv1) return x2i_set_error(X2I_ERR_ARG, "gemm_qkv_pair: null descriptor");
+  return x2i_launch_gemm_pair(args0, qkv0, args1, qkv1, (hipStream_t)stream);
+}
 int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_stream_t stream) {
   if (!qkv) return x2i_set_error(X2I_ERR_ARG, "gemm_qkv: null descriptor");
   return x2i_launch_gemm_qkv(args, qkv, (hipStream_t)stream);

@@ -61,12 +61,7 @@ int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStrea
   return launch_gemm_impl(a, nullptr, qd, stream);
 }
 
-static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream) {
-  if (!a || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
-  const bool conv = cd != nullptr;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
-  if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
-  GemmP p;
+static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p) {
   p.A = (const bf16_t*)a->A; p.a_bs = a->a_batch_stride; p.lda = a->lda;
   p.W = (const bf16_t*)a->W; p.ldw = a->ldw; p.w_bs = a->w_batch_stride;
   p.bias = (const bf16_t*)a->bias;
@@ -88,6 +83,90 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT;
     p.ldc = a->N; p.c_bs = 0;  // C is never written
   }
+}
+
+// patch shape per XCD (measured, profiles/r01g_gm_sweep.log): few tile columns and a deep K -> one tile row at a time, so the XCD's
+// concurrent tiles share each A panel and it leaves HBM once; otherwise near-square patches (6 x 5.3) keep the L2 traffic per K-step
+// lowest; very wide N prefers two rows
+static int pick_gm(int tn, int K) {
+  const X2IOptions& opt = x2i_options();
+  if (opt.gemm_gm > 0) return opt.gemm_gm;
+  if (tn <= 16) return K >= 8192 ? 1 : 4;
+  if (tn <= 64) return 6;
+  return 2;
+}
+
+// operands and epilogue of a plain (or fused-QKV) GEMM as the persistent kernel needs them
+static bool persistent_ok(const x2i_gemm_args* a, const x2i_qkv_desc* qd) {
+  const X2IOptions& opt = x2i_options();
+  const bool res = a->res != nullptr;
+  const bool fast = (a->K % BK == 0) && (a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->W & 15) == 0) &&
+                    ((a->a_batch_stride & 7) == 0) && ((long long)a->M * a->lda * 2 < 0x7f000000LL) && ((long long)a->N * a->ldw * 2 < 0x7f000000LL);
+  return fast && opt.gemm_persist && opt.gemm_w4 == 1 && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
+         (qd || ((a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0)) &&
+         ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
+         (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL));
+}
+
+// stream-K decision for `tiles` 256^2 tiles of nkt K-tiles on `cus` CUs (see launch_gemm_impl); fetches the workspace
+static bool streamk_for(long long tiles, int nkt, int cus, hipStream_t stream, float** slabs, unsigned** flags) {
+  const X2IOptions& opt = x2i_options();
+  if (!(opt.gemm_streamk && opt.gemm_tile == 0 && tiles > cus && cus <= SK_MAX_TILES && nkt >= 16)) return false;
+  const long long r = tiles % cus, S = tiles / cus;
+  if (!(r > 0 && r * nkt / cus + 6 <= nkt && r * nkt >= 6 && cus <= r * (S + 1))) return false;
+  return x2i_streamk_workspace(stream, slabs, flags);
+}
+
+// Two GEMMs of the same kind in ONE persistent launch (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16): problem 1's tiles follow problem
+// 0's in the tile list.  Same results as two launches (each output tile is computed exactly as before); taken when both problems
+// are served by the persistent kernel, have the same K and the same epilogue kind; otherwise the two launches are issued one
+// after the other.
+int x2i_launch_gemm_pair(const x2i_gemm_args* a0, const x2i_qkv_desc* q0, const x2i_gemm_args* a1, const x2i_qkv_desc* q1, hipStream_t stream) {
+  if (!a0 || !a1 || ((q0 != nullptr) != (q1 != nullptr))) return x2i_set_error(X2I_ERR_ARG, "gemm_pair: null pointer / mixed kinds");
+  X2IOptions& opt = x2i_options();
+  auto plain = [](const x2i_gemm_args* a) { return a->A && a->W && a->M > 0 && a->N >= 256 && a->K > 0 && a->batch > 0 && !a->C2 && !a->out_f32 && !a->bias2 && a->M >= 256; };
+  bool ok = opt.gemm_pair && opt.gemm_tile == 0 && plain(a0) && plain(a1) && a0->K == a1->K && a0->act == a1->act &&
+            ((a0->res != nullptr) == (a1->res != nullptr)) && (q0 || (a0->C && a1->C)) && persistent_ok(a0, q0) && persistent_ok(a1, q1);
+  if (ok && q0) ok = check_qkv_desc(a0, q0, "gemm_qkv_pair") == X2I_OK && check_qkv_desc(a1, q1, "gemm_qkv_pair") == X2I_OK && (q0->H * 128) % BN2 == 0 && (q1->H * 128) % BN2 == 0;
+  if (ok && a0->gate && !a0->res) ok = false;
+  kern2_t kern = ok ? pick_gemm256p_pair(a0->act, a0->res != nullptr, q0 != nullptr) : nullptr;
+  if (!kern) {
+    const int rc = q0 ? x2i_launch_gemm_qkv(a0, q0, stream) : x2i_launch_gemm(a0, stream);
+    if (rc) return rc;
+    return q1 ? x2i_launch_gemm_qkv(a1, q1, stream) : x2i_launch_gemm(a1, stream);
+  }
+  GemmP2 pp;
+  const x2i_gemm_args* as[2] = {a0, a1};
+  const x2i_qkv_desc* qs[2] = {q0, q1};
+  long long tiles = 0;
+  for (int i = 0; i < 2; ++i) {
+    GemmP& p = pp.p[i];
+    fill_gemm_p(as[i], qs[i], p);
+    p.tilesM = (as[i]->M + BM2 - 1) / BM2; p.tilesN = (as[i]->N + BN2 - 1) / BN2;
+    p.gm = pick_gm(p.tilesN, as[i]->K);
+    p.nbatch = as[i]->batch;
+    tiles += (long long)p.tilesM * p.tilesN * p.nbatch;
+  }
+  int rc = x2i_ensure_dynamic_smem((const void*)kern, SMEM2P_BYTES);
+  if (rc) return rc;
+  const int cus = x2i_num_cus();
+  float* sk_slabs = nullptr;
+  unsigned* sk_flags = nullptr;
+  const bool sk = streamk_for(tiles, a0->K / BK, cus, stream, &sk_slabs, &sk_flags);
+  pp.p[0].sk_on = sk ? 1 : 0; pp.p[0].sk_slabs = sk_slabs; pp.p[0].sk_flags = sk_flags;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pp);
+  if (sk) x2i_streamk_mark_used(stream);
+  opt.last_gemm_tile = 2256;  // (read-back for tests: the grouped launch was taken)
+  return x2i_check_launch("gemm_pair");
+}
+
+static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream) {
+  if (!a || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
+  const bool conv = cd != nullptr;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
+  if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
+  GemmP p;
+  fill_gemm_p(a, qd, p);
   if (conv) {
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
@@ -163,13 +242,10 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     bool sk = false;
     float* sk_slabs = nullptr;
     unsigned* sk_flags = nullptr;
-    if (kernp && opt.gemm_streamk && force == 0 && tiles256 > cus && cus <= SK_MAX_TILES && nkt >= 16) {
-      // ... and only when the segments of a tile can run at different places of the workgroups' tile lists (segments per tile
-      // = cus / r <= whole tiles per workgroup + 1): with fewer whole tiles the chain of hand-offs serialises (measured: M = 2048,
-      // N = 9216, 288 tiles -> 8-segment chains behind ONE whole tile ran at half the speed of the peeled form)
-      const long long r = tiles256 % cus, S = tiles256 / cus;
-      if (r > 0 && r * nkt / cus + 6 <= nkt && r * nkt >= 6 && cus <= r * (S + 1)) sk = x2i_streamk_workspace(stream, &sk_slabs, &sk_flags);
-    }
+    // ... and only when the segments of a tile can run at different places of the workgroups' tile lists (segments per tile
+    // = cus / r <= whole tiles per workgroup + 1): with fewer whole tiles the chain of hand-offs serialises (measured: M = 2048,
+    // N = 9216, 288 tiles -> 8-segment chains behind ONE whole tile ran at half the speed of the peeled form)
+    if (kernp) sk = streamk_for(tiles256, nkt, cus, stream, &sk_slabs, &sk_flags);
     int tm_main = tm_all;
     // (re-measured in round 2, tools/tail_probe.py: peeling pays up to a 3/8-full last round at any depth, and for a half-full one
     // only behind >= 8 full rounds; a fuller last round is faster left in the one launch.  Either way the results are bit-identical.)
@@ -178,15 +254,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       if (tm_fit >= 1 && tm_fit < tm_all) tm_main = (int)tm_fit;
     }
     GemmP pm = p;
-    {
-      // Patch shape per XCD (measured, profiles/r01g_gm_sweep.log): few tile columns and a deep K -> one tile row at a time, so
-      // the XCD's concurrent tiles share each A panel and it leaves HBM once; otherwise near-square patches (6 x 5.3) keep
-      // the L2 traffic per K-step lowest; very wide N prefers two rows.
-      if (opt.gemm_gm > 0) pm.gm = opt.gemm_gm;
-      else if (tn <= 16) pm.gm = a->K >= 8192 ? 1 : 4;
-      else if (tn <= 64) pm.gm = 6;
-      else pm.gm = 2;
-    }
+    pm.gm = pick_gm(tn, a->K);
     pm.M = (tm_main < tm_all) ? tm_main * BM2 : a->M;
     pm.tilesM = tm_main; pm.tilesN = tn;
     if (kernp) {

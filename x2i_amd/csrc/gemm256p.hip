@@ -4,6 +4,7 @@
 // the operands of tile n+1 already landing, and tile n+1 starts multiplying straight out of registers.  LDS: 128 KiB operand ring +
 // 4 x 8 KiB per-wave staging = all 160 KiB; epilogues leave in 32-row chunks.  Same image / MFMA / k order as every other bf16
 // GEMM kernel here: bit-identical results (tested).  Launcher: gemm.hip (plain and batched launches with whole-line bf16 epilogues; the batch items' tiles form one list).
+#include <type_traits>
 #include "gemm_device.h"
 #include "gemm256w_loop.inc"
 
@@ -342,43 +343,88 @@ struct Unit {
   int vb, k0, len, slab;  // slab = index of the split tile (partial-accumulator slab and progress flag); -1: whole tile
 };
 
-template <int ACT, bool RES, bool HASC2, bool QKV = false>
-__global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
+template <bool PAIR> using GemmArg = std::conditional_t<PAIR, GemmP2, GemmP>;
+__device__ __forceinline__ const GemmP& prob(const GemmP& a, int) { return a; }
+__device__ __forceinline__ const GemmP& first(const GemmP& a) { return a; }
+__device__ __forceinline__ const GemmP& first(const GemmP2& a) { return a.p[0]; }
+__device__ __forceinline__ const GemmP& second(const GemmP& a) { return a; }
+__device__ __forceinline__ const GemmP& second(const GemmP2& a) { return a.p[1]; }
+// problem `sel` of a grouped launch, field by field (a dynamic index into the kernel argument would move it to scratch memory and
+// its fields into VGPRs; a scalar select per field keeps every one of them an SGPR)
+__device__ __forceinline__ GemmP prob(const GemmP2& a, int sel) {
+  const GemmP &x = a.p[0], &y = a.p[1];
+  GemmP q;
+#define X2I_F(f) q.f = sel ? y.f : x.f;
+  X2I_F(A) X2I_F(a_bs) X2I_F(lda) X2I_F(W) X2I_F(ldw) X2I_F(w_bs) X2I_F(bias) X2I_F(C) X2I_F(c_bs) X2I_F(ldc) X2I_F(C2) X2I_F(act2)
+  X2I_F(gate) X2I_F(gate_bs) X2I_F(res) X2I_F(r_bs) X2I_F(ldr) X2I_F(bias2) X2I_F(bias2_bs) X2I_F(M) X2I_F(N) X2I_F(K) X2I_F(act)
+  X2I_F(out_f32) X2I_F(tilesM) X2I_F(tilesN) X2I_F(cH) X2I_F(cW) X2I_F(cCin) X2I_F(cOW) X2I_F(cKW) X2I_F(cStride) X2I_F(cPad) X2I_F(cUp)
+  X2I_F(q_on) X2I_F(q_H) X2I_F(q_Spad) X2I_F(q_tok_off) X2I_F(q_rpb) X2I_F(q_row0) X2I_F(gm) X2I_F(q_eps) X2I_F(q_qs) X2I_F(q_nq) X2I_F(q_nk)
+  X2I_F(q_cos) X2I_F(q_sin) X2I_F(q_Q) X2I_F(q_K) X2I_F(q_VT) X2I_F(f_sa) X2I_F(f_sa_bs) X2I_F(f_sw) X2I_F(f_alpha) X2I_F(f_oinv) X2I_F(f_out8)
+  X2I_F(nbatch) X2I_F(sk_on) X2I_F(sk_slabs) X2I_F(sk_flags)
+#undef X2I_F
+  return q;
+}
+
+// PAIR: a GROUPED launch of two problems with the same K and the same epilogue kind (the image-stream and the text-stream linear of
+// a double block: same layer type, different weights, 8 : 1 in rows): one tile list, problem 1's tiles behind problem 0's, so the
+// small problem's tiles ride in the rounds of the large one instead of under-filling a launch of their own.
+template <int ACT, bool RES, bool HASC2, bool QKV = false, bool PAIR = false>
+__global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A image 32 KiB | W image 32 KiB][4 waves x 8 KiB staging]
+  const GemmP& p = first(pp);  // launch-wide fields (K, nbatch of problem 0, stream-K workspace) live in problem 0's descriptor
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int T = p.tilesM * p.tilesN;  // tiles per batch item; virtual block vb -> item z = vb / T, tile vb % T of that item
-  const int TT = T * p.nbatch;
+  const int TT0 = p.tilesM * p.tilesN * p.nbatch;  // virtual block vb < TT0: problem 0, item z = vb / T, tile vb % T of that item
+  int TT = TT0;
+  if constexpr (PAIR) TT += second(pp).tilesM * second(pp).tilesN * second(pp).nbatch;
   const int G = gridDim.x, w = blockIdx.x;
   const int nk = p.K / BK;
 
-  auto tile_of = [&](int vb, int& z, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
-    z = vb / T;
-    int bid = vb - z * T;
-    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = p.gm;
-    const int per_group = GM * p.tilesN;
+  auto tile_of = [&](int vb, int& sel, int& z, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
+    sel = PAIR ? min(max(vb - TT0 + 1, 0), 1) : 0;
+    const GemmP& q = prob(pp, sel);
+    const int T = q.tilesM * q.tilesN;
+    const int v = vb - sel * TT0;
+    z = v / T;
+    int bid = v - z * T;
+    const int qq = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    const int GM = q.gm;
+    const int per_group = GM * q.tilesN;
     const int group = bid / per_group;
     const int first_m = group * GM;
-    const int gsize = min(p.tilesM - first_m, GM);
+    const int gsize = min(q.tilesM - first_m, GM);
     m0 = (first_m + (bid % per_group) % gsize) * BM2;
     n0 = ((bid % per_group) / gsize) * BN2;
   };
   const int khl = lane >> 5, r8 = (lane >> 2) & 7, cphys = lane & 3;
   const int kel = khl * 32 + ((cphys ^ (3 * (wave & 1))) << 3);  // group parity = wave parity (4 pieces per row-group step)
-  auto offsets = [&](int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {  // (W is shared by the batch items: w_bs == 0)
-    const long long zoff = (long long)z * p.a_bs;
+  auto offsets = [&](int sel, int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {  // (W is shared by the batch items: w_bs == 0)
+    const GemmP& q = prob(pp, sel);
+    const long long zoff = (long long)z * q.a_bs;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int row = (jj * 4 + wave) * 8 + r8;
-      va[jj] = (m0 + row < p.M) ? (uint32_t)((zoff + (long long)(m0 + row) * p.lda + kel) * 2) : 0x80000000u;
-      vw[jj] = (n0 + row < p.N) ? (uint32_t)(((long long)(n0 + row) * p.ldw + kel) * 2) : 0x80000000u;
+      va[jj] = (m0 + row < q.M) ? (uint32_t)((zoff + (long long)(m0 + row) * q.lda + kel) * 2) : 0x80000000u;
+      vw[jj] = (n0 + row < q.N) ? (uint32_t)(((long long)(n0 + row) * q.ldw + kel) * 2) : 0x80000000u;
     }
   };
-
+  auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };  // (workgroup-uniform by construction; makes it provable)
+  auto mk_rsrc = [&](const void* ptr, uint32_t bytes) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
+    const unsigned long long au = ((unsigned long long)(unsigned)uni((int)(a >> 32)) << 32) | (unsigned)uni((int)(a & 0xffffffffu));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)au, 0, (uint32_t)uni((int)bytes), 0x00020000);
+  };
+  auto a_rsrc_of = [&](int sel) {
+    const GemmP& q = prob(pp, sel);
+    return mk_rsrc(q.A, (uint32_t)(((long long)(q.nbatch - 1) * q.a_bs + (long long)(q.M - 1) * q.lda + q.K) * 2));  // < 2 GB (launcher)
+  };
+  auto w_rsrc_of = [&](int sel) {
+    const GemmP& q = prob(pp, sel);
+    return mk_rsrc(q.W, (uint32_t)(((long long)(q.N - 1) * q.ldw + q.K) * 2));
+  };
   // ---- this workgroup's unit list: S whole tiles (vb = w + s*G) and, with stream-K, up to two segments of the last round's tiles
   int S = TT / G;
   auto hasXlen = [](const Unit& u) { return u.len > 0; };
@@ -411,7 +457,6 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   }
   const int hasH = segH.len > 0, hasX = segX.len > 0;
   const int n_units = S + hasH + hasX;
-  auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };  // (workgroup-uniform by construction; makes it provable)
   auto unit = [&](int i) -> Unit {
     Unit u{w + (i - hasH) * G, 0, nk, -1};
     if (i >= n_units) u = Unit{-1, 0, 0, -1};
@@ -424,10 +469,6 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
     return Unit{uni(u.vb), uni(u.k0), uni(u.len), uni(u.slab)};
   };
 
-  const uint32_t a_bytes = (uint32_t)(((long long)(p.nbatch - 1) * p.a_bs + (long long)(p.M - 1) * p.lda + p.K) * 2);  // < 2 GB (launcher)
-  const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
-  __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
 
   const int frow = lane & 15;
   const uint32_t frag = (frow >> 3) * 1024 + (frow & 7) * 64 + (((lane >> 4) ^ (3 * ((frow >> 3) & 1))) << 4);
@@ -444,10 +485,11 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   };
   if (n_units == 0) return;  // (workgroup-uniform)
   Unit cur = unit(0);
-  int z, m0, n0;
-  tile_of(cur.vb, z, m0, n0);
+  int sel, z, m0, n0;
+  tile_of(cur.vb, sel, z, m0, n0);
   uint32_t va[8], vw[8], na[8], nw[8];
-  offsets(z, m0, n0, va, vw);
+  offsets(sel, z, m0, n0, va, vw);
+  __amdgpu_buffer_rsrc_t a_rsrc = a_rsrc_of(sel), w_rsrc = w_rsrc_of(sel);
   bf16x8_t fr[32];  // wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31
   uint32_t s_koff, s_it, s_so;
   int k0b = cur.k0 * (BK * 2);
@@ -458,10 +500,13 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
   for (int ui = 0;; ++ui) {
     const Unit nxt = unit(ui + 1);
     const bool has_next = nxt.vb >= 0;
-    int nz = 0, nm0 = 0, nn0 = 0;
+    // (integer arithmetic, not a comparison, and no resource descriptor behind a branch: both would end up in VGPRs)
+    int nsel = PAIR ? min(max(nxt.vb - TT0 + 1, 0), 1) : 0, nz = 0, nm0 = 0, nn0 = 0;
+    if constexpr (PAIR) a_rsrc = a_rsrc_of(sel), w_rsrc = w_rsrc_of(sel);   // (not carried around the loop: recomputed, provably scalar)
+    const __amdgpu_buffer_rsrc_t na_rsrc = PAIR ? a_rsrc_of(nsel) : a_rsrc, nw_rsrc = PAIR ? w_rsrc_of(nsel) : w_rsrc;
     if (has_next) {
-      tile_of(nxt.vb, nz, nm0, nn0);
-      offsets(nz, nm0, nn0, na, nw);
+      tile_of(nxt.vb, nsel, nz, nm0, nn0);
+      offsets(nsel, nz, nm0, nn0, na, nw);
     } else {
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) na[jj] = nw[jj] = 0x80000000u;  // behind the last unit: every piece out of range (zero fill, no fetch)
@@ -497,7 +542,8 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
     asm volatile(X2I_GEMM256P_MAIN
                  : X2I_GEMM256P_OPS_ACC_IO(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
                    [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
-                 : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nk] "s"(len),
+                 : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nra] "s"(na_rsrc),
+                   [nrw] "s"(nw_rsrc), [nk] "s"(len),
                    [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
                  : "memory", "scc");
     if (cur.k0 + cur.len < nk) {
@@ -513,11 +559,12 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
     } else {
       // ---- epilogue of (z, m0, n0): per-wave private staging, no workgroup barrier; the next unit's first two K-tiles are in flight
       if (cur.k0 > 0 && tid == 0) __hip_atomic_store(p.sk_flags + cur.slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tile closed: flag back to 0
-      if constexpr (QKV) epilogue_qkv_chunked(p, acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
-      else epilogue_chunked<ACT, RES, HASC2>(p, acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      if constexpr (QKV) epilogue_qkv_chunked(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      else epilogue_chunked<ACT, RES, HASC2>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
     }
     if (!has_next) break;
-    cur = nxt; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
+    cur = nxt; sel = nsel; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
+
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) va[jj] = na[jj], vw[jj] = nw[jj];
   }
@@ -527,6 +574,15 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmP p) {
 }  // namespace
 
 kern_t pick_gemm256p_qkv() { return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true>; }
+
+// grouped (two-problem) forms: the layer types of a double-stream block
+kern2_t pick_gemm256p_pair(int act, bool res, bool qkv) {
+  if (qkv) return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true, true>;
+  if (res) return act == X2I_ACT_NONE ? (kern2_t)gemm256p_bf16_kernel<X2I_ACT_NONE, true, false, false, true> : nullptr;
+  if (act == X2I_ACT_GELU_TANH) return gemm256p_bf16_kernel<X2I_ACT_GELU_TANH, false, false, false, true>;
+  if (act == X2I_ACT_NONE) return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, false, true>;
+  return nullptr;
+}
 
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2) {
   if (f32) return nullptr;

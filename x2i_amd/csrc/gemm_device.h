@@ -44,6 +44,7 @@ struct GemmP {
   float* sk_slabs;
   unsigned* sk_flags;
 };
+struct GemmP2 { GemmP p[2]; };                  // grouped launch of the persistent kernel (gemm256p.hip)
 constexpr int SK_MAX_TILES = 256;               // split tiles per launch (< number of CUs)
 constexpr int SK_ERR_SLOT = SK_MAX_TILES;       // sk_flags[SK_ERR_SLOT] != 0: a segment gave up waiting for its predecessor
 constexpr long long SK_SLAB_BYTES = 256LL * 256 * 4;
@@ -453,6 +454,7 @@ constexpr int TILE2_BYTES = 4 * UNIT_BYTES;     // 64 KiB per K-tile
 constexpr int SMEM2_BYTES = 8 * 18432;          // 144 KiB: 128 KiB operand ring, reused as 8 x 18 KiB epilogue staging
 
 typedef void (*kern_t)(GemmP);
+typedef void (*kern2_t)(GemmP2);
 // kernel pickers (one per translation unit so the kernel families compile in parallel); nullptr = no MFMA instantiation
 // for this epilogue combination
 kern_t pick_gemm128(int act, bool res, bool f32, bool c2, bool conv);
@@ -460,6 +462,7 @@ kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop, persistent over output tiles (gemm256p.hip)
 kern_t pick_gemm256p_qkv();                                 // ... with the fused QKV epilogue (x2i_gemm_qkv_bf16)
+kern2_t pick_gemm256p_pair(int act, bool res, bool qkv);     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
 constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION

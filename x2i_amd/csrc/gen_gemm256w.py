@@ -116,12 +116,12 @@ def emit_event(ev, st):
         return [f"s_add_u32 m0, %[dma], {ev[1] * 4096}" if ev[1] else "s_mov_b32 m0, %[dma]"]
     if kind == "DW":
         st["vm"].append(("W", st["iter"], ev[1]))
-        v = "nw" if mode in ("B1", "B2") else "vw"
-        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[rw], %[koff] offen" + st["aux_w"] + " lds"]
+        v, r = ("nw", "nrw") if mode in ("B1", "B2") else ("vw", "rw")     # (the next unit may belong to another problem of a grouped launch)
+        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[{r}], %[koff] offen" + st["aux_w"] + " lds"]
     if kind == "DA":
         st["vm"].append(("A", st["iter"], ev[1]))
-        v = "na" if mode in ("B1", "B2") else "va"
-        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[ra], %[koff] offen" + st["aux_a"] + " lds"]
+        v, r = ("na", "nra") if mode in ("B1", "B2") else ("va", "ra")
+        return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[{r}], %[koff] offen" + st["aux_a"] + " lds"]
     if kind == "XD":
         return ["s_xor_b32 %[dma], %[dma], 0x10000"] + (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" else [])
     if kind == "BAR":

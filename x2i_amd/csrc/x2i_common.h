@@ -28,6 +28,7 @@ struct X2IOptions {
   int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
   int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
   int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
+  int gemm_pair;          // 1 = x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 issue ONE grouped persistent launch when they can (0: always two launches)
   int gemm_streamk;       // 1 = the persistent kernel splits the tiles of a partly filled last round along K (chained partial accumulators,
                           // bit-identical results; default); 0 = whole tiles only (+ the peeled 128^2 tail launch)          X2I_GEMM_STREAMK
   int gemm_persist;       // 1 = batch-1 launches with whole-line epilogues take the persistent form (gemm256p.hip, default)   X2I_GEMM_PERSIST
@@ -77,10 +78,11 @@ __device__ __forceinline__ float xhalf_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
-  // exp(-2u) = exp2(-2 log2(e) u); v_exp_f32 + v_rcp_f32 (1 ulp) instead of a full-precision division
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)  ==  x / (1 + exp2(x (a + b x^2))) with
+  // a = -2 log2(e) sqrt(2/pi), b = 0.044715 a: seven instructions per element (mul, fma, mul, v_exp_f32, add, v_rcp_f32 (1 ulp), mul) --
+  // this runs 64 K times per output tile in the GEMM epilogues with nothing to hide behind
+  const float z = x * __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

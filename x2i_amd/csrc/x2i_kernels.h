@@ -6,6 +6,7 @@
 int x2i_launch_gemm(const x2i_gemm_args* a, hipStream_t stream);
 int x2i_launch_gemm_conv(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream);
 int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStream_t stream);
+int x2i_launch_gemm_pair(const x2i_gemm_args* a0, const x2i_qkv_desc* q0, const x2i_gemm_args* a1, const x2i_qkv_desc* q1, hipStream_t stream);
 int x2i_launch_gemm_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, hipStream_t stream);
 int x2i_launch_gemm_qkv_fp8(const x2i_gemm_args* a, const x2i_fp8_desc* f, const x2i_qkv_desc* qd, hipStream_t stream);
 int x2i_launch_quantize_rows_fp8(const void* x, long long rows, int cols, long long ldx, void* y, long long ldy, float* scale,

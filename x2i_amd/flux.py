@@ -416,11 +416,17 @@ class FluxTransformer2DModel(nn.Module):
                 pass
             elif fuse_qkv:
                 # q/k RMSNorm + RoPE + head split + V transpose ride in the QKV GEMM's epilogue (no [B*S, 3D] round trip)
-                ops.gemm_qkv(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
-                             M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
+                # (image rows and text rows: two problems, ONE grouped launch -- the text tiles ride in the image launch's rounds)
+                g_img = dict(A=NRM, W=f[p + ".qkv.w"], bias=f[p + ".qkv.b"], Q=Q, K=K, VT=VT, norm_q=f[p + ".norm_q"], norm_k=f[p + ".norm_k"],
+                             cos=cos, sin=sin, M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
                              a_offset=St * D, q_scale=qs)
-                ops.gemm_qkv(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], Q, K, VT, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
-                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D, q_scale=qs)
+                g_txt = dict(A=NRM, W=f[p + ".cqkv.w"], bias=f[p + ".cqkv.b"], Q=Q, K=K, VT=VT, norm_q=f[p + ".norm_added_q"],
+                             norm_k=f[p + ".norm_added_k"], cos=cos, sin=sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B,
+                             a_batch_stride=S * D, lda=D, q_scale=qs)
+                if St > 0:
+                    ops.gemm_qkv_pair(g_img, g_txt)
+                else:
+                    ops.gemm_qkv(**g_img)
             else:
                 ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=QKV, M=Si, batch=B, a_batch_stride=S * D, lda=D,
                          a_offset=St * D, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
@@ -443,12 +449,16 @@ class FluxTransformer2DModel(nn.Module):
             if fp8_all:
                 pass
             elif not taps:
-                ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
-                         a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
-                         res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
-                ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=X, M=St, batch=B, a_batch_stride=S * D, lda=D,
-                         c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
-                         gate_batch_stride=Ntot)
+                g_img = dict(A=ATT, W=f[p + ".to_out.w"], bias=f[p + ".to_out.b"], out=X, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                             a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D,
+                             res_offset=St * D, gate=mod(oi + 2 * D), gate_batch_stride=Ntot)
+                g_txt = dict(A=ATT, W=f[p + ".to_add_out.w"], bias=f[p + ".to_add_out.b"], out=X, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                             c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
+                             gate_batch_stride=Ntot)
+                if St > 0:
+                    ops.gemm_pair(g_img, g_txt)
+                else:
+                    ops.gemm(**g_img)
             else:
                 # the module's outputs as the reference's Attention returns them (image, text), fresh tensors per block for the hooks
                 t_img = torch.empty((B, Si, D), device=self.device, dtype=torch.bfloat16)
@@ -464,11 +474,21 @@ class FluxTransformer2DModel(nn.Module):
             ffh_img_off = B * St * 4 * D
             if fp8 is None:
                 ops.ln_modulate(X, NRM, B, S, D, St, mod(oc + 3 * D), mod(oc + 4 * D), mod(oi + 3 * D), mod(oi + 4 * D), Ntot)
-                ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=CAT, M=Si, batch=B, a_batch_stride=S * D, lda=D,
-                         a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ffh_img_off, act=ACT_GELU_TANH)
-                ops.gemm(CAT, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D,
-                         a_offset=ffh_img_off, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D,
-                         ldr=D, res_offset=St * D, gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
+                # ff and ff_context: hidden layers of both streams, then both output layers, each pair one grouped launch
+                h_img = dict(A=NRM, W=f[p + ".ff.0.w"], bias=f[p + ".ff.0.b"], out=CAT, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                             a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ffh_img_off, act=ACT_GELU_TANH)
+                o_img = dict(A=CAT, W=f[p + ".ff.2.w"], bias=f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D,
+                             a_offset=ffh_img_off, c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D,
+                             ldr=D, res_offset=St * D, gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
+                if St > 0:
+                    ops.gemm_pair(h_img, dict(A=NRM, W=f[p + ".ff_context.0.w"], bias=f[p + ".ff_context.0.b"], out=CAT, M=St, batch=B,
+                                              a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D, ldc=4 * D, act=ACT_GELU_TANH))
+                    ops.gemm_pair(o_img, dict(A=CAT, W=f[p + ".ff_context.2.w"], bias=f[p + ".ff_context.2.b"], out=X, M=St, batch=B,
+                                              a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D,
+                                              ldr=D, gate=mod(oc + 5 * D), gate_batch_stride=Ntot))
+                else:
+                    ops.gemm(**h_img)
+                    ops.gemm(**o_img)
             else:
                 # text rows: bf16 norm for the bf16 ff_context; image rows: the norm emits the e4m3 operand + per-row scales
                 if St > 0:
@@ -483,11 +503,12 @@ class FluxTransformer2DModel(nn.Module):
                 ops.gemm_fp8(ws["H8"], w2, f[p + ".ff.2.b"], out=X, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, w_scale=s2,
                              c_batch_stride=S * D, ldc=D, c_offset=St * D, res=X, res_batch_stride=S * D, ldr=D, res_offset=St * D,
                              gate=mod(oi + 5 * D), gate_batch_stride=Ntot)
-            ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=CAT, M=St, batch=B, a_batch_stride=S * D,
-                     lda=D, c_batch_stride=St * 4 * D, ldc=4 * D, act=ACT_GELU_TANH)
-            ops.gemm(CAT, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=X, M=St, batch=B,
-                     a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D,
-                     gate=mod(oc + 5 * D), gate_batch_stride=Ntot)
+            if fp8 is not None and St > 0:
+                ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=CAT, M=St, batch=B, a_batch_stride=S * D,
+                         lda=D, c_batch_stride=St * 4 * D, ldc=4 * D, act=ACT_GELU_TANH)
+                ops.gemm(CAT, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=X, M=St, batch=B,
+                         a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D,
+                         gate=mod(oc + 5 * D), gate_batch_stride=Ntot)
             if control is not None:
                 # hidden_states += control_nets[i](guided_hint, timestep)['out'] * 1.0 (lightcontrol_flux.py:504-507),
                 # fused into the last ControlNeXt conv's epilogue (residual add into the image rows of X)

@@ -42,11 +42,9 @@ def pad128(n):
     return (n + 127) // 128 * 128
 
 
-def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=None, c_batch_stride=0, ldc=None,
+def _gemm_args(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=None, c_batch_stride=0, ldc=None,
          act=ACT_NONE, gate=None, gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, out2=None, act2=ACT_NONE,
          out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None, bias2=None, bias2_batch_stride=0, w_batch_stride=0):
-    """C = epi(A W^T).  A, out, res may be sub-views addressed as (tensor, element offset, row stride, batch stride)."""
-    lib = _lib.load()
     _req(A, torch.bfloat16, "A")
     _req(W, torch.bfloat16, "W")
     N = W.shape[-2] if N is None else N
@@ -83,16 +81,40 @@ def gemm(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=No
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act = act
     a.out_f32 = 1 if out_f32 else 0
-    check(lib.x2i_gemm_bf16(C.byref(a), _stream()), "gemm")
+    return a, out
+
+
+def gemm(A, W, bias=None, out=None, **kw):
+    """C = epi(A W^T).  A, out, res may be sub-views addressed as (tensor, element offset, row stride, batch stride)."""
+    a, out = _gemm_args(A, W, bias, out, **kw)
+    check(_lib.load().x2i_gemm_bf16(C.byref(a), _stream()), "gemm")
     return out
 
 
-def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1, a_batch_stride=0,
-             lda=None, a_offset=0, eps=1e-6, q_scale=1.0):
+def gemm_pair(g0, g1):
+    """Two gemm() calls of the same kind (dicts of gemm()'s arguments: A, W, bias, out, ...) as one grouped launch of the persistent
+    kernel when the library can (include/x2i.h: x2i_gemm_pair_bf16); bit-identical to the two calls."""
+    a0, _ = _gemm_args(**g0)
+    a1, _ = _gemm_args(**g1)
+    check(_lib.load().x2i_gemm_pair_bf16(C.byref(a0), C.byref(a1), _stream()), "gemm_pair")
+
+
+def gemm_qkv_pair(g0, g1):
+    """Two gemm_qkv() calls (dicts of its arguments) as one grouped launch (x2i_gemm_qkv_pair_bf16)."""
+    (a0, q0), (a1, q1) = _gemm_qkv_args(**g0), _gemm_qkv_args(**g1)
+    check(_lib.load().x2i_gemm_qkv_pair_bf16(C.byref(a0), C.byref(q0), C.byref(a1), C.byref(q1), _stream()), "gemm_qkv_pair")
+
+
+def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, **kw):
     """QKV projection with RMSNorm(q,k) + RoPE + head split + V transpose fused into the epilogue: rows of A (row m of batch
     item z = joint token tok_off + m % rows_per_sample of sample z + m // rows_per_sample) go straight to Q/K [B,H,Spad,128]
     and VT [B,H,128,Spad]; the [M, 3*H*128] product is never written (include/x2i.h: x2i_gemm_qkv_bf16)."""
-    lib = _lib.load()
+    a, q = _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, **kw)
+    check(_lib.load().x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), _stream()), "gemm_qkv")
+
+
+def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1, a_batch_stride=0,
+             lda=None, a_offset=0, eps=1e-6, q_scale=1.0):
     _req(A, torch.bfloat16, "A")
     _req(W, torch.bfloat16, "W")
     a = GemmArgs()
@@ -112,7 +134,7 @@ def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_
     q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
     q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
-    check(lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), _stream()), "gemm_qkv")
+    return a, q
 
 
 def attention(Q, K, VT, out, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0):
