@@ -103,7 +103,7 @@ static bool persistent_ok(const x2i_gemm_args* a, const x2i_qkv_desc* qd) {
   const bool fast = (a->K % BK == 0) && (a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) && (((uintptr_t)a->W & 15) == 0) &&
                     ((a->a_batch_stride & 7) == 0) && ((long long)a->M * a->lda * 2 < 0x7f000000LL) && ((long long)a->N * a->ldw * 2 < 0x7f000000LL);
   return fast && opt.gemm_persist && opt.gemm_w4 == 1 && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
-         (qd || ((a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0)) &&
+         (qd || ((a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 && (long long)a->M * a->ldc * 2 < 0x7f000000LL)) &&
          ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
          (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL));
 }
@@ -230,7 +230,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     // next unit)
     kern_t kernp = nullptr;
     if (threads2 == 256 && opt.gemm_persist && opt.gemm_w4 == 1 && a->K >= 3 * BK && !a->w_batch_stride && (a->N & 7) == 0 && (a->ldc & 7) == 0 &&
-        (qd || ((a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0)) &&
+        (qd || ((a->c_batch_stride & 7) == 0 && ((((uintptr_t)a->C) | ((uintptr_t)a->C2)) & 15) == 0 && (long long)a->M * a->ldc * 2 < 0x7f000000LL)) &&
         ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) * 2 < 0x7f000000LL &&
         (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)))
       kernp = qd ? pick_gemm256p_qkv() : pick_gemm256p(p.act, res, f32, c2);

@@ -31,6 +31,9 @@ __device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[
   bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
   const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+#ifdef X2I_ABLATION
+  if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer, tools/gemm_unit_timeline.py)
+#endif
   float bv[8][4], gv[8][4];
   static_for<8>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -132,11 +135,169 @@ __device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[
         const int row = it * 8 + srow;
         const bf16x8_t d = *(const bf16x8_t*)(buf + it * 1024 + lane * 16);
         const int m = m_wave + c * 32 + row, n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
+#ifdef X2I_ABLATION
+        if (p.act2 == 78) {  // measurement only: everything but the global stores
+          asm volatile("" ::"v"(d));
+          continue;
+        }
+#endif
         if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
       }
       // the rows have left the buffer before it is written again (next pass / chunk q+2's pieces, issued at the top of step q+1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+  });
+}
+
+// The same epilogue without residual, as a three-stage pipeline over the eight chunks (what bounded the form above was not store
+// bandwidth but LATENCY: per chunk one LDS round trip for the parked values plus four more, each `ds_read_b128 -> s_waitcnt -> store`
+// behind its own exec-mask branch -- 7.5 us per tile against 1.3 us of K-loop hand-over, tools/gemm_unit_timeline.py):
+//   A(q): accumulators of chunk q -> bias / activation -> bf16 -> staging buffer q & 1      (VALU + 8-byte LDS writes)
+//   B(q): the chunk's four 16-byte row pieces back from LDS                                  (issued together, ONE wait)
+//   C(q): four buffer_store_dwordx4                                                          (no branches: rows >= M fall behind the
+//         descriptor's num_records, columns >= N get the out-of-range offset bit)
+// order  A(0) | B(0) A(1) C(0) | B(1) A(2) C(1) | ...: B(q)'s LDS latency hides behind A(q+1)'s VALU work, C(q) never waits for LDS.
+// RES: out = bf16(gate * act(acc + bias) + residual), one rounding as everywhere.  The residual comes STRAIGHT INTO REGISTERS in the
+// accumulator layout (a lane's four consecutive columns = one 8-byte load; the four column groups of a row share a 128-byte line, so
+// L2 sees every line once), two chunks ahead of its use.  (The first form of this epilogue fetched residual rows by LDS-DMA into the
+// staging buffer, one chunk ahead -- all the look-ahead 8 KiB allow -- and waited ~2 us per chunk for it: 17 us per tile.)
+template <int ACT, bool HASC2, bool RES>
+__device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
+                                                      char* stage) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const int mlane = lane & 15, ng = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+#ifdef X2I_ABLATION
+  if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer, tools/gemm_unit_timeline.py)
+#endif
+  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
+  float bv[8][4], gv[RES ? 8 : 1][4];
+  static_for<8>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n_wave + j * 16 + ng * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bv[j][r] = 0.f;
+      if constexpr (RES) gv[j][r] = 1.f;
+    }
+    if (n + 3 < p.N) {
+      if (p.bias) {
+        const uint2 bb = *(const uint2*)(p.bias + n);
+        bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
+        bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
+      }
+      if constexpr (RES) {
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[j][0] = g4[0]; gv[j][1] = g4[1]; gv[j][2] = g4[2]; gv[j][3] = g4[3];
+        }
+      }
+      if (b2) {
+        const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+        bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
+      }
+    }
+  });
+  // residual: descriptor of this batch item, per-lane offsets of the (i = 0 / 1, j = 0) block of the chunk at (c = 0, h = 0); a
+  // chunk's eight 8-byte loads differ by the 16-row step (i), a 32-byte immediate (j) and the scalar chunk offset
+  __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  uint32_t roff[2] = {0, 0};
+  if constexpr (RES) {
+    r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)z * p.r_bs), 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) roff[i] = (uint32_t)(((long long)(m_wave + i * 16 + mlane) * p.ldr + n_wave + ng * 4) * 2);
+  }
+  u32x2 rres[RES ? 3 : 1][2][4];   // residual window: chunk q lives in rres[q % 3]
+  auto load_res = [&](auto qc) {
+    if constexpr (RES) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int h = q >> 2, c = q & 3;
+      const uint32_t soff = (uint32_t)(((long long)c * 32 * p.ldr + h * 64) * 2);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[q % 3][i][j] = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, roff[i] + j * 32, soff, 0);
+    }
+  };
+  // output descriptors of this batch item: rows at or behind M are out of range (dropped by the hardware)
+  const uint32_t c_bytes = (uint32_t)(((long long)(p.M - 1) * p.ldc + p.N) * 2);
+  __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.C + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t c2_rsrc = c_rsrc;
+  if constexpr (HASC2) c2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
+  // per-lane store offsets of the chunk at (c = 0, h): piece `it` is row it*8 + srow, 16-byte column group sch ^ swizzle(row)
+  uint32_t voff[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + srow;
+      const int n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
+      voff[h][it] = (n + 7 < p.N) ? (uint32_t)(((long long)(m_wave + row) * p.ldc + n) * 2) : 0x80000000u;
+    }
+  asm volatile("" ::: "memory");  // the bias loads stay in front of everything below
+  // A(q), column group j of the chunk (a quarter of the stage: 8 accumulator reads, bias / activation, two 8-byte parks)
+  auto stage_a = [&](auto qc, auto jc, int pass, int which) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int j = decltype(jc)::value;
+    constexpr int h = q >> 2, c = q & 3;
+    char* buf = stage + which * 4096;
+    static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
+        v[r] = apply_act(t + bv[h * 4 + j][r], ACT);
+      }
+      if constexpr (RES) {
+        const u32x2 r2 = rres[q % 3][i][j];
+        v[0] = fmaf(gv[h * 4 + j][0], v[0], __uint_as_float(r2[0] << 16));
+        v[1] = fmaf(gv[h * 4 + j][1], v[1], __uint_as_float(r2[0] & 0xffff0000u));
+        v[2] = fmaf(gv[h * 4 + j][2], v[2], __uint_as_float(r2[1] << 16));
+        v[3] = fmaf(gv[h * 4 + j][3], v[3], __uint_as_float(r2[1] & 0xffff0000u));
+      }
+      if (pass == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
+      }
+      const int row = i * 16 + mlane;
+      char* slot = buf + row * 128 + ((((j << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
+      *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    });
+  };
+  constexpr int NPASS = HASC2 ? 2 : 1;
+  constexpr int NST = 8 * NPASS;  // pipeline steps: (chunk, pass), pass-minor; step s uses staging buffer s & 1
+  u32x4 d[4];
+  auto run_a = [&](auto sc, auto jc) {
+    constexpr int s_ = decltype(sc)::value;
+    stage_a(std::integral_constant<int, s_ / NPASS>{}, jc, s_ % NPASS, s_ & 1);
+  };
+  load_res(std::integral_constant<int, 0>{});
+  load_res(std::integral_constant<int, 1>{});
+  static_for<4>([&](auto jc) { run_a(std::integral_constant<int, 0>{}, jc); });
+  static_for<NST>([&](auto sc) {
+    constexpr int s_ = decltype(sc)::value;
+    constexpr int q = s_ / NPASS, pass = s_ % NPASS;
+    constexpr int h = q >> 2, c = q & 3;
+    char* buf = stage + (s_ & 1) * 4096;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RES && s_ + 2 < NST) load_res(std::integral_constant<int, s_ + 2>{});   // (window slot of chunk s-1, consumed by A(s-1))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A(s)'s writes have landed (and B(s-1)'s reads returned long ago)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) d[it] = *(const u32x4*)(buf + it * 1024 + lane * 16);   // B(s)
+    const uint32_t soff = (uint32_t)((long long)c * 32 * p.ldc * 2);
+    // A(s+1) into the other buffer, a quarter at a time, one store of C(s) behind each quarter: a wave's stores issue at roughly one per
+    // 150 cycles whatever sits between them (tools/ubench/store_issue.hip), so the VALU work between two stores is free
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (s_ + 1 < NST) run_a(std::integral_constant<int, s_ + 1>{}, jc);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_raw_buffer_store_b128(d[j], pass == 0 ? c_rsrc : c2_rsrc, voff[h][j], soff, 0);
+    });
   });
 }
 
@@ -484,6 +645,12 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)au, 0, (uint32_t)SK_SLAB_BYTES, 0x00020000);
   };
   if (n_units == 0) return;  // (workgroup-uniform)
+#ifdef X2I_ABLATION
+  if (p.act2 >= 81) {  // measurement only: start offsets -- 81: by XCD (w & 7) x 10 us; 82: by workgroup, spread over 80 us
+    const int n = p.act2 == 81 ? (w & 7) * 10 : (((w * 167) & 255) * 80) >> 8;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(27);
+  }
+#endif
   Unit cur = unit(0);
   int sel, z, m0, n0;
   tile_of(cur.vb, sel, z, m0, n0);
@@ -539,6 +706,11 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
                  : [vo] "v"(slab_vo), [rs] "s"(s_rsrc), [fromp] "s"(fromp)
                  : "memory", "scc");
     const int zs = 1 - fromp;
+#ifdef X2I_ABLATION
+    // measurement only: 100 MHz timestamps of every unit's K-loop (start, end) of the first 4 workgroups and one per XCD, into p.bias2
+    unsigned long long* tdbg = (p.act2 >= 79 && tid == 0 && w < 16) ? (unsigned long long*)p.bias2 + w * 64 : nullptr;
+    if (tdbg && ui < 31) tdbg[2 * ui] = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile(X2I_GEMM256P_MAIN
                  : X2I_GEMM256P_OPS_ACC_IO(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
                    [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
@@ -546,6 +718,9 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
                    [nrw] "s"(nw_rsrc), [nk] "s"(len),
                    [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
                  : "memory", "scc");
+#ifdef X2I_ABLATION
+    if (tdbg && ui < 31) tdbg[2 * ui + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (cur.k0 + cur.len < nk) {
       // hand the accumulators to the next segment of this tile: write-through stores, drained inside the statement; the flag
       // (K-tiles accumulated so far) goes out behind a workgroup barrier
@@ -559,8 +734,13 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
     } else {
       // ---- epilogue of (z, m0, n0): per-wave private staging, no workgroup barrier; the next unit's first two K-tiles are in flight
       if (cur.k0 > 0 && tid == 0) __hip_atomic_store(p.sk_flags + cur.slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tile closed: flag back to 0
+#ifdef X2I_ABLATION
+      if (p.act2 == 77 || p.act2 == 79) {  // measurement only (tools/gemm_epilogue_cost.py): no epilogue at all -- what the K-loops alone take
+        asm volatile("" ::X2I_GEMM256P_OPS_ACC_IN(acc));
+      } else
+#endif
       if constexpr (QKV) epilogue_qkv_chunked(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
-      else epilogue_chunked<ACT, RES, HASC2>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      else epilogue_chunked_pipe<ACT, HASC2, RES>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
     }
     if (!has_next) break;
     cur = nxt; sel = nsel; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
