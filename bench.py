@@ -38,9 +38,9 @@ def flops_per_denoise_step(B, St, Si, D=3072, L=19, Ls=38, Kj=4096, Cin=64, pool
 
 
 def gemm_roofline(B, iters=10):
-    """Dominant kernel: the bf16 MFMA GEMM.  Times the two largest launches of a single-stream block exactly as the model
-    issues them -- proj_mlp + GELU (M=B*4608, N=12288, K=3072) and proj_out (N=3072, K=15360) -- with HIP events on the
-    launch stream; achieved = algorithmic FLOP / time."""
+    """Dominant kernel: the bf16 MFMA GEMM.  Times the two largest launch shapes of a single-stream block -- proj_mlp + bias + GELU
+    (M=B*4608, N=12288, K=3072) and proj_out + bias (N=3072, K=15360; in the model this launch also adds the gated residual) -- with
+    HIP events on the launch stream; achieved = algorithmic FLOP / time.  (Same two launches since round 1, for comparability.)"""
     from x2i_amd import ops
     D, S = 3072, 4608
     res = []
@@ -65,7 +65,7 @@ def gemm_roofline(B, iters=10):
     tt = sum(r[1] for r in res)
     # HBM-side traffic of the same two launches from the committed rocprofv3 PMC passes over tools/roofline_probe.py (tools/pmc_roofline.sh:
     # FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE, separate passes; per-launch means summed over every GEMM kernel the
-    # pair launches, i.e. the persistent 256^2 kernel and the peeled 128^2 tail).  Only valid for the profiled batch (B=4 -> M=18432).
+    # pair launches; since round 3 that is ONE persistent 256^2 kernel per GEMM, its last round cut along K).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
     pj = os.path.join(ROOT, "profiles", "r03_pmc_roofline.json")
     if B == 4 and os.path.exists(pj):
@@ -78,8 +78,8 @@ def gemm_roofline(B, iters=10):
     alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K) in ((B * S, 4 * D, D), (B * S, D, 5 * D)))
     return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_BF16,
                 traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_bf16_kernel",
-                shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out shapes, 1.39 + 1.74 TFLOP; persistent "
-                       "256^2 kernel + peeled 128^2 tail)" % (B * S))
+                shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out shapes, 1.39 + 1.74 TFLOP; one persistent "
+                       "256^2 launch each, last round cut along K)" % (B * S))
 
 
 def gemm_roofline_fp8(B, iters=10):

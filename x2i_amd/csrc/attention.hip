@@ -323,10 +323,13 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   if (unit) scale_log2 = 1.f;
   const X2IOptions& opt = x2i_options();
   const int var = opt.attn_variant;  // 0 = automatic; A/B: 1 = 8 lock-step waves, 2 = no defer-max, 3 = both, 4 = 4-wave kernel, 5 / 6 = ping-pong schedule 0 (defer-max / none), 7 / 8 = ping-pong schedules 1 / 2
-  // sequences long enough to fill the chip with 256-row workgroups and a Q that already carries the scale: the hand-scheduled
-  // one-wave-per-SIMD kernel (attention_w4.hip), whose softmax has no multiply.  Variant 9 forces it for any scale (the kernel then
-  // rescales its bf16 Q fragments itself, at the price of a second rounding of Q); 5..8 select the 8-wave ping-pong kernel
-  if ((var == 0 && unit && (long long)((S + 255) / 256) * H * B >= 256) || var == 9) {
+  // a Q that already carries the scale and sequences long enough that ONE sample's 256-row workgroups fill half the chip: the
+  // hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip), whose softmax has no multiply.  The rule looks at the sequence, not at
+  // the batch: this kernel rounds differently from the 4-wave / ping-pong pair (which are bit-identical to each other), and a
+  // sample's result must not depend on how many other samples share its launch (tests/test_fullsize_gpu.py).  Variant 9 forces it
+  // for any scale and size (the kernel then rescales its bf16 Q fragments itself, at the price of a second rounding of Q); 5..8
+  // select the 8-wave ping-pong kernel
+  if ((var == 0 && unit && (long long)((S + 255) / 256) * H >= 128) || var == 9) {
     const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse, out8, oinv);
     if (rc != X2I_ERR_STATE) return rc;
   }

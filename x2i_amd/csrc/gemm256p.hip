@@ -17,139 +17,8 @@ constexpr int P_STAGE_WAVE = 8192;
 // Epilogue of one wave (128 x 128 outputs) in eight 32-row x 64-column chunks through a double-buffered 2 x 4 KiB staging area.
 // Image of a chunk: [32 rows][128 B], 16-byte chunk ch of row r at physical chunk ch ^ ((r >> 1) & 7); a lane parks its four
 // consecutive columns with one ds_write_b64, rows leave as whole 128-byte lines (16-byte stores, 8 lines per wave instruction).
-// RES: the residual rows of chunk q+1 are fetched by LDS-DMA (swizzle applied on the source address) into the other buffer while
-// chunk q is combined in place and stored; the wait for a chunk's rows is COUNTED (the previous chunk's four stores and the next
-// chunk's four pieces stay in flight) -- a vmcnt(0) per chunk would serialise the epilogue on store latency.  Bias / gate vectors are
-// loaded once, up front, for the same reason (a load behind a store is waited for with the store).  Same arithmetic (explicit fmaf,
-// same rounding points) as epilogue_store_lds: bit-identical results.
-template <int ACT, bool RES, bool HASC2>
-__device__ __forceinline__ void epilogue_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                 char* stage) {
-  const int mlane = lane & 15, ng = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
-  bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
-  bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
-  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
-  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
-#ifdef X2I_ABLATION
-  if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer, tools/gemm_unit_timeline.py)
-#endif
-  float bv[8][4], gv[8][4];
-  static_for<8>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int n = n_wave + j * 16 + ng * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f, gv[j][r] = 1.f;
-    if (n + 3 < p.N) {
-      if (p.bias) {
-        const uint2 bb = *(const uint2*)(p.bias + n);
-        bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
-        bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
-      }
-      if (gz) {
-        const f32x4_t g4 = *(const f32x4_t*)(gz + n);
-        gv[j][0] = g4[0]; gv[j][1] = g4[1]; gv[j][2] = g4[2]; gv[j][3] = g4[3];
-      }
-      if (b2) {
-        const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
-        bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
-      }
-    }
-  });
-  __amdgpu_buffer_rsrc_t r_rsrc;
-  if constexpr (RES)
-    r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)z * p.r_bs), 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
-  auto issue = [&](int q) {  // chunk q = h*4 + c  ->  rows m_wave + 32c .., columns n_wave + 64h ..
-    if constexpr (RES) {
-      const int h = q >> 2, c = q & 3;
-      char* buf = stage + (q & 1) * 4096;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + srow;
-        const int m = m_wave + c * 32 + row, n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
-        const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((long long)m * p.ldr + n) * 2) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (__attribute__((address_space(3))) void*)(buf + it * 1024), 16, off, 0, 0, 0);
-      }
-    }
-  };
-  asm volatile("" ::: "memory");  // the bias / gate loads stay in front of everything below
-  issue(0);
-  static_for<8>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int h = q >> 2, c = q & 3;
-    char* buf = stage + (q & 1) * 4096;
-    // keep each chunk's accumulator reads (v_accvgpr_read) inside the chunk: hoisted to the top they would need 256 VGPRs at once,
-    // on top of the next tile's fragments that stay live across the epilogue
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (q + 1 < 8) issue(q + 1);
-    if constexpr (RES) {
-      // chunk q's four pieces have landed once at most {chunk q-1's 4 stores + chunk q+1's 4 pieces} remain in flight
-      if constexpr (q == 0 || q == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
-    // The accumulators stay in the accumulator file until their chunk: explicit v_accvgpr_read here.  (Left to hipcc, all 256 are
-    // copied to VGPRs straight behind the K-loop statement, which spills the next tile's fragments that are live across the epilogue.)
-    float av[2][4][4];
-    static_for<2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      static_for<4>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t;
-          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
-          av[i][j][r] = t;
-        }
-      });
-    });
-    constexpr int NPASS = HASC2 ? 2 : 1;
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      static_for<4>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        static_for<2>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          const int row = i * 16 + mlane;
-          char* slot = buf + row * 128 + ((((j << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(av[i][j][r] + bv[h * 4 + j][r], ACT);
-          if constexpr (RES) {
-            const uint2 r2 = *(const uint2*)slot;
-            v[0] = fmaf(gv[h * 4 + j][0], v[0], __uint_as_float(r2.x << 16));
-            v[1] = fmaf(gv[h * 4 + j][1], v[1], __uint_as_float(r2.x & 0xffff0000u));
-            v[2] = fmaf(gv[h * 4 + j][2], v[2], __uint_as_float(r2.y << 16));
-            v[3] = fmaf(gv[h * 4 + j][3], v[3], __uint_as_float(r2.y & 0xffff0000u));
-          }
-          if (pass == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
-          }
-          *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        });
-      });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bf16_t* dst = (pass == 0) ? Cz : C2z;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + srow;
-        const bf16x8_t d = *(const bf16x8_t*)(buf + it * 1024 + lane * 16);
-        const int m = m_wave + c * 32 + row, n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
-#ifdef X2I_ABLATION
-        if (p.act2 == 78) {  // measurement only: everything but the global stores
-          asm volatile("" ::"v"(d));
-          continue;
-        }
-#endif
-        if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
-      }
-      // the rows have left the buffer before it is written again (next pass / chunk q+2's pieces, issued at the top of step q+1)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  });
-}
-
-// The same epilogue without residual, as a three-stage pipeline over the eight chunks (what bounded the form above was not store
+// Same arithmetic (explicit fmaf, same rounding points) as epilogue_store_lds of the one-tile kernels: bit-identical results.
+// The chunks run as a three-stage pipeline (what bounded the first, chunk-after-chunk form of this epilogue was not store
 // bandwidth but LATENCY: per chunk one LDS round trip for the parked values plus four more, each `ds_read_b128 -> s_waitcnt -> store`
 // behind its own exec-mask branch -- 7.5 us per tile against 1.3 us of K-loop hand-over, tools/gemm_unit_timeline.py):
 //   A(q): accumulators of chunk q -> bias / activation -> bf16 -> staging buffer q & 1      (VALU + 8-byte LDS writes)
