@@ -32,3 +32,27 @@ for mode, what, kw in ((79, "no epilogue", {}), (80, "bias epilogue with its sto
         gap = [(int(row[i + 1, 0]) - int(row[i, 1])) / 100 for i in range(n - 1)]
         print(f"wg {w}: {n} units; K-loop us: " + " ".join(f"{d:.1f}" for d in dur))
         print("        gaps us: " + " ".join(f"{d:.2f}" for d in gap) + f"   total {(int(row[n - 1, 1]) - t0) / 100:.1f} us")
+
+# the fused QKV epilogue (single-block geometry: one GEMM over B*S rows, N = 3 * 24 * 128)
+H, Sj = 24, 4608
+Nq = 3 * H * 128
+Wq = (torch.randn((Nq, K), device=DEV, generator=g) * 0.02).bfloat16()
+bq = torch.randn((Nq,), device=DEV, generator=g).bfloat16()
+Q, Kk = (torch.zeros((4, H, Sj, 128), device=DEV, dtype=torch.bfloat16) for _ in range(2))
+VT = torch.zeros((4, H, 128, Sj), device=DEV, dtype=torch.bfloat16)
+nq, nk = (torch.ones((128,), device=DEV, dtype=torch.bfloat16) for _ in range(2))
+ang = torch.randn((Sj, 64), device=DEV, generator=g)
+cos, sin = torch.cos(ang).repeat_interleave(2, 1).contiguous(), torch.sin(ang).repeat_interleave(2, 1).contiguous()
+for it in range(4):
+    dbg.zero_()
+    ops.gemm_qkv(A, Wq, bq, Q, Kk, VT, nq, nk, cos, sin, M=M, H=H, Spad=Sj, tok_off=0, rows_per_sample=Sj, _act2=80, _bias2=dbg.view(torch.float32))
+torch.cuda.synchronize()
+t = dbg.view(16, 32, 2).cpu()
+print("== fused QKV epilogue (tiles of the q / k / v sections in the XCD order)")
+for w in (0, 1, 2):
+    row = t[w]
+    n = int((row[:, 0] > 0).sum())
+    dur = [(int(row[i, 1]) - int(row[i, 0])) / 100 for i in range(n)]
+    gap = [(int(row[i + 1, 0]) - int(row[i, 1])) / 100 for i in range(n - 1)]
+    print(f"wg {w}: {n} units; K-loop us: " + " ".join(f"{d:.1f}" for d in dur))
+    print("        gaps us: " + " ".join(f"{d:.2f}" for d in gap))

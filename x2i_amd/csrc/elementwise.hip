@@ -112,13 +112,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     const int h = rem >> 4, c = rem & 15;
     float x[8];
     unpack8(*(const bf16x8_t*)(row + isk * D + h * 128 + c * 8), x);
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+    float ss = sumsq8(x);
     // reduce over the 16 lanes of this (token, head)
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float r = rsqrtf(ss * (1.f / 128.f) + eps);
+    const float r = rms_rsqrt128(ss, eps);
     const bf16_t* wn = isk ? (src0 ? nk0 : nk1) : (src0 ? nq0 : nq1);
     float w[8];
     unpack8(*(const bf16x8_t*)(wn + c * 8), w);
@@ -129,12 +127,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
     float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
     float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
-      o[j] = a * cs[j] - bb * sn[j];
-      o[j + 1] = bb * cs[j + 1] + a * sn[j + 1];
-    }
+    norm_rope8(x, r, w, cs, sn, o);
     bf16_t* dst = (isk ? K : Q) + (((long long)b * H + h) * Spad + s) * 128 + c * 8;
     *(bf16x8_t*)dst = pack8(o);
   }

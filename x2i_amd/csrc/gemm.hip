@@ -320,7 +320,12 @@ static int check_qkv_desc(const x2i_gemm_args* a, const x2i_qkv_desc* qd, const 
   if (qd->Spad % 128 || qd->rows_per_sample <= 0 || qd->tok_off < 0 || qd->tok_off + qd->rows_per_sample > qd->Spad)
     return x2i_set_error(X2I_ERR_SHAPE, "%s: bad token geometry (tok_off=%d rows_per_sample=%d Spad=%d)", who, qd->tok_off,
                          qd->rows_per_sample, qd->Spad);
-  if (a->act || a->res || a->gate || a->C2 || a->out_f32 || a->bias2)
+#ifdef X2I_ABLATION
+  const bool extra = false;  // (measurement library: bias2 carries the timestamp buffer of tools/gemm_unit_timeline.py)
+#else
+  const bool extra = a->bias2 != nullptr;
+#endif
+  if (a->act || a->res || a->gate || a->C2 || a->out_f32 || extra)
     return x2i_set_error(X2I_ERR_ARG, "%s: only the plain bias epilogue can be fused", who);
   if ((((uintptr_t)qd->Q | (uintptr_t)qd->K | (uintptr_t)qd->VT | (uintptr_t)qd->norm_q | (uintptr_t)qd->norm_k | (uintptr_t)qd->cos |
         (uintptr_t)qd->sin) & 15) != 0)

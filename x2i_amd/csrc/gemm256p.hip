@@ -199,11 +199,8 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
     const uint32_t u = (r & 2) ? bvp[j].y : bvp[j].x;
     return __uint_as_float((r & 1) ? (u & 0xffff0000u) : (u << 16));
   };
-  auto token = [&](int m, int& b, int& st) {  // row m of batch item z -> sample b, position st of the joint sequence
-    const int mg = p.q_row0 + m;
-    b = z + mg / p.q_rpb;
-    st = p.q_tok_off + mg % p.q_rpb;
-  };
+  const TokMap tmap = tok_map(p, z, m_wave);
+  auto token = [&](int m, int& b, int& st) { tok_of(tmap, m - m_wave, b, st); };  // rows m_wave <= m < m_wave + 128
   if (sec < 2) {
     const int c = lane & 15, rsub = lane >> 4;  // 8-dim chunk of the head; row of the pass
     float w[8];
@@ -212,27 +209,33 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
 #pragma unroll
       for (int j = 0; j < 8; ++j) w[j] = bf16_to_f32((bf16_t)wv[j]) * (sec ? 1.f : p.q_qs);
     }
-    bf16_t* dstbase = sec ? p.q_K : p.q_Q;
-    f32x4_t cs[2][4];  // per pass of a half chunk: cos[0..3], cos[4..7], sin[0..3], sin[4..7] of this lane's 8 dims
+    // Q / K rows and the RoPE tables through buffer descriptors with 32-bit offsets (the launcher keeps Q / K below 2 GB): no 64-bit
+    // address arithmetic per row, and rows at or behind M get the out-of-range offset instead of a branch around their store
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sec ? p.q_K : p.q_Q), 0, 0x7ffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t cos_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.q_cos, 0, 0x7ffffff0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t sin_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.q_sin, 0, 0x7ffffff0u, 0x00020000);
+    f32x4_t cs[2][4];   // per pass of a half chunk: cos[0..3], cos[4..7], sin[0..3], sin[4..7] of this lane's 8 dims
+    uint32_t qoff[2];   // ... and where the pass's 16 bytes of Q / K go
     auto load_cs = [&](int half) {  // half = 2 passes (8 tokens) of the 16-token chunks
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
-        const int m = m_wave + half * 8 + ps * 4 + rsub;
+        const int dm = half * 8 + ps * 4 + rsub;
+        const bool valid = m_wave + dm < p.M;
         int b, st;
-        token(m < p.M ? m : 0, b, st);
-        const float* cp = p.q_cos + (long long)st * 128 + c * 8;
-        const float* sp = p.q_sin + (long long)st * 128 + c * 8;
-        cs[ps][0] = *(const f32x4_t*)cp; cs[ps][1] = *(const f32x4_t*)(cp + 4);
-        cs[ps][2] = *(const f32x4_t*)sp; cs[ps][3] = *(const f32x4_t*)(sp + 4);
+        tok_of(tmap, valid ? dm : 0, b, st);
+        const uint32_t co = (uint32_t)(st * 128 + c * 8) * 4u;
+        cs[ps][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co, 0, 0));
+        cs[ps][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co + 16, 0, 0));
+        cs[ps][2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co, 0, 0));
+        cs[ps][3] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co + 16, 0, 0));
+        qoff[ps] = valid ? (uint32_t)(((b * p.q_H + head) * p.q_Spad + st) * 128 + c * 8) * 2u : 0x80000000u;
       }
     };
-    asm volatile("" ::: "memory");
-    load_cs(0);
-    static_for<8>([&](auto qc) {
+    auto park = [&](auto qc) {  // chunk q16 (16 tokens x 128 dims) as bf16(acc + bias) into staging buffer q16 & 1
       constexpr int q16 = decltype(qc)::value;
       constexpr int c2 = q16 >> 1, rr = q16 & 1;
       char* buf = stage + (q16 & 1) * 4096;
-      __builtin_amdgcn_sched_barrier(0);
       static_for<2>([&](auto hc) {
         constexpr int h = decltype(hc)::value;
         static_for<4>([&](auto jc) {
@@ -248,51 +251,52 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
               make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
         });
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    asm volatile("" ::: "memory");
+    load_cs(0);
+    park(std::integral_constant<int, 0>{});
+    static_for<8>([&](auto qc) {
+      constexpr int q16 = decltype(qc)::value;
+      char* buf = stage + (q16 & 1) * 4096;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the chunk is parked
+      bf16x8_t xv[4];                                       // its four passes' rows, requested together: one LDS round trip per chunk
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = k * 4 + rsub;
+        xv[k] = *(const bf16x8_t*)(buf + row * 256 + ((c ^ row) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
       static_for<2>([&](auto hfc) {
         constexpr int hf = decltype(hfc)::value;  // passes 2hf, 2hf + 1 of this chunk = half-chunk index 2 q16 + hf
-        bf16x8_t outv[2];
+        u32x4 outv[2];
+        uint32_t so[2];
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-          const int row = hf * 8 + ps * 4 + rsub;
-          const bf16x8_t xv = *(const bf16x8_t*)(buf + row * 256 + ((c ^ row) << 4));
           float x[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[j]);
-          float ss = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+          for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[hf * 2 + ps][j]);
+          float ss = sumsq8(x);
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this token
-          const float r = rsqrtf(ss * (1.f / 128.f) + p.q_eps);
+          const float r = rms_rsqrt128(ss, p.q_eps);
           const float csv[8] = {cs[ps][0][0], cs[ps][0][1], cs[ps][0][2], cs[ps][0][3], cs[ps][1][0], cs[ps][1][1], cs[ps][1][2], cs[ps][1][3]};
           const float snv[8] = {cs[ps][2][0], cs[ps][2][1], cs[ps][2][2], cs[ps][2][3], cs[ps][3][0], cs[ps][3][1], cs[ps][3][2], cs[ps][3][3]};
           float o8[8];
+          norm_rope8(x, r, w, csv, snv, o8);
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
-            o8[j] = a * csv[j] - bb * snv[j];
-            o8[j + 1] = bb * csv[j + 1] + a * snv[j + 1];
-          }
-          union { bf16x8_t v8; uint32_t uu[4]; } pk;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pk.uu[j] = pack_bf16x2(o8[2 * j], o8[2 * j + 1]);
-          outv[ps] = pk.v8;
+          for (int j = 0; j < 4; ++j) outv[ps][j] = pack_bf16x2(o8[2 * j], o8[2 * j + 1]);
+          so[ps] = qoff[ps];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (2 * q16 + hf + 1 < 16) load_cs(2 * q16 + hf + 1);  // in front of this half's stores (see the header comment)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const int m = m_wave + q16 * 16 + hf * 8 + ps * 4 + rsub;
-          if (m < p.M) {
-            int b, st;
-            token(m, b, st);
-            *(bf16x8_t*)(dstbase + (((long long)b * p.q_H + head) * p.q_Spad + st) * 128 + c * 8) = outv[ps];
-          }
-        }
+        for (int ps = 0; ps < 2; ++ps) __builtin_amdgcn_raw_buffer_store_b128(outv[ps], q_rsrc, so[ps], 0, 0);
       });
+      // (parking the next chunk HERE, behind this chunk's stores: in front of the compute it would hide one more LDS round trip, but
+      // that order miscompiles -- wrong accumulators reach the epilogue, Q / K / V^T all differ; tools/r03_dbg_qkv.py)
+      if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
     });
   } else {
     const int ch_lo = lane & 7, dp_lo = lane >> 3;

@@ -49,6 +49,30 @@ constexpr int SK_MAX_TILES = 256;               // split tiles per launch (< num
 constexpr int SK_ERR_SLOT = SK_MAX_TILES;       // sk_flags[SK_ERR_SLOT] != 0: a segment gave up waiting for its predecessor
 constexpr long long SK_SLAB_BYTES = 256LL * 256 * 4;
 
+// Row m of a QKV GEMM -> (sample b, position st in the joint sequence) without a division per row: the division happens ONCE for a
+// uniform base row; rows behind it wrap by subtraction (at most once when a sample has at least as many rows as the span, 256).  (The per-row `mg / rows_per_sample` of the first form was most of the fused epilogue's instruction count.)
+struct TokMap {
+  int b0, r0, rpb, tok_off;
+};
+__device__ __forceinline__ TokMap tok_map(const GemmP& p, int z, int m_base_uniform) {
+  const int mg0 = __builtin_amdgcn_readfirstlane(p.q_row0 + m_base_uniform);
+  const int q = mg0 / p.q_rpb;
+  return TokMap{z + q, mg0 - q * p.q_rpb, p.q_rpb, p.q_tok_off};
+}
+__device__ __forceinline__ void tok_of(const TokMap& t, int dm, int& b, int& st) {  // dm = m - m_base, 0 <= dm < 256
+  int r = t.r0 + dm;
+  int q = r >= t.rpb ? 1 : 0;  // one wrap, branch-free: all there is when a sample has >= 256 rows (every shape of the model)
+  r -= q ? t.rpb : 0;
+  if (__builtin_expect(r >= t.rpb, 0)) {  // shorter samples: keep wrapping
+    do {
+      r -= t.rpb;
+      ++q;
+    } while (r >= t.rpb);
+  }
+  b = t.b0 + q;
+  st = t.tok_off + r;
+}
+
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const uint32_t (&voff)[4],
                                            uint32_t koff_bytes, int wave) {
   // 1024 16-byte chunks per tile; instruction j covers chunks [j*256 + wave*64, +64): LDS dest is wave-uniform
@@ -355,6 +379,7 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
   const int Dm = p.q_H * 128;
   const int sec = n0 / Dm;  // 0 = q, 1 = k, 2 = v (a tile never straddles sections: Dm % TC == 0, checked by the launcher)
   const int head0 = (n0 - sec * Dm) >> 7;
+  const TokMap tmap = tok_map(p, z, m0);  // (tile rows m0 .. m0 + TR - 1, TR <= 256)
   auto lds_at = [&](int row, int col) -> const char* {  // bf16 element (row, col) of the tile
     return smem + ((row / WR) * WN + (col >> 6)) * REGION + (row % WR) * EPI_ROW_BYTES + (col & 63) * 2;
   };
@@ -375,15 +400,13 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
       float x[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[j]);
-      float ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+      float ss = sumsq8(x);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this (token, head)
       if (m < p.M) {
-        const float r = rsqrtf(ss * (1.f / 128.f) + p.q_eps);
-        const int mg = p.q_row0 + m;
-        const int b = z + mg / p.q_rpb, st = p.q_tok_off + mg % p.q_rpb;
+        const float r = rms_rsqrt128(ss, p.q_eps);
+        int b, st;
+        tok_of(tmap, row, b, st);
         const float* cp = p.q_cos + (long long)st * 128 + c * 8;
         const float* sp = p.q_sin + (long long)st * 128 + c * 8;
         const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
@@ -391,12 +414,7 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
         const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
         const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
         float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const float a = x[j] * r * w[j], bb = x[j + 1] * r * w[j + 1];
-          o[j] = a * cs[j] - bb * sn[j];
-          o[j + 1] = bb * cs[j + 1] + a * sn[j + 1];
-        }
+        norm_rope8(x, r, w, cs, sn, o);
         union { bf16x8_t v8; uint32_t uu[4]; } pk;
 #pragma unroll
         for (int j = 0; j < 4; ++j) pk.uu[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
@@ -419,8 +437,8 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
       const int m = m0 + ch * 8;
       if (m >= p.M) continue;
       const int h = head0 + (d0 >> 7), d = d0 & 127;
-      const int mg = p.q_row0 + m;
-      const int b = z + mg / p.q_rpb, st = p.q_tok_off + mg % p.q_rpb;
+      int b, st;
+      tok_of(tmap, m - m0, b, st);
       bf16_t* row0 = p.q_VT + (((long long)b * p.q_H + h) * 128 + d) * p.q_Spad;
       if (aligned) {
         union { bf16x8_t v8; uint32_t uu[4]; } lo, hi;
@@ -435,8 +453,8 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           if (m + k < p.M) {
-            const int mgk = mg + k;
-            const int bk = z + mgk / p.q_rpb, sk = p.q_tok_off + mgk % p.q_rpb;
+            int bk, sk;
+            tok_of(tmap, m + k - m0, bk, sk);
             bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + h) * 128 + d) * p.q_Spad + sk;
             rk[0] = (bf16_t)(v[k] & 0xffffu);
             rk[p.q_Spad] = (bf16_t)(v[k] >> 16);

@@ -84,6 +84,25 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float z = x * __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
+// RMSNorm statistics and normalise + interleaved-pair RoPE of a lane's 8 dims, with every fused / unfused operation spelled out: the
+// fused QKV epilogues of the GEMM kernels and x2i_qkv_split_bf16 must round identically (bit-exact tests, batch independence), which
+// a contractable `a * c - b * s` only does as long as the compiler happens to contract it the same way in every surrounding
+__device__ __forceinline__ float sumsq8(const float (&x)[8]) {
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(x[j], x[j], ss);
+  return ss;
+}
+__device__ __forceinline__ float rms_rsqrt128(float ss, float eps) { return rsqrtf(__builtin_fmaf(ss, 1.f / 128.f, eps)); }
+__device__ __forceinline__ void norm_rope8(const float (&x)[8], float r, const float (&w)[8], const float (&cs)[8], const float (&sn)[8],
+                                           float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const float a = __fmul_rn(__fmul_rn(x[j], r), w[j]), bb = __fmul_rn(__fmul_rn(x[j + 1], r), w[j + 1]);
+    o[j] = __builtin_fmaf(a, cs[j], -__fmul_rn(bb, sn[j]));
+    o[j + 1] = __builtin_fmaf(bb, cs[j + 1], __fmul_rn(a, sn[j + 1]));
+  }
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 

@@ -114,7 +114,7 @@ def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, **kw):
 
 
 def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1, a_batch_stride=0,
-             lda=None, a_offset=0, eps=1e-6, q_scale=1.0):
+             lda=None, a_offset=0, eps=1e-6, q_scale=1.0, _act2=0, _bias2=None):
     _req(A, torch.bfloat16, "A")
     _req(W, torch.bfloat16, "W")
     a = GemmArgs()
@@ -126,8 +126,8 @@ def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     a.bias = bias.data_ptr() if bias is not None else None
     a.C = None
     a.c_batch_stride, a.ldc = 0, 3 * H * 128
-    a.C2, a.act2, a.gate, a.gate_batch_stride, a.res, a.res_batch_stride, a.ldr = None, 0, None, 0, None, 0, 0
-    a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
+    a.C2, a.act2, a.gate, a.gate_batch_stride, a.res, a.res_batch_stride, a.ldr = None, _act2, None, 0, None, 0, 0
+    a.bias2, a.bias2_batch_stride, a.w_batch_stride = (_bias2.data_ptr() if _bias2 is not None else None), 0, 0   # (_act2 / _bias2: tools only)
     a.M, a.N, a.K, a.batch = M, 3 * H * 128, W.shape[-1], batch
     a.act, a.out_f32 = ACT_NONE, 0
     q = QkvDesc()
