@@ -194,6 +194,14 @@ def test_c_abi_argument_validation_returns_codes_without_a_gpu():
     q.Spad, a.act = 256, 1
     assert lib.x2i_gemm_qkv_bf16(C.byref(a), C.byref(q), None) < 0 and b"plain bias" in lib.x2i_last_error()
     assert lib.x2i_gemm_qkv_bf16(C.byref(a), None, None) < 0
+    # grouped launches: same validation as the two calls they stand for (no GPU needed to be refused)
+    g = _lib.GemmArgs()
+    assert lib.x2i_gemm_pair_bf16(C.byref(g), None, None) < 0 and lib.x2i_gemm_pair_bf16(None, C.byref(g), None) < 0
+    assert lib.x2i_gemm_pair_bf16(C.byref(g), C.byref(g), None) < 0 and b"null" in lib.x2i_last_error()   # falls back to x2i_gemm_bf16's checks
+    assert lib.x2i_gemm_qkv_pair_bf16(C.byref(a), None, C.byref(a), C.byref(q), None) < 0
+    a.act = 0
+    q.Spad = 200
+    assert lib.x2i_gemm_qkv_pair_bf16(C.byref(a), C.byref(q), C.byref(a), C.byref(q), None) < 0 and b"geometry" in lib.x2i_last_error()
 
     cd = _lib.ConvDesc(H=8, W=8, Cin=48, KH=3, KW=3, stride=1, pad=1, up=0)
     a = _lib.GemmArgs()

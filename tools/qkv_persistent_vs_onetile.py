@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Tools-only: the fused QKV projection at the single-block shape through the persistent kernel, the one-tile kernel and the two-step
+form (plain GEMM + x2i_qkv_split_bf16): counts of differing elements (all three must agree bit for bit), with the first offenders."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from x2i_amd import ops, _lib

@@ -7,9 +7,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# X2I_LIB_VARIANT=ablate (read once, at import) makes tools/ load the measurement-only build (ablation kernels, k-half-unit
-# GEMM form); the product package never sets it.
-LIB_PATH = os.path.join(_HERE, "libx2i_hip_ablate.so" if os.environ.get("X2I_LIB_VARIANT") == "ablate" else "libx2i_hip.so")
+# X2I_LIB_VARIANT=<name> (read once, at import) makes tools/ load libx2i_hip_<name>.so instead: "ablate" = the measurement-only build
+# (ablation kernels, k-half-unit GEMM form), anything else = a library built from another commit for a same-box A/B.  The product
+# package never sets it.
+_VARIANT = os.environ.get("X2I_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "libx2i_hip_%s.so" % _VARIANT if _VARIANT else "libx2i_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
 

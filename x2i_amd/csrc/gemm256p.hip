@@ -295,7 +295,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         for (int ps = 0; ps < 2; ++ps) __builtin_amdgcn_raw_buffer_store_b128(outv[ps], q_rsrc, so[ps], 0, 0);
       });
       // (parking the next chunk HERE, behind this chunk's stores: in front of the compute it would hide one more LDS round trip, but
-      // that order miscompiles -- wrong accumulators reach the epilogue, Q / K / V^T all differ; tools/r03_dbg_qkv.py)
+      // that order miscompiles -- wrong accumulators reach the epilogue, Q / K / V^T all differ; tools/qkv_persistent_vs_onetile.py)
       if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
     });
   } else {
