@@ -43,6 +43,7 @@ def gemm_roofline(B, iters=10):
     HIP events on the launch stream; achieved = algorithmic FLOP / time.  (Same two launches since round 1, for comparability.)"""
     from x2i_amd import ops
     D, S = 3072, 4608
+    B = min(B, 8)   # (the probe's flattened A operand must stay below the kernels' 2 GB operand limit: 8 x 4608 rows x 15360 x 2 B = 1.1 GB)
     res = []
     for (M, N, K, act) in ((B * S, 4 * D, D, 1), (B * S, D, 5 * D, 0)):
         A = torch.randn(M, K, device="cuda").bfloat16()
@@ -87,6 +88,7 @@ def gemm_roofline_fp8(B, iters=10):
     dense fp8 peak.  proj_mlp + GELU writes e4m3, proj_out carries the gated residual, exactly as the fp8 model issues them."""
     from x2i_amd import ops
     D, S = 3072, 4608
+    B = min(B, 8)   # (the probe's flattened A operand must stay below the kernels' 2 GB operand limit: 8 x 4608 rows x 15360 x 2 B = 1.1 GB)
     res = []
     for (M, N, K, gelu) in ((B * S, 4 * D, D, True), (B * S, D, 5 * D, False)):
         A8, sa = ops.quantize_rows_fp8(torch.randn(M, K, device="cuda").bfloat16())

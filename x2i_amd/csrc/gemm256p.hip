@@ -519,8 +519,15 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
   };
   if (n_units == 0) return;  // (workgroup-uniform)
 #ifdef X2I_ABLATION
-  if (p.act2 >= 81) {  // measurement only: start offsets -- 81: by XCD (w & 7) x 10 us; 82: by workgroup, spread over 80 us
-    const int n = p.act2 == 81 ? (w & 7) * 10 : (((w * 167) & 255) * 80) >> 8;
+  if (p.act2 >= 81) {  // measurement only: start offsets -- 82: by workgroup, spread over 80 us; 81 / 83 / 84 / 85: by XCD (w & 7) x 10 / 5 / 2.5 / 20 us
+    int n = (w & 7) * 10;
+    if (p.act2 == 82) n = (((w * 167) & 255) * 80) >> 8;
+    if (p.act2 == 83) n = (w & 7) * 5;
+    if (p.act2 == 85) n = (w & 7) * 20;
+    if (p.act2 == 84) {
+      for (int i = 0; i < (w & 7) * 5; ++i) __builtin_amdgcn_s_sleep(13);  // ~ 0.5 us
+      n = 0;
+    }
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(27);
   }
 #endif
