@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_w4_kernel(const bf16_t* __restrict__
                  [vd3] "v"(vd[3]), [kdst] "s"(kdst), [vdst] "s"(vdst), [qo0] "v"(qo0), [qo1] "v"(qo1), [lo] "v"(lo), [qv] "v"(q), [lim] "v"(lim), [hi] "v"(hi), [kr] "s"(k_rsrc),
                  [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2), [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt),
                  [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale), [o8] "s"(out8), [oinv] "s"(oinv), [n448] "s"(-448.0f)
-               : "memory", "vcc", "scc", X2I_ATTN_W4_CLOBBERS);
+               : "memory", "vcc", "scc", "m0", X2I_ATTN_W4_CLOBBERS);
 }
 
 }  // namespace

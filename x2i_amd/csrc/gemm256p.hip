@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
   asm volatile(X2I_GEMM256P_PRO
                : X2I_GEMM256P_OPS_FRAG0_OUT(fr), [koff] "=&s"(s_koff)
                : X2I_GEMM256W_OPS_VOFF(va, vw), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [k0b] "s"(k0b)
-               : "memory", "scc");
+               : "memory", "scc", "m0");
   for (int ui = 0;; ++ui) {
     const Unit nxt = unit(ui + 1);
     const bool has_next = nxt.vb >= 0;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
                  : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nra] "s"(na_rsrc),
                    [nrw] "s"(nw_rsrc), [nk] "s"(len),
                    [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
-                 : "memory", "scc");
+                 : "memory", "scc", "m0");
 #ifdef X2I_ABLATION
     if (tdbg && ui < 31) tdbg[2 * ui + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
