@@ -55,12 +55,12 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ X, l
     if (c < nv) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float d = v[i][j] - mean;
-        sq += d * d;
+        const float d = __fsub_rn(v[i][j], mean);
+        sq = __builtin_fmaf(d, d, sq);
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  const float rstd = rsqrtf(__fadd_rn(wave_sum(sq) / (float)D, eps));
   const float* sh = nullptr;
   const float* sc = nullptr;
   if (!AFFINE) {
@@ -83,11 +83,74 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16_t* __restrict__ X, l
         const f32x4_t h0 = *(const f32x4_t*)(sh + c * 8), h1 = *(const f32x4_t*)(sh + c * 8 + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          o[j] = (v[i][j] - mean) * rstd * (1.f + s0[j]) + h0[j];
-          o[j + 4] = (v[i][j + 4] - mean) * rstd * (1.f + s1[j]) + h1[j];
+          o[j] = ln_mod1(v[i][j], mean, rstd, s0[j], h0[j]);
+          o[j + 4] = ln_mod1(v[i][j + 4], mean, rstd, s1[j], h1[j]);
         }
       }
       *(bf16x8_t*)(y + c * 8) = pack8(o);
+    }
+  }
+}
+
+// The modulated form for D = 512 * CPL, several consecutive rows per wave: the (1 + scale) / shift vectors of a sample (2 x 4 D bytes,
+// four times a row's bf16 bytes) stay in registers across the rows instead of coming back from L2 for every row.  Same arithmetic
+// as ln_kernel<false>, element for element.
+template <int CPL, int RW>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const bf16_t* __restrict__ X, long long x_bs, int ldx, bf16_t* __restrict__ Y,
+                                                      long long y_bs, int ldy, int S, int S0, const float* shift0, const float* scale0,
+                                                      const float* shift1, const float* scale1, long long mod_bs, float eps,
+                                                      long long total_rows) {
+  constexpr int D = CPL * 512;
+  const int lane = threadIdx.x & 63;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  float sc[CPL][8], sh[CPL][8];
+  int cb = -1, cside = -1;
+#pragma unroll 1
+  for (int r = 0; r < RW; ++r) {
+    const long long row = row0 + r;
+    if (row >= total_rows) return;
+    const int b = (int)(row / S);
+    const int s = (int)(row - (long long)b * S);
+    const int side = s < S0 ? 0 : 1;
+    const bf16_t* x = X + (long long)b * x_bs + (long long)s * ldx;
+    float v[CPL][8];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) unpack8(*(const bf16x8_t*)(x + (lane + i * 64) * 8), v[i]);
+    if (b != cb || side != cside) {  // (wave-uniform) a new sample or stream: fetch its modulation vectors once
+      const float* shp = (side ? shift1 : shift0) + (long long)b * mod_bs;
+      const float* scp = (side ? scale1 : scale0) + (long long)b * mod_bs;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = (lane + i * 64) * 8;
+        const f32x4_t s0 = *(const f32x4_t*)(scp + c), s1 = *(const f32x4_t*)(scp + c + 4);
+        const f32x4_t h0 = *(const f32x4_t*)(shp + c), h1 = *(const f32x4_t*)(shp + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[i][j] = s0[j]; sc[i][j + 4] = s1[j]; sh[i][j] = h0[j]; sh[i][j + 4] = h1[j]; }
+      }
+      cb = b; cside = side;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = __fsub_rn(v[i][j], mean);
+        sq = __builtin_fmaf(d, d, sq);
+      }
+    const float rstd = rsqrtf(__fadd_rn(wave_sum(sq) / (float)D, eps));
+    bf16_t* y = Y + (long long)b * y_bs + (long long)s * ldy;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = ln_mod1(v[i][j], mean, rstd, sc[i][j], sh[i][j]);
+      *(bf16x8_t*)(y + (lane + i * 64) * 8) = pack8(o);
     }
   }
 }
@@ -333,6 +396,11 @@ int x2i_launch_ln_modulate(const void* X, long long x_bs, int ldx, void* Y, long
   if (D % 8 || D > 64 * 8 * LN_MAXV || B <= 0 || S <= 0) return x2i_set_error(X2I_ERR_SHAPE, "ln_modulate: D=%d must be a multiple of 8 and <= %d", D, 64 * 8 * LN_MAXV);
   if (ldx % 8 || ldy % 8 || x_bs % 8 || y_bs % 8 || mod_bs % 4 || !al16(X) || !al16(Y)) return x2i_set_error(X2I_ERR_ALIGN, "ln_modulate: rows must be 16-byte aligned");
   const long long rows = (long long)B * S;
+  if (D == 3072 && rows >= 4096) {  // the model's width, enough rows to fill the chip with 4 waves x 4 rows per workgroup
+    hipLaunchKernelGGL((ln_rows_kernel<6, 4>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)X, x_bs, ldx, (bf16_t*)Y, y_bs,
+                       ldy, S, S0, shift0 ? shift0 : shift1, scale0 ? scale0 : scale1, shift1, scale1, mod_bs, eps, rows);
+    return x2i_check_launch("ln_modulate");
+  }
   hipLaunchKernelGGL(ln_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)X, x_bs, ldx,
                      (bf16_t*)Y, y_bs, ldy, S, D, S0, shift0 ? shift0 : shift1, scale0 ? scale0 : scale1, shift1, scale1, mod_bs,
                      (const bf16_t*)nullptr, (const bf16_t*)nullptr, eps, rows);

@@ -94,12 +94,12 @@ __global__ __launch_bounds__(256) void ln_fp8_kernel(const bf16_t* __restrict__ 
     if (c < nv) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float d = v[i][j] - mean;
-        sq += d * d;
+        const float d = __fsub_rn(v[i][j], mean);
+        sq = __builtin_fmaf(d, d, sq);
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  const float rstd = rsqrtf(__fadd_rn(wave_sum(sq) / (float)D, eps));
   const float* sh = (s < S0 ? shift0 : shift1) + (long long)b * mod_bs;
   const float* sc = (s < S0 ? scale0 : scale1) + (long long)b * mod_bs;
   float amax = 0.f;
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void ln_fp8_kernel(const bf16_t* __restrict__ 
       const f32x4_t h0 = *(const f32x4_t*)(sh + c * 8), h1 = *(const f32x4_t*)(sh + c * 8 + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[i][j] = (v[i][j] - mean) * rstd * (1.f + s0[j]) + h0[j];
-        v[i][j + 4] = (v[i][j + 4] - mean) * rstd * (1.f + s1[j]) + h1[j];
+        v[i][j] = ln_mod1(v[i][j], mean, rstd, s0[j], h0[j]);
+        v[i][j + 4] = ln_mod1(v[i][j + 4], mean, rstd, s1[j], h1[j]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[i][j]));

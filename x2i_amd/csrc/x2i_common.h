@@ -84,6 +84,11 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float z = x * __builtin_fmaf(x * x, -0.10294324f, -2.3022082f);
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
+// LayerNorm(no affine) * (1 + scale) + shift of one element, operation by operation (shared by ln_kernel, ln_rows_kernel and
+// ln_fp8_kernel, whose bf16 outputs must agree bit for bit)
+__device__ __forceinline__ float ln_mod1(float v, float mean, float rstd, float sc, float sh) {
+  return __builtin_fmaf(__fmul_rn(__fsub_rn(v, mean), rstd), __fadd_rn(1.f, sc), sh);
+}
 // RMSNorm statistics and normalise + interleaved-pair RoPE of a lane's 8 dims, with every fused / unfused operation spelled out: the
 // fused QKV epilogues of the GEMM kernels and x2i_qkv_split_bf16 must round identically (bit-exact tests, batch independence), which
 // a contractable `a * c - b * s` only does as long as the compiler happens to contract it the same way in every surrounding
