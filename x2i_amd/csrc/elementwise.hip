@@ -237,10 +237,12 @@ template <int NB>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restrict__ Xv, int x_is_bf16, const bf16_t* __restrict__ W,
                                                             const bf16_t* __restrict__ bias, float* __restrict__ Y, int ldy, int N,
                                                             int K, int act_in, int act_out, int accumulate, int rpw) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [K][NB]: the NB samples' values of one k side by side
   for (int i = threadIdx.x; i < NB * K; i += 256) {
+    const int b = i / K, k = i - b * K;
     float v = x_is_bf16 ? bf16_to_f32(((const bf16_t*)Xv)[i]) : ((const float*)Xv)[i];
-    xs[i] = apply_act(v, act_in);
+    xs[k * NB + b] = apply_act(v, act_in);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -249,37 +251,52 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restri
   // R = 4 weight rows are streamed together: 4 x (K/512) independent 16-byte loads in flight per lane (a single row
   // would leave the wave latency-bound on HBM)
   constexpr int R = 4;
+  constexpr int NP = NB / 2;  // sample pairs: one packed fma (v_pk_fma_f32) carries two samples' chains
 #pragma unroll 1
   for (int rr = 0; rr < rpw; rr += R) {
     const int n0 = n_base + rr;
     if (n0 >= N) break;
     float acc[R][NB];
+    f32x2 acc2[R][NP > 0 ? NP : 1];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) acc2[r][q] = f32x2{0.f, 0.f};
+    }
     for (int k = lane * 8; k < K; k += 512) {
       bf16x8_t wv[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int n = min(n0 + r, N - 1);  // clamp: rows past N are computed and discarded
-        wv[r] = *(const bf16x8_t*)(W + (long long)n * K + k);
+        wv[r] = __builtin_nontemporal_load((const bf16x8_t*)(W + (long long)n * K + k));  // read once: do not keep it in the caches
       }
+      float wf[R][8];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const f32x4_t x0 = *(const f32x4_t*)(xs + b * K + k), x1 = *(const f32x4_t*)(xs + b * K + k + 4);
+      for (int r = 0; r < R; ++r) unpack8(wv[r], wf[r]);
+      // explicit fma chains, k ascending: the arithmetic of one sample must not depend on how many samples share the launch (a packed
+      // fma is two independent fmas)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float wf[8];
-          unpack8(wv[r], wf);
-          // explicit fma chain: the arithmetic of one sample must not depend on how many samples share the launch
-          float a = acc[r][b];
-          a = fmaf(wf[0], x0[0], a); a = fmaf(wf[1], x0[1], a); a = fmaf(wf[2], x0[2], a); a = fmaf(wf[3], x0[3], a);
-          a = fmaf(wf[4], x1[0], a); a = fmaf(wf[5], x1[1], a); a = fmaf(wf[6], x1[2], a); a = fmaf(wf[7], x1[3], a);
-          acc[r][b] = a;
+      for (int j = 0; j < 8; ++j) {
+        const float* xk = xs + (k + j) * NB;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const f32x2 x2 = *(const f32x2*)(xk + 2 * q);
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc2[r][q] = __builtin_elementwise_fma(f32x2{wf[r][j], wf[r][j]}, x2, acc2[r][q]);
+        }
+        if constexpr (NB & 1) {
+          const float x1 = xk[NB - 1];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r][NB - 1] = fmaf(wf[r][j], x1, acc[r][NB - 1]);
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) { acc[r][2 * q] = acc2[r][q][0]; acc[r][2 * q + 1] = acc2[r][q][1]; }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
