@@ -294,8 +294,9 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) __builtin_amdgcn_raw_buffer_store_b128(outv[ps], q_rsrc, so[ps], 0, 0);
       });
-      // (parking the next chunk HERE, behind this chunk's stores: in front of the compute it would hide one more LDS round trip, but
-      // that order miscompiles -- wrong accumulators reach the epilogue, Q / K / V^T all differ; tools/qkv_persistent_vs_onetile.py)
+      // (parking the next chunk HERE, behind this chunk's stores.  In front of the compute it would hide one more LDS round trip, but
+      // with that order the kernel's Q, K AND V^T all come out wrong -- deterministically, also with a full LDS wait behind the park and
+      // with M0 declared clobbered -- for a reason not found; tools/qkv_persistent_vs_onetile.py is the check)
       if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
     });
   } else {
