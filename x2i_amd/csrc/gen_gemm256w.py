@@ -292,6 +292,10 @@ def generate_persistent(aux_a="", aux_w=""):
     MC = ["s_nop 4", "s_add_u32 %[koff], %[k0b], 256", "s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[zs], 0", "s_cbranch_scc1 5f",
           "s_cmp_lg_u32 %[it], 0", "s_cbranch_scc0 2f", "s_branch 1f", "5:"]
     MC += a0 + ["s_cbranch_scc0 2f", "1:"] + bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
+    # The last body has requested the NEXT unit's first fragments (ds_read into the FRAG0 operands).  They must have landed when the
+    # statement ends: the compiler is free to copy or spill those registers between two statements (the fused-QKV instantiation does
+    # spill), and a copy taken while the LDS data is still in flight carries stale values into the next unit's first MFMAs.
+    MC += ["s_waitcnt lgkmcnt(0)"]
     MZ = None
     D = ["s_waitcnt vmcnt(0)", "s_barrier"]
     return P, MC, MZ, D, counts[0]
