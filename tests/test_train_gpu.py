@@ -378,7 +378,7 @@ def test_distill_step_end_to_end_loss_decreases_and_matches_autograd():
     assert losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 2, 200), (2, 3, 192), (1, 1, 64), (1, 2, 333 // 8 * 8)])
+@pytest.mark.parametrize("B,H,S", [(1, 2, 200), (2, 3, 192), (1, 1, 64), (1, 2, 333 // 8 * 8), (1, 2, 640)])
 def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     """x2i_attention_bwd_bf16 (statistics pass, dQ pass, dK / dV pass) against torch autograd through fp32 softmax attention on the same
     bf16 operands; ragged sequence lengths (S % 64 != 0, S % 128 != 0) exercise the key mask and the row neutralisation."""
@@ -426,6 +426,15 @@ def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ2, dK2, dV2, B, H, S, Spad, scale, have_lse=True)
     for a, b_ in ((dQ2, dQ), (dK2, dK), (dV2, dV)):
         assert rel_l2(a[:, :, :S], b_[:, :, :S].float().cpu()) < 2e-3
+    # the dQ pass with 64 query rows per wave (default) against the 32-row form: the same arithmetic per row, bit for bit
+    from x2i_amd import _lib
+    old = _lib.set_option("attn_bwd_dq64", 0)
+    try:
+        dQ3, dK3, dV3 = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
+        ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ3, dK3, dV3, B, H, S, Spad, scale, have_lse=True)
+    finally:
+        _lib.set_option("attn_bwd_dq64", old)
+    assert torch.equal(dQ3, dQ2) and torch.equal(dK3, dK2) and torch.equal(dV3, dV2)
 
 
 def test_full_width_distillation_gradient_vs_oracle_autograd():

@@ -357,6 +357,164 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// dQ with 64 persistent query rows per wave (two 32-row blocks qb): every streamed fragment feeds TWO MFMAs, so the LDS traffic per
+// MFMA is half that of attn_bwd_kernel<0> (whose one-fragment-per-MFMA stream sits at the LDS roof with the matrix pipe half idle).
+// 256 query rows per workgroup; same tiles, fragments, arithmetic and rounding per row as the 32-row form (bit-identical results).
+__device__ __forceinline__ void dq64_tile(const char* __restrict__ cur, char* __restrict__ nxt, bool issue, int s_next, int s0, const Rsrc4& R,
+                                          const int (&row_src)[4], const int (&col_src)[4], int wave, const Geo& G, const bf16x8_t (&pa)[2][8],
+                                          const bf16x8_t (&pb)[2][8], const float (&myL)[2], const float (&myD)[2], int S, float scale_log2,
+                                          f32x16_t (&oacc)[2][4]) {
+  if (issue) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* dst = nxt + (j * 256 + wave * 64) * 16;
+      dma16(R.a, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
+      dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst + TILE);
+      dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst + 2 * TILE);
+    }
+  }
+  f32x16_t sacc[2][2], dacc[2][2];   // [qb][sub-tile u]
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[qb][u][r] = 0.f; dacc[qb][u][r] = 0.f; }
+  {  // scores S^T = K Q^T and dP^T = V dO^T as one fragment pipeline (steps 0-3: K tile, 4-7: V tile)
+    bf16x8_t fr[2][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fr[0][f] = row_frag(cur, G, 0, f);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      if (st + 1 < 8) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fr[(st + 1) & 1][f] = row_frag(st + 1 < 4 ? cur : cur + TILE, G, (st + 1) & 3, f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int g = st & 3;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          if (st < 4) sacc[qb][f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][f], pa[qb][2 * g + (f >> 1)], sacc[qb][f & 1], 0, 0, 0);
+          else dacc[qb][f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][f], pb[qb][2 * g + (f >> 1)], dacc[qb][f & 1], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  bf16x8_t fr[2][4];   // first fragments of the accumulation pipeline: in flight while the element-wise section runs
+#pragma unroll
+  for (int db = 0; db < 4; ++db) fr[0][db] = col_frag(cur + 2 * TILE, G, 0, db);
+  bf16x8_t dsf[2][2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = s0 + u * 32 + 16 * (r >> 3) + 8 * G.hi + (r & 7);
+        const float p = key < S ? __builtin_amdgcn_exp2f(sacc[qb][u][r] * scale_log2 - myL[qb]) : 0.f;
+        dacc[qb][u][r] = p * (dacc[qb][u][r] - myD[qb]);
+      }
+    pack_frags(dacc[qb], dsf[qb]);
+  }
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {   // dQ^T += K^T dS^T
+    if (st + 1 < 4) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) fr[(st + 1) & 1][db] = col_frag(cur + 2 * TILE, G, st + 1, db);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+        oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st & 1][db], dsf[qb][st >> 1][st & 1], oacc[qb][db], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT, const float* __restrict__ L2,
+                                                              const float* __restrict__ Dv, bf16_t* __restrict__ dQ, int H, int S, int Spad,
+                                                              float scale, float scale_log2, int nbatch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 3 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Geo G;
+  G.hi = lane >> 5; G.li = lane & 31;
+  {
+    const int kvm = (G.li & 0x13) | ((G.li & 4) << 1) | ((G.li & 8) >> 1);
+    G.k_row_off = kvm * 256; G.k_swz = kvm & 15; G.v_row_off = G.li * 128; G.v_swz = (G.li >> 1) & 7;
+  }
+  const int nblk = (Spad + 255) / 256;
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int blk = bid % nblk, h = (bid / nblk) % H, b = bid / (nblk * H);
+  const long long bh = (long long)b * H + h;
+  const long long hoff = bh * Spad * 128;
+  bf16x8_t pa[2][8], pb[2][8];
+  float myL[2], myD[2];
+  int r0[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    r0[qb] = blk * 256 + wave * 64 + qb * 32 + G.li;   // this lane's persistent query rows
+    const int rr = min(r0[qb], Spad - 1);              // (rows behind Spad -- a last, half block -- read a valid row and are never stored)
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      pa[qb][ds] = *(const bf16x8_t*)(Q + hoff + (long long)rr * 128 + ds * 16 + G.hi * 8);
+      pb[qb][ds] = *(const bf16x8_t*)(dO + hoff + (long long)rr * 128 + ds * 16 + G.hi * 8);
+    }
+    myL[qb] = L2[bh * Spad + rr];
+    myD[qb] = Dv[bh * Spad + rr];
+  }
+  int row_src[4], col_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + tid;
+    { const int row = p >> 4, c = p & 15; row_src[j] = row * 128 + ((c ^ (row & 15)) << 3); }
+    { const int row = p >> 3, c = p & 7; col_src[j] = row * Spad + ((c ^ ((row >> 1) & 7)) << 3); }
+  }
+  Rsrc4 R;
+  {
+    const uint32_t bytes = (uint32_t)Spad * 256u;
+    R.a = __builtin_amdgcn_make_buffer_rsrc((void*)(K + hoff), 0, bytes, 0x00020000);
+    R.b = __builtin_amdgcn_make_buffer_rsrc((void*)(V + hoff), 0, bytes, 0x00020000);
+    R.c = __builtin_amdgcn_make_buffer_rsrc((void*)(KT + hoff), 0, bytes, 0x00020000);
+    R.d = R.c;
+  }
+  f32x16_t oacc[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+  const int nt = (S + KVB - 1) / KVB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    char* dst = smem + (j * 256 + wave * 64) * 16;
+    dma16(R.a, (uint32_t)(row_src[j] * 2), dst);
+    dma16(R.b, (uint32_t)(row_src[j] * 2), dst + TILE);
+    dma16(R.c, (uint32_t)(col_src[j] * 2), dst + 2 * TILE);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    dq64_tile(smem + buf * STAGE, smem + (buf ^ 1) * STAGE, t + 1 < nt, (t + 1) * KVB, t * KVB, R, row_src, col_src, wave, G, pa, pb, myL, myD, S,
+              scale_log2, oacc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) store_rows(dQ + hoff + (long long)r0[qb] * 128, oacc[qb], scale, G.hi, r0[qb] < S);
+}
+
 // D[b][h][s] = sum_d dO[b][s][h*128 + d] * O[b][s][h*128 + d] for s < S, 0 for the padding rows; 16 lanes x 8 elements per (token, head)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, long long do_bs, int lddo, const bf16_t* __restrict__ O,
                                                             long long o_bs, int ldo, float* __restrict__ Dv, int H, int S, int Spad) {
@@ -394,7 +552,13 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)nullptr, (bf16_t*)nullptr, H, S,
                        Spad, scale, scale_log2, B);
   }
-  {
+  if (x2i_options().attn_bwd_dq64) {  // dQ: 64 query rows per wave (attn_bwd_dq64_kernel); option 0 = the 32-row form (A/B, bit-identical)
+    const int shm = 2 * 3 * TILE;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dq64_kernel, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3(((Spad + 255) / 256) * H * B), dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)dOh,
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)KT, L2, Dv, (bf16_t*)dQ, H, S, Spad, scale, scale_log2, B);
+  } else {
     const int shm = 2 * 3 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<0>, shm);
     if (rc) return rc;
