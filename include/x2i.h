@@ -55,7 +55,8 @@ const char* x2i_last_error(void);
  * through a per-device workspace -- bit-identical to the one-tile kernel.  ONE workspace per device: two GEMM launches that both
  * take this path must not run concurrently on different streams of one device; a caller that overlaps GEMMs across streams sets 0,
  * which restores the peeled 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
- * "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
+ * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
+ * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
  * "gemm_sk_error" (read-only: non-zero after a chained segment gave up waiting for its
  * predecessor -- never observed; the result of that launch is then undefined), "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
  * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale), "conv5_variant" (0),

@@ -552,19 +552,28 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)nullptr, (bf16_t*)nullptr, H, S,
                        Spad, scale, scale_log2, B);
   }
+  // The dQ pass and the dK / dV pass are independent (both read Q, K, V, dO and the statistics; they write different tensors) and each
+  // ends in a partly filled round of one-workgroup-per-CU blocks (B = 1: 1.7 and 3.4 rounds): dQ goes to a side stream, forked and
+  // joined by events, so that the two launches fill each other's tails.  (Option attn_bwd_overlap = 0: one after the other.)
+  hipStream_t side = stream;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const bool overlap = x2i_options().attn_bwd_overlap && x2i_side_stream(stream, &side, &ev_fork, &ev_join) &&
+                       hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
+  hipStream_t qs = overlap ? side : stream;
   if (x2i_options().attn_bwd_dq64) {  // dQ: 64 query rows per wave (attn_bwd_dq64_kernel); option 0 = the 32-row form (A/B, bit-identical)
     const int shm = 2 * 3 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dq64_kernel, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3(((Spad + 255) / 256) * H * B), dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)dOh,
+    hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3(((Spad + 255) / 256) * H * B), dim3(256), shm, qs, (const bf16_t*)Q, (const bf16_t*)dOh,
                        (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)KT, L2, Dv, (bf16_t*)dQ, H, S, Spad, scale, scale_log2, B);
   } else {
     const int shm = 2 * 3 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<0>, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_bwd_kernel<0>), grid, dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)dOh, (const bf16_t*)K, (const bf16_t*)V,
+    hipLaunchKernelGGL((attn_bwd_kernel<0>), grid, dim3(256), shm, qs, (const bf16_t*)Q, (const bf16_t*)dOh, (const bf16_t*)K, (const bf16_t*)V,
                        (const bf16_t*)KT, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)dQ, (bf16_t*)nullptr, H, S, Spad, scale, scale_log2, B);
   }
+  if (overlap) (void)hipEventRecord(ev_join, side);
   {
     const int shm = 2 * 4 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<1>, shm);
@@ -572,6 +581,7 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
     hipLaunchKernelGGL((attn_bwd_kernel<1>), grid, dim3(256), shm, stream, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Q, (const bf16_t*)dOh,
                        (const bf16_t*)dOT, (const bf16_t*)QT, L2, Dv, (bf16_t*)dV, (bf16_t*)dK, H, S, Spad, scale, scale_log2, B);
   }
+  if (overlap) (void)hipStreamWaitEvent(stream, ev_join, 0);
   return x2i_check_launch("attention_bwd");
 }
 

@@ -45,6 +45,7 @@ X2IOptions make_options() {
   o.gemm_persist = env_int("X2I_GEMM_PERSIST", 1);
   o.gemm_streamk = env_int("X2I_GEMM_STREAMK", 1);
   o.gemm_pair = env_int("X2I_GEMM_PAIR", 1);
+  o.attn_bwd_overlap = env_int("X2I_ATTN_BWD_OVERLAP", 1);
   o.attn_bwd_dq64 = env_int("X2I_ATTN_BWD_DQ64", 1);
   o.conv256 = env_int("X2I_CONV256", 1);
   o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
@@ -143,6 +144,39 @@ void x2i_streamk_mark_used(hipStream_t stream) {
   if (w.last_done) (void)hipEventRecord(w.last_done, stream);
 }
 
+// A second stream per device for launches that are independent of each other (the dQ and the dK / dV pass of the attention backward):
+// fork / join by events, which is also the form a stream capture accepts.  Created on first use outside a capture; returns false when
+// it is not available (the caller then issues its launches one after the other on its own stream).
+namespace {
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool failed = false;
+};
+SideStream g_side[64];
+std::mutex g_side_mu;
+}  // namespace
+
+bool x2i_side_stream(hipStream_t main, hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream& w = g_side[dev];
+  if (!w.s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone || w.failed) { (void)hipGetLastError(); return false; }
+    if (hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&w.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&w.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      w.s = nullptr; w.failed = true;
+      return false;
+    }
+  }
+  *side = w.s; *fork = w.fork; *join = w.join;
+  return true;
+}
+
 int x2i_streamk_error_marker() {
   int dev = 0;
   hipGetDevice(&dev);
@@ -159,7 +193,7 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(attn_bwd_dq64) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(attn_bwd_overlap) X2I_OPT_INT(attn_bwd_dq64) X2I_OPT_INT(conv256) X2I_OPT_INT(attn_variant) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
   X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate)
 #endif

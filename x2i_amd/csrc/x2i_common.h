@@ -28,6 +28,7 @@ struct X2IOptions {
   int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
   int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
   int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
+  int attn_bwd_overlap;   // 1 = the dQ pass runs on a side stream beside the dK / dV pass (their partly filled last rounds fill each other)
   int attn_bwd_dq64;      // 1 = the dQ pass of the attention backward keeps 64 query rows per wave (0: 32, A/B; bit-identical)
   int gemm_pair;          // 1 = x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 issue ONE grouped persistent launch when they can (0: always two launches)
   int gemm_streamk;       // 1 = the persistent kernel splits the tiles of a partly filled last round along K (chained partial accumulators,
@@ -50,6 +51,7 @@ int x2i_ensure_dynamic_smem(const void* kernel, int bytes);
 int x2i_num_cus();  // compute units of the current device (cached)
 // per-device workspace of the stream-K GEMM (partial-accumulator slabs + progress flags), allocated on first use outside stream
 // capture; returns false when it cannot be provided for this launch (first use inside a capture): the caller keeps whole tiles.
+bool x2i_side_stream(hipStream_t main, hipStream_t* side, hipEvent_t* fork, hipEvent_t* join);
 bool x2i_streamk_workspace(hipStream_t stream, float** slabs, unsigned** flags);
 void x2i_streamk_mark_used(hipStream_t stream);  // call behind a launch that used the workspace
 int x2i_streamk_error_marker();
