@@ -124,12 +124,12 @@ static bool streamk_for(long long tiles, int nkt, int cus, hipStream_t stream, f
 int x2i_launch_gemm_pair(const x2i_gemm_args* a0, const x2i_qkv_desc* q0, const x2i_gemm_args* a1, const x2i_qkv_desc* q1, hipStream_t stream) {
   if (!a0 || !a1 || ((q0 != nullptr) != (q1 != nullptr))) return x2i_set_error(X2I_ERR_ARG, "gemm_pair: null pointer / mixed kinds");
   X2IOptions& opt = x2i_options();
-  auto plain = [](const x2i_gemm_args* a) { return a->A && a->W && a->M > 0 && a->N >= 256 && a->K > 0 && a->batch > 0 && !a->C2 && !a->out_f32 && !a->bias2 && a->M >= 256; };
+  auto plain = [](const x2i_gemm_args* a) { return a->A && a->W && a->M > 0 && a->N >= 256 && a->K > 0 && a->batch > 0 && !a->out_f32 && !a->bias2 && a->M >= 256; };
   bool ok = opt.gemm_pair && opt.gemm_tile == 0 && plain(a0) && plain(a1) && a0->K == a1->K && a0->act == a1->act &&
-            ((a0->res != nullptr) == (a1->res != nullptr)) && (q0 || (a0->C && a1->C)) && persistent_ok(a0, q0) && persistent_ok(a1, q1);
+            ((a0->res != nullptr) == (a1->res != nullptr)) && ((a0->C2 != nullptr) == (a1->C2 != nullptr)) && (q0 || (a0->C && a1->C)) && persistent_ok(a0, q0) && persistent_ok(a1, q1);
   if (ok && q0) ok = check_qkv_desc(a0, q0, "gemm_qkv_pair") == X2I_OK && check_qkv_desc(a1, q1, "gemm_qkv_pair") == X2I_OK && (q0->H * 128) % BN2 == 0 && (q1->H * 128) % BN2 == 0;
   if (ok && a0->gate && !a0->res) ok = false;
-  kern2_t kern = ok ? pick_gemm256p_pair(a0->act, a0->res != nullptr, q0 != nullptr) : nullptr;
+  kern2_t kern = ok ? pick_gemm256p_pair(a0->act, a0->res != nullptr, q0 != nullptr, a0->C2 != nullptr) : nullptr;
   if (!kern) {
     const int rc = q0 ? x2i_launch_gemm_qkv(a0, q0, stream) : x2i_launch_gemm(a0, stream);
     if (rc) return rc;

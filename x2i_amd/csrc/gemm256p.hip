@@ -637,8 +637,9 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
 kern_t pick_gemm256p_qkv() { return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true>; }
 
 // grouped (two-problem) forms: the layer types of a double-stream block
-kern2_t pick_gemm256p_pair(int act, bool res, bool qkv) {
+kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2) {
   if (qkv) return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true, true>;
+  if (c2) return (act == X2I_ACT_NONE && !res) ? (kern2_t)gemm256p_bf16_kernel<X2I_ACT_NONE, false, true, false, true> : nullptr;
   if (res) return act == X2I_ACT_NONE ? (kern2_t)gemm256p_bf16_kernel<X2I_ACT_NONE, true, false, false, true> : nullptr;
   if (act == X2I_ACT_GELU_TANH) return gemm256p_bf16_kernel<X2I_ACT_GELU_TANH, false, false, false, true>;
   if (act == X2I_ACT_NONE) return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, false, true>;

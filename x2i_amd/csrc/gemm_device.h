@@ -480,7 +480,7 @@ kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop, persistent over output tiles (gemm256p.hip)
 kern_t pick_gemm256p_qkv();                                 // ... with the fused QKV epilogue (x2i_gemm_qkv_bf16)
-kern2_t pick_gemm256p_pair(int act, bool res, bool qkv);     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
+kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
 constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION

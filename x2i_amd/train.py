@@ -144,19 +144,19 @@ class DistillBackward:
             sv = dict(Xin=self._keep(p + ".Xin", X))
             ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
             qkv = self._buf(p + ".QKV", (B * S, 3 * D))
-            ops.gemm(NRM, f[p + ".qkv.w"], f[p + ".qkv.b"], out=qkv, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
-                     c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off)
-            ops.gemm(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], out=qkv, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=St * 3 * D,
-                     ldc=3 * D)
+            ops.gemm_pair(dict(A=NRM, W=f[p + ".qkv.w"], bias=f[p + ".qkv.b"], out=qkv, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                               a_offset=St * D, c_batch_stride=Si * 3 * D, ldc=3 * D, c_offset=qkv_img_off),
+                          dict(A=NRM, W=f[p + ".cqkv.w"], bias=f[p + ".cqkv.b"], out=qkv, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                               c_batch_stride=St * 3 * D, ldc=3 * D))
             ops.qkv_split(qkv, qkv.view(-1)[qkv_img_off:], 3 * D, 3 * D, B, S, St, H, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
                           f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, Q, K, VT, Spad)
             sv["L"] = self._buf(p + ".L", (B, H, Spad), torch.float32)
             ops.attention_lse(Q, K, VT, ATT, sv["L"], B, H, S, Spad, D, S * D, scale)
             OP = self._buf(p + ".OP", (B, S, D))
-            ops.gemm(ATT, f[p + ".to_out.w"], f[p + ".to_out.b"], out=OP, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
-                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
-            ops.gemm(ATT, f[p + ".to_add_out.w"], f[p + ".to_add_out.b"], out=OP, M=St, batch=B, a_batch_stride=S * D, lda=D,
-                     c_batch_stride=S * D, ldc=D)
+            ops.gemm_pair(dict(A=ATT, W=f[p + ".to_out.w"], bias=f[p + ".to_out.b"], out=OP, M=Si, batch=B, a_batch_stride=S * D, lda=D,
+                               a_offset=St * D, c_batch_stride=S * D, ldc=D, c_offset=St * D),
+                          dict(A=ATT, W=f[p + ".to_add_out.w"], bias=f[p + ".to_add_out.b"], out=OP, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                               c_batch_stride=S * D, ldc=D))
             sv["O"] = self._keep(p + ".O", ATT)                             # attention output (rowsum(dO * O) of the fused attention backward)
             sv["Gimg"] = tap(0, i, OP, Si, D, offset_rows=St)   # reference lists[0]: image-stream attention output
             sv["Gtxt"] = tap(1, i, OP, St, D, offset_rows=0)    # lists[1]: text-stream attention output
@@ -167,15 +167,16 @@ class DistillBackward:
             PRE = self._buf(p + ".PRE", (B * S, 4 * D))   # text rows [B*St] first, image rows behind (as CAT in denoise)
             Hh = self._buf("Hh", (B * S, 4 * D))
             ff_img = B * St * 4 * D
-            ops.gemm(NRM, f[p + ".ff.0.w"], f[p + ".ff.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=Si, batch=B, a_batch_stride=S * D, lda=D,
-                     a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img)
-            ops.gemm(NRM, f[p + ".ff_context.0.w"], f[p + ".ff_context.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=St, batch=B,
-                     a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D, ldc=4 * D)
+            ops.gemm_pair(dict(A=NRM, W=f[p + ".ff.0.w"], bias=f[p + ".ff.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=Si, batch=B,
+                               a_batch_stride=S * D,
+                               lda=D, a_offset=St * D, c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img),
+                          dict(A=NRM, W=f[p + ".ff_context.0.w"], bias=f[p + ".ff_context.0.b"], out=PRE, out2=Hh, act2=ACT_GELU_TANH, M=St, batch=B,
+                               a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D, ldc=4 * D))
             FF = self._buf(p + ".FF", (B, S, D))
-            ops.gemm(Hh, f[p + ".ff.2.w"], f[p + ".ff.2.b"], out=FF, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, a_offset=ff_img,
-                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
-            ops.gemm(Hh, f[p + ".ff_context.2.w"], f[p + ".ff_context.2.b"], out=FF, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D,
-                     c_batch_stride=S * D, ldc=D)
+            ops.gemm_pair(dict(A=Hh, W=f[p + ".ff.2.w"], bias=f[p + ".ff.2.b"], out=FF, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D,
+                               a_offset=ff_img, c_batch_stride=S * D, ldc=D, c_offset=St * D),
+                          dict(A=Hh, W=f[p + ".ff_context.2.w"], bias=f[p + ".ff_context.2.b"], out=FF, M=St, batch=B, a_batch_stride=St * 4 * D,
+                               lda=4 * D, c_batch_stride=S * D, ldc=D))
             ops.gated_residual_(X, FF, mod(oi + 5 * D), B, Si, D, S * D, D, S * D, D, Ntot, x_offset=St * D, t_offset=St * D)
             ops.gated_residual_(X, FF, mod(oc + 5 * D), B, St, D, S * D, D, S * D, D, Ntot)
             sv.update(PRE=PRE, FF=FF)
@@ -357,32 +358,34 @@ class DistillBackward:
             gate_bwd(d_["FF"], None, oc + 5 * D, 0, St)
             dH = self._buf("dH", (B * S, 4 * D))
             ff_img = B * St * 4 * D
-            ops.gemm(dT, self._wt(p + ".ff.2.w"), out=dH, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
-                     c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img)
-            ops.gemm(dT, self._wt(p + ".ff_context.2.w"), out=dH, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=St * 4 * D,
-                     ldc=4 * D)
+            ops.gemm_pair(dict(A=dT, W=self._wt(p + ".ff.2.w"), out=dH, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                               c_batch_stride=Si * 4 * D, ldc=4 * D, c_offset=ff_img),
+                          dict(A=dT, W=self._wt(p + ".ff_context.2.w"), out=dH, M=St, batch=B, a_batch_stride=S * D, lda=D,
+                               c_batch_stride=St * 4 * D, ldc=4 * D))
             ops.act_bwd_(dH, d_["PRE"], ACT_GELU_TANH)
-            ops.gemm(dH, self._wt(p + ".ff.0.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, a_offset=ff_img,
-                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
-            ops.gemm(dH, self._wt(p + ".ff_context.0.w"), out=dN, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D, c_batch_stride=S * D,
-                     ldc=D)
+            ops.gemm_pair(dict(A=dH, W=self._wt(p + ".ff.0.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 4 * D, lda=4 * D, a_offset=ff_img,
+                               c_batch_stride=S * D, ldc=D, c_offset=St * D),
+                          dict(A=dH, W=self._wt(p + ".ff_context.0.w"), out=dN, M=St, batch=B, a_batch_stride=St * 4 * D, lda=4 * D,
+                               c_batch_stride=S * D, ldc=D))
             ln_bwd(d_["Xmid"], oi + 4 * D, oi + 3 * D, St, Si)
             ln_bwd(d_["Xmid"], oc + 4 * D, oc + 3 * D, 0, St)
             # attention: x_mid = x_in + gate_msa * OP, OP = to_out(attention) -- the taps sit on OP
             gate_bwd(d_["OP"], d_["Gimg"], oi + 2 * D, St, Si)
             gate_bwd(d_["OP"], d_["Gtxt"], oc + 2 * D, 0, St)
             dATT = self._buf("dATT", (B, S, D))
-            ops.gemm(dT, self._wt(p + ".to_out.w"), out=dATT, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
-                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
-            ops.gemm(dT, self._wt(p + ".to_add_out.w"), out=dATT, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=S * D, ldc=D)
+            ops.gemm_pair(dict(A=dT, W=self._wt(p + ".to_out.w"), out=dATT, M=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
+                               c_batch_stride=S * D, ldc=D, c_offset=St * D),
+                          dict(A=dT, W=self._wt(p + ".to_add_out.w"), out=dATT, M=St, batch=B, a_batch_stride=S * D, lda=D, c_batch_stride=S * D,
+                               ldc=D))
             dQKV = self._buf("dQKV", (B * S, 3 * D))
             img = B * St * 3 * D
             self._attention_bwd(d_["QKV"], d_["QKV"].view(-1)[img:], 3 * D, St,
                                 (f[p + ".norm_added_q"], f[p + ".norm_added_k"], f[p + ".norm_q"], f[p + ".norm_k"]), dATT, D, dQKV,
                                 dQKV.view(-1)[img:], O=d_["O"], L=d_["L"])
-            ops.gemm(dQKV, self._wt(p + ".qkv.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 3 * D, lda=3 * D, a_offset=img,
-                     c_batch_stride=S * D, ldc=D, c_offset=St * D)
-            ops.gemm(dQKV, self._wt(p + ".cqkv.w"), out=dN, M=St, batch=B, a_batch_stride=St * 3 * D, lda=3 * D, c_batch_stride=S * D, ldc=D)
+            ops.gemm_pair(dict(A=dQKV, W=self._wt(p + ".qkv.w"), out=dN, M=Si, batch=B, a_batch_stride=Si * 3 * D, lda=3 * D, a_offset=img,
+                               c_batch_stride=S * D, ldc=D, c_offset=St * D),
+                          dict(A=dQKV, W=self._wt(p + ".cqkv.w"), out=dN, M=St, batch=B, a_batch_stride=St * 3 * D, lda=3 * D,
+                               c_batch_stride=S * D, ldc=D))
             ln_bwd(d_["Xin"], oi + D, oi, St, Si)
             ln_bwd(d_["Xin"], oc + D, oc, 0, St)
         # ---- embedders: text rows of dX -> context_embedder -> encoder_hidden_states
