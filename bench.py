@@ -8,6 +8,11 @@ i.e. everything between the MLLM and the VAE for a batch of images.  Workload at
 batch 4), random-init weights, synthetic inputs already resident in HBM.  N>1: weak scaling, the batch axis is
 sharded (batch 4 per rank), one all-gather of the final packed latents over RCCL.
 
+`python bench.py --gpus N` launches the N ranks ITSELF when it is not already running under a launcher (WORLD_SIZE unset): it
+re-executes this file under `python -m torch.distributed.run --standalone --nnodes=1 --nproc-per-node N` on 127.0.0.1; under a
+launcher (torchrun / the driver's torch.distributed.run command) it asserts WORLD_SIZE == --gpus.  The printed n_gpus is
+dist.get_world_size(), never the flag.
+
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = bf16 MFMA GEMM, measured live with HIP
 events on the launch stream) and "cpu_baseline" (the CPU oracle timed on the host cores on a bounded sample).
 """
@@ -37,116 +42,220 @@ def flops_per_denoise_step(B, St, Si, D=3072, L=19, Ls=38, Kj=4096, Cin=64, pool
     return emb + dbl + sgl + out
 
 
-def gemm_roofline(B, iters=10):
+class ClockPowerSampler:
+    """sclk / socket power of the bench GPU sampled by a host thread (amdsmi, ~100 Hz) while a probe runs, so that a roofline figure
+    carries the power state it was measured in (the part is power-capped: DESIGN.md section 4)."""
+
+    def __init__(self, index=0, period=0.01):
+        self.samples, self.period, self._stop, self._thr, self._h = [], period, False, None, None
+        try:
+            import amdsmi
+            self._smi = amdsmi
+            try:
+                amdsmi.amdsmi_init()
+            except Exception:  # noqa: BLE001  (already initialised)
+                pass
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._h = hs[index] if index < len(hs) else None
+        except Exception:  # noqa: BLE001
+            self._h = None
+
+    def _read(self):
+        smi, h = self._smi, self._h
+        clk = pw = None
+        try:
+            clk = float(smi.amdsmi_get_clock_info(h, smi.AmdSmiClkType.GFX)["clk"])
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            pi = smi.amdsmi_get_power_info(h)
+            for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                if k in pi and isinstance(pi[k], (int, float)) and pi[k] > 0:
+                    pw = float(pi[k])
+                    break
+        except Exception:  # noqa: BLE001
+            pass
+        return clk, pw
+
+    def __enter__(self):
+        if self._h is not None:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    self.samples.append(self._read())
+                    time.sleep(self.period)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=2)
+
+    def summary(self):
+        def stats(v):
+            v = sorted(x for x in v if x is not None)
+            return None if not v else dict(min=v[0], median=v[len(v) // 2], max=v[-1])
+        return dict(n=len(self.samples), sclk_mhz=stats([c for c, _ in self.samples]), socket_power_w=stats([p for _, p in self.samples]),
+                    source="amdsmi, host thread, %.0f ms period" % (self.period * 1e3) if self._h is not None else "unavailable")
+
+
+def _interleaved_probe(fns, rounds, per_round):
+    """fns: the launches of the roofline pair.  `rounds` rounds; in each, every shape is launched `per_round` times back to back between
+    its own pair of HIP events on the launch stream, the shapes alternating (so a slow clock phase hits both, not one).  Returns
+    per-shape lists of per-launch seconds (one entry per round) plus the clock / power record of the whole probe."""
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds)] for _ in fns]
+    for fn in fns:
+        for _ in range(3):
+            fn()
+    torch.cuda.synchronize()
+    with ClockPowerSampler(torch.cuda.current_device()) as smp:
+        for r in range(rounds):
+            for i, fn in enumerate(fns):
+                ev[i][r][0].record()
+                for _ in range(per_round):
+                    fn()
+                ev[i][r][1].record()
+        torch.cuda.synchronize()
+    times = [[e0.elapsed_time(e1) * 1e-3 / per_round for (e0, e1) in row] for row in ev]
+    return times, smp.summary()
+
+
+def _in_step_gemm_rate(B):
+    """GEMM FLOPs of the timed job / summed GEMM kernel time, from the COMMITTED rocprofv3 --kernel-trace --stats of this bench
+    (profiles/<tag>_bench_b4_1024_kernel_stats.csv: TotalDurationNs over every gemm* kernel of 1 warm-up + 2 timed passes = 12 denoise
+    steps): the rate of the dominant kernel INSIDE the step, which cannot drift with the state of a probe.  B = 4 only."""
+    import csv
+    import glob
+    if B != 4:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*_bench_b4_1024_kernel_stats.csv")))
+    if not files:
+        return None
+    path = files[-1]
+    t_ns, calls = 0.0, 0
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            name = row.get("Name", "")
+            if "gemm" in name and "fp8" not in name and "skinny" not in name:
+                t_ns += float(row["TotalDurationNs"])
+                calls += int(row["Calls"])
+    meta = path.replace("_kernel_stats.csv", "_kernel_stats.meta.json")
+    passes = 3
+    if os.path.exists(meta):
+        passes = int(json.load(open(meta)).get("passes", 3))
+    D, St, Si = 3072, 512, 4096
+    S = St + Si
+    gemm_fl = (2 * B * Si * 64 * D + 2 * B * St * 4096 * D + 19 * B * S * 2 * 12 * D * D + 38 * B * S * 2 * 12 * D * D + 2 * B * Si * D * 64)
+    gemm_fl += 2 * B * St * (2048 * 4096 + 4096 * 4096 + 4096 * 768) / 4     # the projector's three linears, once per 4-step pass
+    steps = 4 * passes
+    if t_ns <= 0:
+        return None
+    rate = gemm_fl * steps / (t_ns * 1e-9)
+    return dict(achieved=rate / 1e12, frac=rate / PEAK_BF16, unit="TFLOP/s", gemm_ms_per_denoise_step=t_ns * 1e-6 / steps, gemm_launches=calls,
+                source=os.path.relpath(path, ROOT), note="all MFMA GEMM launches of %d denoise steps (2*M*N*K of every nn.Linear of the DiT, SURVEY.md "
+                "Appendix C) / their summed rocprofv3 kernel time" % steps)
+
+
+def gemm_roofline(B, rounds=6, per_round=8):
     """Dominant kernel: the bf16 MFMA GEMM.  Times the two largest launch shapes of a single-stream block -- proj_mlp + bias + GELU
     (M=B*4608, N=12288, K=3072) and proj_out + bias (N=3072, K=15360; in the model this launch also adds the gated residual) -- with
-    HIP events on the launch stream; achieved = algorithmic FLOP / time.  (Same two launches since round 1, for comparability.)"""
+    HIP events on the launch stream; achieved = algorithmic FLOP / time.  (Same two launches since round 1, for comparability.)
+    Round 4: the two shapes are INTERLEAVED over `rounds` rounds x `per_round` launches; frac = the MEDIAN round, `frac_best` the fastest,
+    and the sclk / socket power sampled during the probe ride along, so that a box-to-box difference is explained by the record
+    itself (driver 0.51 vs builder 0.58 with equal whole-step rates)."""
     from x2i_amd import ops
     D, S = 3072, 4608
     B = min(B, 8)   # (the probe's flattened A operand must stay below the kernels' 2 GB operand limit: 8 x 4608 rows x 15360 x 2 B = 1.1 GB)
-    res = []
-    for (M, N, K, act) in ((B * S, 4 * D, D, 1), (B * S, D, 5 * D, 0)):
+    shapes = ((B * S, 4 * D, D, 1), (B * S, D, 5 * D, 0))
+    bufs, fns = [], []
+    for (M, N, K, act) in shapes:
         A = torch.randn(M, K, device="cuda").bfloat16()
         W = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
         bias = torch.randn(N, device="cuda").bfloat16()
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        for _ in range(3):
-            ops.gemm(A, W, bias, out=out, act=act)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        s.record()
-        for _ in range(iters):
-            ops.gemm(A, W, bias, out=out, act=act)
-        e.record()
-        torch.cuda.synchronize()
-        t = s.elapsed_time(e) / iters * 1e-3
-        res.append((2.0 * M * N * K, t))
-        del A, W, out
-    fl = sum(r[0] for r in res)
-    tt = sum(r[1] for r in res)
+        bufs.append((A, W, bias, out))
+        fns.append(lambda A=A, W=W, bias=bias, out=out, act=act: ops.gemm(A, W, bias, out=out, act=act))
+    times, power = _interleaved_probe(fns, rounds, per_round)
+    del bufs, fns
+    fl = [2.0 * M * N * K for (M, N, K, _) in shapes]
+    pair = sorted(times[0][r] + times[1][r] for r in range(rounds))      # per-round time of the pair
+    t_med, t_min, t_max = pair[len(pair) // 2], pair[0], pair[-1]
+    flt = sum(fl)
     # HBM-side traffic of the same two launches from the committed rocprofv3 PMC passes over tools/roofline_probe.py (tools/pmc_roofline.sh:
     # FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE, separate passes; per-launch means summed over every GEMM kernel the
     # pair launches; since round 3 that is ONE persistent 256^2 kernel per GEMM, its last round cut along K).  Only valid for the profiled batch (B=4 -> M=18432).
     traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r03_pmc_roofline.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]*_pmc_roofline.json"))) or [os.path.join(ROOT, "profiles", "r03_pmc_roofline.json")]
+    pj = cands[-1]
     if B == 4 and os.path.exists(pj):
         try:
             d = json.load(open(pj))
             traffic = float(d["traffic_bytes_per_pair"])
-            src = "profiles/r03_pmc_roofline.json (%s)" % d.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
+            src = "%s (%s)" % (os.path.relpath(pj, ROOT), d.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE"))
         except (KeyError, ValueError):
             traffic = None
-    alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K) in ((B * S, 4 * D, D), (B * S, D, 5 * D)))
-    return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_BF16,
+    alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K, _) in shapes)
+    return dict(bound="mfma", achieved=flt / t_med / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=flt / t_med / PEAK_BF16,
+                frac_best=flt / t_min / PEAK_BF16, frac_worst=flt / t_max / PEAK_BF16,
+                probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", statistic="median round (frac), fastest (frac_best)",
+                           us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times], clock_power=power),
+                in_step=_in_step_gemm_rate(B),
                 traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_bf16_kernel",
                 shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out shapes, 1.39 + 1.74 TFLOP; one persistent "
                        "256^2 launch each, last round cut along K)" % (B * S))
 
 
-def gemm_roofline_fp8(B, iters=10):
-    """--dtype fp8: the same two launches on the e4m3 kernel (gemm256_fp8_kernel: MX-scaled K=128 MFMA), priced against the 5 PF
-    dense fp8 peak.  proj_mlp + GELU writes e4m3, proj_out carries the gated residual, exactly as the fp8 model issues them."""
+def gemm_roofline_fp8(B, rounds=6, per_round=8):
+    """--dtype fp8: the same two launches on the e4m3 kernel (MX-scaled K=128 MFMA), priced against the 5 PF dense fp8 peak.
+    proj_mlp + GELU writes e4m3, proj_out carries the gated residual, exactly as the fp8 model issues them.  Same interleaved
+    median-of-rounds estimator as gemm_roofline()."""
     from x2i_amd import ops
     D, S = 3072, 4608
-    B = min(B, 8)   # (the probe's flattened A operand must stay below the kernels' 2 GB operand limit: 8 x 4608 rows x 15360 x 2 B = 1.1 GB)
-    res = []
-    for (M, N, K, gelu) in ((B * S, 4 * D, D, True), (B * S, D, 5 * D, False)):
+    B = min(B, 8)   # (the probe's flattened A operand must stay below the kernels' 2 GB operand limit)
+    shapes = ((B * S, 4 * D, D, True), (B * S, D, 5 * D, False))
+    fns, keep = [], []
+    for (M, N, K, gelu) in shapes:
         A8, sa = ops.quantize_rows_fp8(torch.randn(M, K, device="cuda").bfloat16())
         W8, sw = ops.quantize_rows_fp8((torch.randn(N, K, device="cuda") * 0.02).bfloat16())
         bias = torch.randn(N, device="cuda").bfloat16()
         out = torch.empty(M, N, device="cuda", dtype=ops.FP8 if gelu else torch.bfloat16)
         gate = torch.randn(1, N, device="cuda")
+        keep.append((A8, sa, W8, sw, bias, out, gate))
         if gelu:
-            fn = lambda: ops.gemm_fp8(A8, W8, bias, out=out, a_scale=sa, w_scale=sw, act=1, out_fp8=True)  # noqa: E731
+            fns.append(lambda A8=A8, W8=W8, bias=bias, out=out, sa=sa, sw=sw: ops.gemm_fp8(A8, W8, bias, out=out, a_scale=sa, w_scale=sw, act=1, out_fp8=True))
         else:
-            fn = lambda: ops.gemm_fp8(A8, W8, bias, out=out, w_scale=sw, res=out, gate=gate)  # noqa: E731
-        for _ in range(3):
-            fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        s.record()
-        for _ in range(iters):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        res.append((2.0 * M * N * K, s.elapsed_time(e) / iters * 1e-3))
-        del A8, W8, out
-    fl, tt = sum(r[0] for r in res), sum(r[1] for r in res)
+            fns.append(lambda A8=A8, W8=W8, bias=bias, out=out, sw=sw, gate=gate: ops.gemm_fp8(A8, W8, bias, out=out, w_scale=sw, res=out, gate=gate))
+    times, power = _interleaved_probe(fns, rounds, per_round)
+    kernel = "gemm256_fp8_kernel"
+    try:
+        from x2i_amd import _lib
+        if _lib.get_option("last_gemm_tile") in (8256, 9256):
+            kernel = "gemm256p_fp8_kernel"
+    except Exception:  # noqa: BLE001
+        pass
+    del fns, keep
+    fl = sum(2.0 * M * N * K for (M, N, K, _) in shapes)
+    pair = sorted(times[0][r] + times[1][r] for r in range(rounds))
+    t_med, t_min = pair[len(pair) // 2], pair[0]
     alg_bytes = (B * S * D + 4 * D * D + B * S * 4 * D) + (B * S * 5 * D + 5 * D * D + 2 * 2 * B * S * D)
-    traffic, src = None, None
-    pj = os.path.join(ROOT, "profiles", "r02d_pmc_gemm_attn.json")
-    if B == 4 and os.path.exists(pj):
-        d = json.load(open(pj))
-        try:
-            traffic = sum(d[k]["hbm_read_bytes_corrected"] + d[k]["hbm_write_bytes"]
-                          for k in ("gemm256_fp8_kernel<1, false, true> grid=1769472", "gemm256_fp8_kernel<0, true, false> grid=442368"))
-            src = "profiles/r02d_pmc_gemm_attn.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes; L2<->fabric bytes of both launches)"
-        except KeyError:
-            traffic = None
-    return dict(bound="mfma", achieved=fl / tt / 1e12, peak=PEAK_FP8 / 1e12, unit="TFLOP/s", frac=fl / tt / PEAK_FP8, traffic=traffic,
-                traffic_source=src, algorithmic_bytes=float(alg_bytes), kernel="gemm256_fp8_kernel",
+    return dict(bound="mfma", achieved=fl / t_med / 1e12, peak=PEAK_FP8 / 1e12, unit="TFLOP/s", frac=fl / t_med / PEAK_FP8,
+                frac_best=fl / t_min / PEAK_FP8, traffic=None, algorithmic_bytes=float(alg_bytes), kernel=kernel,
+                probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", clock_power=power,
+                           us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times]),
                 shapes="M=%d: N=12288,K=3072 (+GELU, e4m3 out) + N=3072,K=15360 (gated residual), e4m3 operands" % (B * S))
 
 
-def _pick_cpu_threads():
-    """torch's CPU GEMM peaks well below the logical core count in this container (cgroup quota / SMT): probe a few thread
-    counts on a short matmul and keep the fastest."""
-    a, b = torch.randn(1024, 3072), torch.randn(3072, 3072)
+def _cpu_threads(phys):
+    """Thread count of the CPU baseline: physical_cores / 2, pinned (a per-box sweep made the figure box-dependent; torch's
+    CPU GEMM peaks near half the physical cores on the 2-socket hosts of this pool), capped by the cores this process may use."""
     n_max = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    best, best_t = 1, 1e9
-    for n in (8, 16, 32, 64, 128, 256):
-        if n > n_max:
-            break
-        torch.set_num_threads(n)
-        torch.nn.functional.linear(a, b)
-        t0 = time.time()
-        for _ in range(3):
-            torch.nn.functional.linear(a, b)
-        dt = time.time() - t0
-        if dt < best_t:
-            best, best_t = n, dt
-    torch.set_num_threads(best)
-    return best, n_max
+    n = max(1, min(n_max, (phys // 2) if phys else max(1, n_max // 4)))
+    torch.set_num_threads(n)
+    return n, n_max
 
 
 def _physical_cores():
@@ -159,17 +268,18 @@ def _physical_cores():
         return None, "?"
 
 
-def cpu_baseline():
+def cpu_baseline(reps=3, budget_s=75.0):
     """The CPU oracle (restated reference path, fp32, torch eager) on the host cores.  MEASURED: one whole denoise step at 512 x 512,
     batch 1 -- 19 double-stream + 38 single-stream FLUX blocks at full width on 512 text + 1024 image tokens (21.5 TFLOP; SURVEY.md
     section 8(d)); the 57 blocks share one double-block and one single-block weight set (same arithmetic and bytes per block; generating
-    11.9 B random fp32 parameters on the host would take longer than the measurement).  EXTRAPOLATED and labelled so: the 1024 x 1024
+    11.9 B random fp32 parameters on the host would take longer than the measurement).  Timed `reps` times (fewer when the time budget
+    is spent), value = the median.  EXTRAPOLATED and labelled so: the 1024 x 1024
     step the GPU line is quoted on (74.4 TFLOP: 1 + 1 blocks timed on 512 + 4096 tokens, x19 / x38)."""
     from oracle import flux as OF
     from oracle import primitives as P
     from oracle import sampler as OS
-    threads, logical = _pick_cpu_threads()
     phys, cpu_name = _physical_cores()
+    threads, logical = _cpu_threads(phys)
     cfg = dict(OF.DEFAULT_CFG)
     cfg.update(num_layers=1, num_single_layers=1)
     sd = OF.random_flux_state_dict(cfg, seed=0)
@@ -191,22 +301,63 @@ def cpu_baseline():
             t_s = time.time() - t0
         return t_d, t_s
 
-    d512, s512 = blocks(32, 19, 38)          # measured: a whole 512^2 step
-    step512 = d512 + s512
+    steps, t_start = [], time.time()
+    for r in range(reps):                    # measured: whole 512^2 steps
+        d512, s512 = blocks(32, 19, 38)
+        steps.append(d512 + s512)
+        if time.time() - t_start + steps[-1] > budget_s:
+            break
+    st = sorted(steps)
+    step512 = st[len(st) // 2]
     d1k, s1k = blocks(64, 1, 1)              # 1 + 1 blocks at 1024^2, extrapolated below
     step1k = 19 * d1k + 38 * s1k
     return dict(value=1.0 / (4 * step512), unit="images/s (512x512, 4 steps, batch 1: MEASURED whole step)", cores=threads, kind="port",
-                physical_cores=phys, logical_cpus=logical, cpu=cpu_name,
-                sample="CPU oracle fp32 (torch eager, %d threads = fastest of a thread sweep; %s physical cores, %d logical CPUs visible): "
-                       "19 double + 38 single FLUX blocks at D=3072 on 512 txt + 1024 img tokens, batch 1, timed once = %.1f s per "
-                       "512x512 denoise step (21.5 TFLOP); 4 steps per image" % (threads, phys, logical, step512),
+                physical_cores=phys, logical_cpus=logical, cpu=cpu_name, repeats=len(steps), step_seconds=[round(x, 2) for x in steps],
+                sample="CPU oracle fp32 (torch eager, %d threads = physical cores / 2, pinned; %s physical cores, %d logical CPUs visible): "
+                       "19 double + 38 single FLUX blocks at D=3072 on 512 txt + 1024 img tokens, batch 1, timed %d x, median = %.1f s per "
+                       "512x512 denoise step (21.5 TFLOP); 4 steps per image" % (threads, phys, logical, len(steps), step512),
                 ms_per_denoise_step=step512 * 1e3,
                 extrapolated_1024=dict(value=1.0 / (4 * step1k), unit="images/s", ms_per_denoise_step=step1k * 1e3,
                                        note="1 double + 1 single block timed on 512 txt + 4096 img tokens (%.2f s + %.2f s), x19 / x38: "
                                             "the workload of the GPU line; an extrapolation, not a measurement" % (d1k, s1k)))
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_under_torchrun(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: become the launcher.  One process per GPU over RCCL on this node,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns the launcher's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what the host driver supports (RCCL needs it)
+    env["X2I_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def stub_workload(args, rank):
+    """--selftest-launcher: a CPU stand-in for the hot path (a few matmuls on a [B, 4096, 64] 'latent'), so that the launcher, the
+    gloo / RCCL rendezvous, the all-gather of the final latents, the barrier-bracketed max-over-ranks timing and the JSON contract can be
+    exercised without a GPU (tests/test_dist_cpu.py).  Its line says so in `metric` and `data`; it is never a bench figure."""
+    g = torch.Generator().manual_seed(100 + rank)
+    lat0 = torch.randn((args.batch, (args.size // 16) ** 2, 64), generator=g)
+    w = torch.randn((64, 64), generator=torch.Generator().manual_seed(1234)) / 8   # the same "weights" on every rank
+
+    def one_pass():
+        lat = lat0
+        for _ in range(args.denoise_steps):
+            lat = lat - 0.25 * torch.tanh(lat @ w)
+        return lat
+    return one_pass
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -217,6 +368,9 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config (1-based): 2 = Qwen-3B/shuttle-3 (default, the bench line), 3 = MiniCPM projector, "
                          "4 = InternVL-4B projector, 5 = LightControl edit branch (FLUX.1-dev schedule, 20 steps, 19 ControlNeXt)")
+    ap.add_argument("--conditioning", default=None, choices=["qwen3b", "qwen7b", "minicpm", "internvl4b", "internvl1b"],
+                    help="override the MLLM whose hidden-state geometry / projector factory feeds the DiT; `--conditioning qwen7b` with the "
+                         "default config is the north-star's named target (QwenVL-2.5-7B -> FLUX-schnell)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="bf16 (default, the headline arithmetic = the reference's) or fp8: the MLP GEMMs (72 %% of the GEMM FLOPs) on "
                          "e4m3 MFMA (FluxTransformer2DModel.enable_fp8), reported as a separate line with its own tolerance")
@@ -226,88 +380,126 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fp8-lines", action="store_true", help="skip the extra fp8_mlp / fp8_all measurements attached to the bf16 line")
-    args = ap.parse_args()
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the live roofline probe (for rocprofv3 --kernel-trace runs whose GEMM total must contain the timed job only)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU stand-in workload over gloo: exercises the launcher / collective / timing / JSON path without a GPU (tests only)")
+    args = ap.parse_args(argv)
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to print a line whose n_gpus differs from "
+                         "the request" % (args.gpus, world))
+    stub = args.selftest_launcher
     dist = None
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))   # "nccl" IS RCCL on ROCm
+        world = dist.get_world_size()   # what is reported below is the group's size, not the flag
 
-    from x2i_amd.flux import FluxTransformer2DModel
-    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
-    from x2i_amd.proj import create_proj3_qwen3b
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
-    from x2i_amd.infer.harness import PROJECTORS, HIDDEN
     B, N = args.batch, args.denoise_steps
     St = 512
-    kind = {2: "qwen3b", 3: "minicpm", 4: "internvl4b", 5: "qwen7b"}[args.config]
-    make, C, pkw = PROJECTORS[kind]
-    Hm = HIDDEN[kind]
-    proj = make(in_channels=C, device=dev, **pkw).init_random_(seed=7)
-    hint = None
-    if args.config == 5:
-        from x2i_amd.lightcontrol import ControlNeXtModel, FluxTransformer2DModel as LCFlux
-        if N == 4:
-            N = 20
-        model = LCFlux(guidance_embeds=True, device=dev).init_random_(seed=1234)  # every rank holds the SAME weight replica
-        nets = []
-        for i in range(19):
-            net = ControlNeXtModel(device=dev)
-            gw = torch.Generator(device="cpu").manual_seed(500 + i)
-            for name, prm in net.named_parameters():
-                if prm.dim() > 1:  # conv / linear weights: N(0, 1/fan_in)
-                    v = torch.randn(prm.shape, generator=gw) / prm[0].numel() ** 0.5
-                elif name.endswith("weight"):  # GroupNorm scale
-                    v = 1.0 + 0.1 * torch.randn(prm.shape, generator=gw)
-                else:
-                    v = 0.02 * torch.randn(prm.shape, generator=gw)
-                prm.data.copy_(v)
-            nets.append(net)
-        pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True), control_nets=nets)
-        hint = (torch.rand((B, 3, args.size, args.size), device=dev) * 2 - 1).bfloat16()
+    kind = args.conditioning or {2: "qwen3b", 3: "minicpm", 4: "internvl4b", 5: "qwen7b"}[args.config]
+    ops = model = None
+    if stub:
+        C = Hm = 0
+        inner = stub_workload(args, rank)
+        noise = inner()
     else:
-        model = FluxTransformer2DModel(device=dev).init_random_(seed=1234)  # every rank holds the SAME weight replica
-        pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
-    if args.dtype == "fp8":
-        model.enable_fp8(args.fp8_mode)
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
-    mllm_hidden = (torch.randn((B, C, St, Hm), device=dev, generator=g) * 3.0).bfloat16()
-    noise = torch.randn((B, (args.size // 16) ** 2, 64), device=dev, generator=g).bfloat16()
+        from x2i_amd import ops
+        from x2i_amd.flux import FluxTransformer2DModel
+        from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+        from x2i_amd.infer.harness import PROJECTORS, HIDDEN
+        make, C, pkw = PROJECTORS[kind]
+        Hm = HIDDEN[kind]
+        proj = make(in_channels=C, device=dev, **pkw).init_random_(seed=7)
+        hint = None
+        if args.config == 5:
+            from x2i_amd.lightcontrol import ControlNeXtModel, FluxTransformer2DModel as LCFlux
+            if N == 4:
+                N = 20
+            model = LCFlux(guidance_embeds=True, device=dev).init_random_(seed=1234)  # every rank holds the SAME weight replica
+            nets = []
+            for i in range(19):
+                net = ControlNeXtModel(device=dev)
+                gw = torch.Generator(device="cpu").manual_seed(500 + i)
+                for name, prm in net.named_parameters():
+                    if prm.dim() > 1:  # conv / linear weights: N(0, 1/fan_in)
+                        v = torch.randn(prm.shape, generator=gw) / prm[0].numel() ** 0.5
+                    elif name.endswith("weight"):  # GroupNorm scale
+                        v = 1.0 + 0.1 * torch.randn(prm.shape, generator=gw)
+                    else:
+                        v = 0.02 * torch.randn(prm.shape, generator=gw)
+                    prm.data.copy_(v)
+                nets.append(net)
+            pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True), control_nets=nets)
+            hint = (torch.rand((B, 3, args.size, args.size), device=dev) * 2 - 1).bfloat16()
+        else:
+            model = FluxTransformer2DModel(device=dev).init_random_(seed=1234)  # every rank holds the SAME weight replica
+            pipe = FluxPipeline(model, FlowMatchEulerDiscreteScheduler())  # schnell / shuttle-3 schedule: shift 1.0
+        if args.dtype == "fp8":
+            model.enable_fp8(args.fp8_mode)
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        mllm_hidden = (torch.randn((B, C, St, Hm), device=dev, generator=g) * 3.0).bfloat16()
+        noise = torch.randn((B, (args.size // 16) ** 2, 64), device=dev, generator=g).bfloat16()
+
+        def inner():
+            pooled, embeds = proj(mllm_hidden)
+            return pipe(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=N, guidance_scale=3.5,
+                        height=args.size, width=args.size, output_type="latent", latents=noise, guided_hint=hint,
+                        use_graph=not args.no_graph).images
     gathered = [torch.empty_like(noise) for _ in range(world)] if world > 1 else None
 
     def one_pass():
-        pooled, embeds = proj(mllm_hidden)
-        lat = pipe(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=N, guidance_scale=3.5,
-                   height=args.size, width=args.size, output_type="latent", latents=noise, guided_hint=hint,
-                   use_graph=not args.no_graph).images
+        lat = inner()
         if world > 1:
-            dist.all_gather(gathered, lat)  # one RCCL all-gather of the final packed latents
+            dist.all_gather(gathered, lat)  # one all-gather of the final packed latents (RCCL over xGMI on the GPU path)
             return gathered
-        return FluxPipeline._unpack_latents(lat, args.size, args.size, 16)
+        return lat if stub else FluxPipeline._unpack_latents(lat, args.size, args.size, 16)
 
     for _ in range(args.warmup):
         one_pass()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    sync()
+    dt_local = dt = time.perf_counter() - t0
+    rank_ms = [dt_local / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
+        dt = max(float(x.item()) for x in allt)          # MAX over ranks
+    if ops is not None:
+        ops.streamk_check(sync=True)   # outside the timed region: a stream-K segment that gave up = undefined results = no line
 
     if rank == 0:
         ms_pass = dt / args.steps * 1e3
@@ -319,6 +511,9 @@ def main():
             "value": images_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_pass, "ms_per_denoise_step": ms_pass / N, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random MLLM hidden states, seeded noise)",
+            "rccl_ranks": world if world > 1 else 0, "rank_ms_per_step": [round(x, 3) for x in rank_ms],
+            "launcher": ("self (bench.py re-executed under torch.distributed.run)" if os.environ.get("X2I_BENCH_LAUNCHED") else
+                         "external (WORLD_SIZE set by the caller)") if world > 1 else "none",
             "config": {"workload": "BASELINE configs[%d]: %s conditioning (C=%d,H=%d,S_txt=512) -> projector -> %s DiT %dx%d, %d steps"
                                    % (args.config - 1, kind, C, Hm,
                                       "FLUX.1-dev + 19 ControlNeXt (LightControl)" if args.config == 5 else "shuttle-3/FLUX-schnell",
@@ -328,42 +523,51 @@ def main():
             "model_tflops_per_gpu": fl * N / (ms_pass * 1e-3) / 1e12,
             "model_frac_of_bf16_peak": fl * N / (ms_pass * 1e-3) / PEAK_BF16,
         }
-        if args.config == 5:
-            line["metric"] = "images/sec, LightControl FLUX.1-dev 1024x1024 %d-step (projector + denoise loop), whole job" % N
-            line["model_tflops_per_gpu"] = (fl + 8.30e12 * B) * N / (ms_pass * 1e-3) / 1e12  # + 19 x 436.8 GFLOP per image-step
-            line["model_frac_of_bf16_peak"] = line["model_tflops_per_gpu"] * 1e12 / PEAK_BF16
-        if args.dtype == "fp8":
-            line["dtype"] = "fp8"
-            line["dtype_detail"] = ("e4m3 (OCP) operands with fp32 accumulation for ff.net.0/ff.net.2 (image stream) and the single blocks' "
-                                    "proj_mlp/proj_out = 72% of the GEMM FLOPs" +
-                                    ("; plus image-stream / single-block to_q|k|v and to_out / to_add_out = 97%" if args.fp8_mode == "all" else "") +
-                                    "; everything else bf16 as in the headline run; stated tolerance vs the fp32 oracle in "
-                                    "tests/test_fp8_gpu.py")
-            line["metric"] += " [fp8 MLP GEMMs]" if args.fp8_mode == "mlp" else " [fp8 MLP + attention-projection GEMMs]"
-            line["roofline"] = gemm_roofline_fp8(B)
+        if stub:
+            line.update({"metric": "LAUNCHER SELF-TEST (CPU stand-in workload, gloo) -- not a benchmark figure", "dtype": "f32",
+                         "data": "launcher self-test: no GPU work", "model_tflops_per_gpu": None, "model_frac_of_bf16_peak": None,
+                         "config": {"workload": "launcher self-test", "batch_per_gpu": B, "global_batch": B * world,
+                                    "parallelism": "batch-sharded x%d" % world},
+                         "gathered_shape": [world] + list(noise.shape) if world > 1 else list(noise.shape)})
+            print(json.dumps(line), flush=True)
         else:
-            line["roofline"] = gemm_roofline(B)
-        if args.dtype == "bf16" and world == 1 and args.config == 2 and not args.no_fp8_lines:
-            # the opt-in e4m3 configurations in the same driver-timed record (the headline above stays bf16 = the reference's arithmetic):
-            # 1 warm-up + 3 timed passes each; stated tolerances in tests/test_fp8_gpu.py / test_fullscale_parity_gpu.py
-            for mode in ("mlp", "all"):
-                model.enable_fp8(mode)
-                one_pass()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
+            if args.config == 5:
+                line["metric"] = "images/sec, LightControl FLUX.1-dev 1024x1024 %d-step (projector + denoise loop), whole job" % N
+                line["model_tflops_per_gpu"] = (fl + 8.30e12 * B) * N / (ms_pass * 1e-3) / 1e12  # + 19 x 436.8 GFLOP per image-step
+                line["model_frac_of_bf16_peak"] = line["model_tflops_per_gpu"] * 1e12 / PEAK_BF16
+            if args.dtype == "fp8":
+                line["dtype"] = "fp8"
+                line["dtype_detail"] = ("e4m3 (OCP) operands with fp32 accumulation for ff.net.0/ff.net.2 (image stream) and the single blocks' "
+                                        "proj_mlp/proj_out = 72% of the GEMM FLOPs" +
+                                        ("; plus image-stream / single-block to_q|k|v and to_out / to_add_out = 97%" if args.fp8_mode == "all" else "") +
+                                        "; everything else bf16 as in the headline run; stated tolerance vs the fp32 oracle in "
+                                        "tests/test_fp8_gpu.py")
+                line["metric"] += " [fp8 MLP GEMMs]" if args.fp8_mode == "mlp" else " [fp8 MLP + attention-projection GEMMs]"
+                line["roofline"] = None if args.no_roofline else gemm_roofline_fp8(B)
+            else:
+                line["roofline"] = None if args.no_roofline else gemm_roofline(B)
+            if args.dtype == "bf16" and world == 1 and args.config == 2 and not args.no_fp8_lines:
+                # the opt-in e4m3 configurations in the same driver-timed record (the headline above stays bf16 = the reference's arithmetic):
+                # 1 warm-up + 3 timed passes each; stated tolerances in tests/test_fp8_gpu.py / test_fullscale_parity_gpu.py
+                for mode in ("mlp", "all"):
+                    model.enable_fp8(mode)
                     one_pass()
-                torch.cuda.synchronize()
-                ms8 = (time.perf_counter() - t1) / 3 * 1e3
-                line["fp8_" + mode] = {"images_s": B * 1e3 / ms8, "ms_per_denoise_step": ms8 / N, "passes": 3,
-                                       "model_tflops_per_gpu": fl * N / (ms8 * 1e-3) / 1e12,
-                                       "gemm_flops_on_e4m3": 0.72 if mode == "mlp" else 0.97}
-            r8 = gemm_roofline_fp8(B)
-            line["fp8_mlp"]["roofline"] = line["fp8_all"]["roofline"] = {k: r8[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "shapes")}
-            model.enable_fp8(None)
-        if not args.no_cpu_baseline and world == 1 and args.config == 2:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        one_pass()
+                    torch.cuda.synchronize()
+                    ms8 = (time.perf_counter() - t1) / 3 * 1e3
+                    line["fp8_" + mode] = {"images_s": B * 1e3 / ms8, "ms_per_denoise_step": ms8 / N, "passes": 3,
+                                           "model_tflops_per_gpu": fl * N / (ms8 * 1e-3) / 1e12,
+                                           "gemm_flops_on_e4m3": 0.72 if mode == "mlp" else 0.97}
+                r8 = gemm_roofline_fp8(B)
+                line["fp8_mlp"]["roofline"] = line["fp8_all"]["roofline"] = {k: r8[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_best", "kernel", "shapes")}
+                model.enable_fp8(None)
+                ops.streamk_check(sync=True)
+            if not args.no_cpu_baseline and world == 1 and args.config == 2:
+                line["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()  # rank 0 is still timing the roofline kernels: leave the job together
         dist.destroy_process_group()

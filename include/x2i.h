@@ -12,12 +12,16 @@
  *   - bf16 tensors are raw uint16 storage; "f32" means IEEE float
  *   - every function returns 0 on success, a negative X2I_ERR_* code otherwise; x2i_last_error() returns a
  *     thread-local message.  Nothing exits or throws across the boundary.
- *   - one process per GPU.  The library is STATELESS: there are no model handles, no weight packing step and no
- *     library-owned workspace (SURVEY.md section 8(b) sketched x2i_create / x2i_pack_weights / a workspace-size query;
- *     they were dropped on purpose -- weights are consumed in the reference's own nn.Linear [N,K] layout, fused only by
- *     row-concatenation on the host side, and every scratch buffer is a caller-owned argument, e.g.
- *     x2i_groupnorm_scratch_floats).  The only process-wide state is the option table below and a per-kernel
- *     "dynamic LDS size already raised" cache; both are mutex-protected.
+ *   - one process per GPU.  The library owns NO device memory: there are no model handles, no weight packing step and no
+ *     library-owned workspace ("PyTorch allocates and owns every buffer ... workspace via a
+ *     workspace_size query") -- weights are consumed in the reference's own nn.Linear [N,K] layout, fused only by
+ *     row-concatenation on the host side, and every scratch buffer is a caller-owned argument sized by a query:
+ *     x2i_groupnorm_scratch_floats, x2i_streamk_workspace_bytes (x2i_gemm_args.workspace).  Process-wide state, all of it
+ *     mutex-protected: the option table below, a per-kernel "dynamic LDS size already raised" cache, and ONE HIP object set per
+ *     device that holds no memory -- a side stream with two events, created on the first x2i_attention_bwd_bf16 call that runs
+ *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
+ *   - ABI version 2 (x2i_abi_version): x2i_gemm_args grew `workspace` / `workspace_bytes` and x2i_qkv_desc `q_scale` since
+ *     version 1; a caller built against another version must not load this library (x2i_amd/_lib.py checks).
  */
 #ifndef X2I_H
 #define X2I_H
@@ -26,7 +30,7 @@
 extern "C" {
 #endif
 
-#define X2I_ABI_VERSION 1
+#define X2I_ABI_VERSION 2
 
 #define X2I_OK 0
 #define X2I_ERR_ARG (-1)
@@ -52,13 +56,11 @@ const char* x2i_last_error(void);
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
  * "gemm_w4" (1: 4-wave hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output
  * tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
- * through a per-device workspace -- bit-identical to the one-tile kernel.  ONE workspace per device: two GEMM launches that both
- * take this path must not run concurrently on different streams of one device; a caller that overlaps GEMMs across streams sets 0,
- * which restores the peeled 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
+ * through the CALLER's workspace, x2i_gemm_args.workspace -- bit-identical to the one-tile kernel; 0, or no workspace: the peeled
+ * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
- * "gemm_sk_error" (read-only: non-zero after a chained segment gave up waiting for its
- * predecessor -- never observed; the result of that launch is then undefined), "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
+ * "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
  * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale), "conv5_variant" (0),
  * "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
  * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
@@ -93,8 +95,26 @@ typedef struct x2i_gemm_args {
   int64_t w_batch_stride;                            /* 0 = one W for every batch item (nn.Linear); else W[z] = W + z*stride (q k^T) */
   int32_t M, N, K, batch;
   int32_t act; int32_t out_f32;
+  void* workspace;                                   /* optional caller-owned stream-K workspace (below); NULL: none */
+  int64_t workspace_bytes;
 } x2i_gemm_args;
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
+
+/* Stream-K workspace of the persistent GEMM kernel (csrc/gemm256p.hip).  A launch whose last round of 256 x 256 output tiles is
+ * partly filled cuts those tiles along K into segments that are chained from workgroup to workgroup: a segment parks its fp32
+ * accumulators in the workspace and the next one continues them (same summation order as an undivided tile: bit-identical
+ * results).  The workspace is CALLER-OWNED device memory of at least x2i_streamk_workspace_bytes() bytes, 256-byte aligned,
+ * ZERO-FILLED ONCE before its first use (the kernels re-arm it themselves), passed in x2i_gemm_args.workspace by every entry point
+ * that takes x2i_gemm_args (for the *_pair_* entry points: args0's).  It must not be shared by launches that may run
+ * concurrently: one workspace per stream (and per captured graph) -- x2i_amd/ops.py keeps them that way.  Without a workspace
+ * (NULL / too small = X2I_ERR_ARG) such launches peel the partly filled round into a second launch of the 128^2 kernel: same
+ * results, a few percent slower.
+ * x2i_streamk_workspace_status: a SYNCHRONISING read of the workspace's give-up marker (a chained segment waits for its
+ * predecessor with a bounded spin; if it ever gives up -- never observed -- the marker is set and the results of that launch are
+ * undefined).  Returns 0 = clean, 1 = a segment gave up, negative X2I_ERR_* on a HIP error.  Callers check it after a batch of
+ * launches and treat 1 as a hard error (x2i_amd: FluxPipeline, harness and bench.py raise). */
+int64_t x2i_streamk_workspace_bytes(void);
+int x2i_streamk_workspace_status(const void* workspace, int64_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------------------
  * fp8 path (BASELINE north_star: "MFMA bf16/fp8 for the QKV/out-proj and MLP GEMMs"; the reference has no fp8 code -- the

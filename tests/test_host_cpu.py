@@ -20,13 +20,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     from x2i_amd import _lib
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "x2i.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(x2i_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(x2i_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 15
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/x2i.h but not exported by libx2i_hip.so"
-    bound = set(_lib.SIGNATURES) | {"x2i_abi_version", "x2i_last_error", "x2i_is_ablation_build"}
+    bound = set(_lib.SIGNATURES) | {"x2i_abi_version", "x2i_last_error", "x2i_is_ablation_build", "x2i_groupnorm_scratch_floats",
+                                    "x2i_streamk_workspace_bytes"}
     assert declared == bound, (declared ^ bound)
-    assert lib.x2i_abi_version() == 1
+    ver = int(re.search(r"#define X2I_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 2   # header, library and binding move together
+    assert lib.x2i_streamk_workspace_bytes() == 4096 + 256 * 256 * 1024   # the caller-owned stream-K workspace: flags + 256 slabs of 256 KiB
 
 
 def test_options_are_resolved_once_and_product_library_has_no_ablation_kernels():

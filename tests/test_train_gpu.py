@@ -510,6 +510,40 @@ def test_training_harness_resumes_from_the_newest_checkpoint(tmp_path, capsys):
     assert all(torch.equal(w4[k], w4b[k]) for k in w4)     # the earlier checkpoint was not rewritten
 
 
+def test_resumed_optimizer_restarts_moments_and_bias_correction_together(tmp_path):
+    """on resume the AdamW moments restart at zero, so the optimizer's step count (the bias corrections) must
+    restart with them -- as in the reference, which builds a fresh AdamW and a fresh lr_scheduler and continues only global_step
+    (train/train_qwenvl.py:404-409, :447-459, :476-481, :535).  The first post-resume update must not depend on the step NUMBER of the
+    checkpoint: resuming the same weights as step 1 and as step 1000 gives bit-identical parameters, and the warm-up restarts."""
+    import shutil
+    from x2i_amd import train_distill as TD
+    base = ["--synthetic", "--tiny", "--batch_size", "2", "--checkpointing_steps", "1", "--learning_rate", "1e-3", "--seed", "1"]
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    TD.main(base + ["--max_train_steps", "1", "--output_dir", str(a)])
+    for d, n in ((b, "1"), (c, "1000")):
+        (d / n).mkdir(parents=True)
+        shutil.copy(a / "1" / "diffusion_pytorch_model.bin", d / n / "diffusion_pytorch_model.bin")
+    TD.main(base + ["--max_train_steps", "2", "--output_dir", str(b)])
+    assert TD.run.last["trainer"].step_count == 1 and TD.run.last["resume_step"] == 1
+    TD.main(base + ["--max_train_steps", "1001", "--output_dir", str(c)])
+    assert TD.run.last["trainer"].step_count == 1 and TD.run.last["resume_step"] == 1000 and TD.run.last["global_step"] == 1001
+    wb, wc = torch.load(b / "2" / "diffusion_pytorch_model.bin"), torch.load(c / "1001" / "diffusion_pytorch_model.bin")
+    w1 = torch.load(a / "1" / "diffusion_pytorch_model.bin")
+    assert all(torch.equal(wb[k], wc[k]) for k in wb)
+    # ... and it is a first Adam step: |update| = lr * |m_hat / (sqrt(v_hat) + eps)| <= lr (+ weight decay, + one bf16 rounding)
+    k = max((k for k in wb if wb[k].dim() == 2), key=lambda k: wb[k].numel())
+    delta = (wb[k].float() - w1[k].float()).abs()
+    ulp = w1[k].float().abs().max().item() * 2.0 ** -7
+    assert delta.max().item() <= 1e-3 * 1.05 + 1e-2 * 1e-3 * w1[k].float().abs().max().item() + ulp and delta.max().item() > 0
+    # the warm-up restarts too: with constant_with_warmup the first post-resume step runs at factor 0 -> parameters unchanged
+    d = tmp_path / "d"
+    (d / "7").mkdir(parents=True)
+    shutil.copy(a / "1" / "diffusion_pytorch_model.bin", d / "7" / "diffusion_pytorch_model.bin")
+    TD.main(base + ["--max_train_steps", "8", "--output_dir", str(d), "--lr_scheduler", "constant_with_warmup", "--lr_warmup_steps", "4"])
+    wd = torch.load(d / "8" / "diffusion_pytorch_model.bin")
+    assert all(torch.equal(wd[k], w1[k]) for k in wd)
+
+
 def test_distillation_loss_kernel_vs_reference_golden(ops):
     """x2i_kd_loss_bf16 against the golden produced by EXECUTING the reference's statements (train/train_qwenvl.py normalize and the
     kl_div loops, tests/golden/make_golden.py gen_distill): the summed loss and the gradient with respect to every student tensor."""

@@ -44,7 +44,8 @@ if which in ("all", "attn"):
     Q, K_, VT = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
-        ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128))
+        # the PRODUCT call: Q carries softmax_scale * log2(e) (x2i_qkv_desc.q_scale) and the kernel gets scale = ln 2 -> attn_w4_kernel
+        ops.attention((Q.float() * (math.log2(math.e) / math.sqrt(128))).bfloat16(), K_, VT, O, B, H, S, Spad, D, S * D, math.log(2.0))
     torch.cuda.synchronize()
 if which == "conv":
     # ControlNeXt ResnetBlock conv2 (3x3, 128 -> 128 at 512^2) with / without the residual, and the 256-wide one

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes over tools/roofline_probe.py (exactly the two launches bench.py's `roofline` times): FETCH_SIZE / WRITE_SIZE /
 # L2 hit rate / SQ busy counters, each in its OWN pass with --kernel-trace only.  Writes <out>/summary.json and
-# <out>/r03_pmc_roofline.json (traffic per launch pair, FETCH_SIZE doubled per the gfx950 correction).
+# <out>/pmc_roofline.json (copied to profiles/<tag>_pmc_roofline.json, which bench.py reads) (traffic per launch pair, FETCH_SIZE doubled per the gfx950 correction).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=${1:-$R/gpurun_out/pmc_roofline}
@@ -21,7 +21,7 @@ tot = sum(v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)
 out = {"traffic_bytes_per_pair": tot, "kernels": ks,
        "note": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes over tools/roofline_probe.py; per-launch means "
                "summed over the GEMM kernels of the pair (bytes at the L2<->fabric boundary)"}
-json.dump(out, open(sys.argv[1] + "/r03_pmc_roofline.json", "w"), indent=1, sort_keys=True)
+json.dump(out, open(sys.argv[1] + "/pmc_roofline.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: round(x) for c, x in v.items()} for k, v in ks.items()}, indent=1)[:3000])
 print("traffic_bytes_per_pair", tot)
 PY

@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-r = bench.gemm_roofline_fp8(4, iters=20) if "--fp8" in sys.argv else bench.gemm_roofline(4, iters=20)
+r = bench.gemm_roofline_fp8(4) if "--fp8" in sys.argv else bench.gemm_roofline(4)
 D, S, B = 3072, 4608, 4
 fl = 2.0 * B * S * (4 * D * D + 5 * D * D)
 r["implied_avg_kernel_us"] = fl / (r["achieved"] * 1e12) / 2 * 1e6  # mean over the two shapes

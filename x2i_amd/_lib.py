@@ -14,6 +14,7 @@ _VARIANT = os.environ.get("X2I_LIB_VARIANT", "")
 LIB_PATH = os.path.join(_HERE, "libx2i_hip_%s.so" % _VARIANT if _VARIANT else "libx2i_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
+ABI_VERSION = 2  # include/x2i.h: X2I_ABI_VERSION
 
 
 class X2IError(RuntimeError):
@@ -33,6 +34,7 @@ class GemmArgs(C.Structure):
         ("w_batch_stride", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("act", C.c_int32), ("out_f32", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -107,6 +109,7 @@ SIGNATURES = {
     "x2i_softmax_rows_bf16": [_vp, _i64, _i32, _f32, _vp],
     "x2i_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "x2i_cast_bf16_to_f32": [_vp, _vp, _i64, _vp],
+    "x2i_streamk_workspace_status": [_vp, _i64],
     "x2i_set_option": [C.c_char_p, _i64],
     "x2i_get_option": [C.c_char_p, C.POINTER(C.c_int64)],
 }
@@ -132,12 +135,15 @@ def load():
     lib.x2i_groupnorm_scratch_floats.argtypes = [_i32, _i32]
     lib.x2i_groupnorm_scratch_floats.restype = C.c_int64
     lib.x2i_is_ablation_build.restype = C.c_int
+    lib.x2i_streamk_workspace_bytes.argtypes = []
+    lib.x2i_streamk_workspace_bytes.restype = C.c_int64
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.x2i_abi_version() != 1:
-        raise X2IError("x2i_amd: ABI version mismatch")
+    if lib.x2i_abi_version() != ABI_VERSION:
+        raise X2IError("x2i_amd: %s reports ABI version %d, this binding is written against %d (stale build? run `python -m x2i_amd.build`)"
+                       % (LIB_PATH, lib.x2i_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

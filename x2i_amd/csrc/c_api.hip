@@ -91,57 +91,19 @@ int x2i_num_cus() {
   return cus[dev];
 }
 
-namespace {
-struct SkWorkspace {
-  float* slabs = nullptr;
-  unsigned* flags = nullptr;
-  hipStream_t last_stream = nullptr;
-  hipEvent_t last_done = nullptr;
-  bool failed = false;
-};
-std::mutex g_sk_mu;
-SkWorkspace g_sk[64];
-}  // namespace
-
-bool x2i_streamk_workspace(hipStream_t stream, float** slabs, unsigned** flags) {
-  int dev = 0;
-  hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) return false;
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  SkWorkspace& w = g_sk[dev];
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
-  const bool capturing = cap != hipStreamCaptureStatusNone;
-  if (!w.slabs) {
-    if (capturing || w.failed) return false;  // no allocation inside a capture: this launch keeps whole tiles (same results)
-    const size_t slab_bytes = (size_t)x2i_gemm_sk_max_tiles() * x2i_gemm_sk_slab_bytes();
-    if (hipMalloc((void**)&w.slabs, slab_bytes) != hipSuccess || hipMalloc((void**)&w.flags, 4096) != hipSuccess ||
-        hipMemset(w.flags, 0, 4096) != hipSuccess || hipEventCreateWithFlags(&w.last_done, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      w.slabs = nullptr; w.failed = true;
-      return false;
-    }
+// Stream-K workspace: caller-owned (include/x2i.h).  Layout: [progress flags + give-up marker, 4 KiB][SK_MAX_TILES accumulator slabs].
+bool x2i_streamk_workspace(const x2i_gemm_args* a, float** slabs, unsigned** flags, int* rc) {
+  *rc = X2I_OK;
+  if (!a->workspace) return false;
+  const long long need = 4096 + (long long)x2i_gemm_sk_max_tiles() * x2i_gemm_sk_slab_bytes();
+  if (a->workspace_bytes < need || (((uintptr_t)a->workspace) & 255)) {
+    *rc = x2i_set_error(X2I_ERR_ARG, "gemm: stream-K workspace must be 256-byte aligned and >= x2i_streamk_workspace_bytes() = %lld bytes (got %lld)",
+                        need, (long long)a->workspace_bytes);
+    return false;
   }
-  // One workspace per device: a launch on another stream waits for the previous user (never needed by the single-stream product
-  // path; inside a capture no cross-stream wait can be recorded -- include/x2i.h states the rule for concurrent streams).
-  if (!capturing) {
-    if (w.last_stream != stream && w.last_stream != nullptr) (void)hipStreamWaitEvent(stream, w.last_done, 0);
-    w.last_stream = stream;
-  }
-  *slabs = w.slabs;
-  *flags = w.flags;
+  *flags = (unsigned*)a->workspace;
+  *slabs = (float*)((char*)a->workspace + 4096);
   return true;
-}
-
-void x2i_streamk_mark_used(hipStream_t stream) {
-  int dev = 0;
-  hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) return;
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  SkWorkspace& w = g_sk[dev];
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
-  if (w.last_done) (void)hipEventRecord(w.last_done, stream);
 }
 
 // A second stream per device for launches that are independent of each other (the dQ and the dK / dV pass of the attention backward):
@@ -177,15 +139,6 @@ bool x2i_side_stream(hipStream_t main, hipStream_t* side, hipEvent_t* fork, hipE
   return true;
 }
 
-int x2i_streamk_error_marker() {
-  int dev = 0;
-  hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !g_sk[dev].flags) return 0;
-  unsigned v = 0;
-  if (hipMemcpy(&v, g_sk[dev].flags + x2i_gemm_sk_max_tiles(), 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int)v;
-}
-
 extern "C" {
 
 int x2i_abi_version(void) { return X2I_ABI_VERSION; }
@@ -215,15 +168,21 @@ int x2i_set_option(const char* name, int64_t value) {
 int x2i_get_option(const char* name, int64_t* value) {
   if (!name || !value) return x2i_set_error(X2I_ERR_ARG, "get_option: null pointer");
   int* ip;
-  if (!strcmp(name, "gemm_sk_error")) {  // read-only: 1 = a stream-K segment gave up waiting for its predecessor (synchronising read)
-    *value = x2i_streamk_error_marker();
-    return X2I_OK;
-  }
   long long* lp = opt_slot(x2i_options(), name, &ip);
   if (ip) *value = *ip;
   else if (lp) *value = *lp;
   else return x2i_set_error(X2I_ERR_ARG, "get_option: unknown option '%s'", name);
   return X2I_OK;
+}
+
+int64_t x2i_streamk_workspace_bytes(void) { return 4096 + (int64_t)x2i_gemm_sk_max_tiles() * x2i_gemm_sk_slab_bytes(); }
+
+int x2i_streamk_workspace_status(const void* workspace, int64_t workspace_bytes) {
+  if (!workspace || workspace_bytes < x2i_streamk_workspace_bytes()) return x2i_set_error(X2I_ERR_ARG, "streamk_workspace_status: no / too small workspace");
+  unsigned v = 0;
+  const hipError_t e = hipMemcpy(&v, (const unsigned*)workspace + x2i_gemm_sk_max_tiles(), 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "streamk_workspace_status: %s", hipGetErrorString(e));
+  return v ? 1 : 0;
 }
 
 int x2i_is_ablation_build(void) {

@@ -238,11 +238,14 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restri
                                                             const bf16_t* __restrict__ bias, float* __restrict__ Y, int ldy, int N,
                                                             int K, int act_in, int act_out, int accumulate, int rpw) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [K][NB]: the NB samples' values of one k side by side
+  // [K][NBP]: the NB samples' values of one k side by side; the row stride is rounded up to an EVEN count so that every sample pair
+  // read below (8-byte vector) is 8-byte aligned also for odd NB (the pad column is never read)
+  constexpr int NBP = NB == 1 ? 1 : (NB + 1) & ~1;
+  extern __shared__ __attribute__((aligned(16))) float xs[];
   for (int i = threadIdx.x; i < NB * K; i += 256) {
     const int b = i / K, k = i - b * K;
     float v = x_is_bf16 ? bf16_to_f32(((const bf16_t*)Xv)[i]) : ((const float*)Xv)[i];
-    xs[k * NB + b] = apply_act(v, act_in);
+    xs[k * NBP + b] = apply_act(v, act_in);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restri
       // fma is two independent fmas)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float* xk = xs + (k + j) * NB;
+        const float* xk = xs + (k + j) * NBP;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
           const f32x2 x2 = *(const f32x2*)(xk + 2 * q);
@@ -465,7 +468,7 @@ int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const 
     // many rows per block when N is huge (the 1M-row AdaLN modulation table) so the activations are staged once
     const int rpw = N >= 65536 ? 16 : 4;
     const dim3 grid((N + 4 * rpw - 1) / (4 * rpw)), block(256);
-    const size_t shm = (size_t)nb * K * 4;
+    const size_t shm = (size_t)(nb == 1 ? 1 : (nb + 1) & ~1) * K * 4;   // (row stride padded to an even sample count)
     if (shm > 160 * 1024) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: B*K too large for LDS");
 #define SK_CASE(NB)                                                                                                   \
   case NB: {                                                                                                          \

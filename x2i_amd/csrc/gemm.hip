@@ -109,12 +109,13 @@ static bool persistent_ok(const x2i_gemm_args* a, const x2i_qkv_desc* qd) {
 }
 
 // stream-K decision for `tiles` 256^2 tiles of nkt K-tiles on `cus` CUs (see launch_gemm_impl); fetches the workspace
-static bool streamk_for(long long tiles, int nkt, int cus, hipStream_t stream, float** slabs, unsigned** flags) {
+static bool streamk_for(const x2i_gemm_args* a, long long tiles, int nkt, int cus, float** slabs, unsigned** flags, int* rc) {
   const X2IOptions& opt = x2i_options();
+  *rc = X2I_OK;
   if (!(opt.gemm_streamk && opt.gemm_tile == 0 && tiles > cus && cus <= SK_MAX_TILES && nkt >= 16)) return false;
   const long long r = tiles % cus, S = tiles / cus;
   if (!(r > 0 && r * nkt / cus + 6 <= nkt && r * nkt >= 6 && cus <= r * (S + 1))) return false;
-  return x2i_streamk_workspace(stream, slabs, flags);
+  return x2i_streamk_workspace(a, slabs, flags, rc);   // the caller's workspace (include/x2i.h); none: whole tiles / peeled tail
 }
 
 // Two GEMMs of the same kind in ONE persistent launch (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16): problem 1's tiles follow problem
@@ -152,10 +153,10 @@ int x2i_launch_gemm_pair(const x2i_gemm_args* a0, const x2i_qkv_desc* q0, const 
   const int cus = x2i_num_cus();
   float* sk_slabs = nullptr;
   unsigned* sk_flags = nullptr;
-  const bool sk = streamk_for(tiles, a0->K / BK, cus, stream, &sk_slabs, &sk_flags);
+  const bool sk = streamk_for(a0, tiles, a0->K / BK, cus, &sk_slabs, &sk_flags, &rc);
+  if (rc) return rc;
   pp.p[0].sk_on = sk ? 1 : 0; pp.p[0].sk_slabs = sk_slabs; pp.p[0].sk_flags = sk_flags;
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pp);
-  if (sk) x2i_streamk_mark_used(stream);
   opt.last_gemm_tile = 2256;  // (read-back for tests: the grouped launch was taken)
   return x2i_check_launch("gemm_pair");
 }
@@ -245,7 +246,10 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     // ... and only when the segments of a tile can run at different places of the workgroups' tile lists (segments per tile
     // = cus / r <= whole tiles per workgroup + 1): with fewer whole tiles the chain of hand-offs serialises (measured: M = 2048,
     // N = 9216, 288 tiles -> 8-segment chains behind ONE whole tile ran at half the speed of the peeled form)
-    if (kernp) sk = streamk_for(tiles256, nkt, cus, stream, &sk_slabs, &sk_flags);
+    if (kernp) {
+      sk = streamk_for(a, tiles256, nkt, cus, &sk_slabs, &sk_flags, &rc);
+      if (rc) return rc;
+    }
     int tm_main = tm_all;
     // (re-measured in round 2, tools/tail_probe.py: peeling pays up to a 3/8-full last round at any depth, and for a half-full one
     // only behind >= 8 full rounds; a fuller last round is faster left in the one launch.  Either way the results are bit-identical.)
@@ -264,7 +268,6 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       pm.sk_on = sk ? 1 : 0; pm.sk_slabs = sk_slabs; pm.sk_flags = sk_flags;
       const long long tiles = (long long)pm.tilesM * pm.tilesN * a->batch;
       hipLaunchKernelGGL(kernp, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pm);
-      if (sk) x2i_streamk_mark_used(stream);
     } else {
       hipLaunchKernelGGL(kern2, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(threads2), SMEM2_BYTES, stream, pm);
     }

@@ -49,12 +49,10 @@ X2IOptions& x2i_options();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch
 int x2i_ensure_dynamic_smem(const void* kernel, int bytes);
 int x2i_num_cus();  // compute units of the current device (cached)
-// per-device workspace of the stream-K GEMM (partial-accumulator slabs + progress flags), allocated on first use outside stream
-// capture; returns false when it cannot be provided for this launch (first use inside a capture): the caller keeps whole tiles.
+// a second stream + fork / join events per device for x2i_attention_bwd_bf16 (created on first use outside a capture; false: not available)
 bool x2i_side_stream(hipStream_t main, hipStream_t* side, hipEvent_t* fork, hipEvent_t* join);
-bool x2i_streamk_workspace(hipStream_t stream, float** slabs, unsigned** flags);
-void x2i_streamk_mark_used(hipStream_t stream);  // call behind a launch that used the workspace
-int x2i_streamk_error_marker();
+struct x2i_gemm_args;
+bool x2i_streamk_workspace(const x2i_gemm_args* a, float** slabs, unsigned** flags, int* rc);  // the caller's workspace, validated
 int x2i_gemm_sk_max_tiles();                      // (gemm.hip: the constants of gemm_device.h)
 long long x2i_gemm_sk_slab_bytes();
 

@@ -12,13 +12,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, device=None):
-    """torchrun-style init (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns (rank, world)."""
+def init_from_env(backend=None, device=None, timeout_hours=24.0):
+    """torchrun-style init (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns (rank, world).  The collective timeout is long on
+    purpose: ranks with nothing to do (the teacher ranks of a synthetic training run) wait in barrier_and_destroy() for the WHOLE run,
+    and the default watchdog (10 min RCCL / 30 min gloo) would abort them -- and with them the job."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {}
+        import datetime
+        kw = {"timeout": datetime.timedelta(hours=timeout_hours)}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)

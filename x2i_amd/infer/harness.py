@@ -22,6 +22,7 @@ import os
 import torch
 
 from .. import dist as xdist
+from .. import ops
 from .. import proj as xproj
 from ..flux import FluxTransformer2DModel
 from ..pipeline import FlowMatchEulerDiscreteScheduler, FluxPipeline
@@ -173,6 +174,7 @@ class Harness:
             latents = self.pipeline(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=a.num_steps,
                                     guidance_scale=3.5, height=height, width=width, output_type="latent", generator=gen,
                                     use_graph=not a.no_graph).images
+        ops.streamk_check(sync=True)   # the images are about to leave the GPU: a stream-K give-up marker (undefined results) is fatal here
         if self.rank != 0:
             return latents
         if self.vae is None:
@@ -231,6 +233,7 @@ class Harness:
                                 latents=noise[[lo + i for i in idx]], use_graph=not a.no_graph).images
             local[idx] = lat
         latents = xdist.all_gather_batch(local, n) if self.world > 1 else local
+        ops.streamk_check(sync=True)
         if self.rank == 0:
             self.save_outputs(latents, subdir, filenames, a.height, a.width)
         return latents

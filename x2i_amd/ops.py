@@ -27,6 +27,103 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---------------------------------------------------------------------------------------------------- stream-K workspaces
+# The persistent GEMM's chained stream-K segments park their accumulators in CALLER-owned memory (include/x2i.h:
+# x2i_gemm_args.workspace).  This module is that caller: one torch-owned workspace per (device, stream) for eager launches, and one
+# per captured graph (streamk_scope, entered by whoever captures: FluxPipeline, GraphedDistillStep) -- launches that can run
+# concurrently never share one.  Inside a capture with no scope there is NO workspace: the launch keeps whole tiles + the peeled
+# tail (same results).
+import threading
+import weakref
+
+SK_ERR_SLOT = 256  # csrc/gemm_device.h: flags[SK_ERR_SLOT] = a chained segment gave up waiting for its predecessor
+_sk_eager = {}
+_sk_all = weakref.WeakSet()
+_sk_tls = threading.local()
+_SK_EAGER_MAX = 8
+
+
+class StreamKWorkspace:
+    """64 MB + 4 KiB of device memory, zero flags; `poll()` enqueues an asynchronous read of the give-up marker, `check()` raises
+    X2IError when a completed read (or, with sync=True, a synchronising one) shows it set."""
+
+    def __init__(self, device=None):
+        n = int(_lib.load().x2i_streamk_workspace_bytes())
+        self.buf = torch.empty(n, dtype=torch.uint8, device=device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        self.buf[:4096].zero_()
+        self.nbytes = n
+        self._host = None
+        self._event = None
+        _sk_all.add(self)
+
+    @property
+    def marker(self):
+        return self.buf[4 * SK_ERR_SLOT:4 * SK_ERR_SLOT + 4].view(torch.int32)
+
+    def poll(self):
+        if self._host is None:
+            self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._event = torch.cuda.Event()
+        self._host.copy_(self.marker, non_blocking=True)
+        self._event.record()
+
+    def check(self, sync=False):
+        bad = False
+        if sync:
+            bad = _lib.load().x2i_streamk_workspace_status(C.c_void_p(self.buf.data_ptr()), self.nbytes) != 0
+        elif self._event is not None and self._event.query():
+            bad = int(self._host[0]) != 0
+        if bad:
+            raise _lib.X2IError("x2i_amd: a chained stream-K GEMM segment gave up waiting for its predecessor (workspace marker set): the "
+                                "results of that launch are undefined.  Set option gemm_streamk = 0 and report.")
+
+
+@contextlib.contextmanager
+def streamk_scope(ws):
+    """Every GEMM issued inside uses `ws` (a StreamKWorkspace, or None for none) -- for stream captures: one workspace per graph."""
+    old = getattr(_sk_tls, "ws", False)
+    _sk_tls.ws = ws
+    try:
+        yield ws
+    finally:
+        _sk_tls.ws = old
+
+
+def _sk_workspace():
+    ws = getattr(_sk_tls, "ws", False)
+    if ws is not False:
+        return ws
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _sk_eager.get(key)
+    if ws is None:
+        if len(_sk_eager) >= _SK_EAGER_MAX:   # streams come and go: drop the oldest (their launches are long enqueued; torch frees by stream order)
+            _sk_eager.pop(next(iter(_sk_eager)))
+        ws = _sk_eager[key] = StreamKWorkspace()
+    return ws
+
+
+def _set_ws(a):
+    ws = _sk_workspace()
+    if ws is not None:
+        a.workspace, a.workspace_bytes = ws.buf.data_ptr(), ws.nbytes
+
+
+def streamk_poll():
+    """Enqueue an asynchronous read of every live workspace's give-up marker on the current stream (no synchronisation)."""
+    for ws in list(_sk_all):
+        if ws.buf.device.index == torch.cuda.current_device():
+            ws.poll()
+
+
+def streamk_check(sync=True):
+    """Raise X2IError if any stream-K workspace carries the give-up marker.  sync=True reads the markers now (synchronises);
+    sync=False only looks at reads enqueued by streamk_poll() that have completed."""
+    for ws in list(_sk_all):
+        ws.check(sync=sync)
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -81,6 +178,7 @@ def _gemm_args(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, 
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act = act
     a.out_f32 = 1 if out_f32 else 0
+    _set_ws(a)
     return a, out
 
 
@@ -130,6 +228,7 @@ def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     a.bias2, a.bias2_batch_stride, a.w_batch_stride = (_bias2.data_ptr() if _bias2 is not None else None), 0, 0   # (_act2 / _bias2: tools only)
     a.M, a.N, a.K, a.batch = M, 3 * H * 128, W.shape[-1], batch
     a.act, a.out_f32 = ACT_NONE, 0
+    _set_ws(a)
     q = QkvDesc()
     q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
@@ -421,6 +520,7 @@ def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_
     a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act, a.out_f32 = act, 0
+    _set_ws(a)
     f = Fp8Desc()
     f.a_scale = a_scale.data_ptr() if a_scale is not None else None
     f.a_scale_batch_stride = a_scale_batch_stride
@@ -448,6 +548,7 @@ def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
     a.M, a.N, a.K, a.batch = M, 3 * H * 128, W8.shape[-1], batch
     a.act, a.out_f32 = ACT_NONE, 0
+    _set_ws(a)
     f = Fp8Desc()
     f.a_scale = a_scale.data_ptr() if a_scale is not None else None
     f.a_scale_batch_stride = a_scale_batch_stride

@@ -196,6 +196,7 @@ class FluxPipeline:
         if output_type != "latent":
             raise ValueError('only output_type="latent" is on the hot path (VAE decode is the caller\'s, as in the reference)')
         tr = self.transformer
+        ops.streamk_check(sync=False)  # a stream-K give-up marker read behind an earlier call fails THIS call loudly (never observed)
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         if height % 16 or width % 16:
@@ -246,6 +247,7 @@ class FluxPipeline:
         if not use_graph:
             latents = latents.clone()
             body(prompt_embeds, pooled_prompt_embeds, latents, hint)
+            ops.streamk_poll()
             return FluxPipelineOutput(latents) if return_dict else (latents,)
 
         key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None,
@@ -254,13 +256,15 @@ class FluxPipeline:
         if entry is None:
             static = dict(pe=prompt_embeds.clone(), pooled=pooled_prompt_embeds.clone(), lat=latents.clone(),
                           hint=None if hint is None else hint.clone())
+            # the graph owns its stream-K workspace (ops.streamk_scope): two graphs replayed on two streams never share one
+            aux["sk_ws"] = ops.StreamKWorkspace(device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # warm-up: lazy allocations, kernel attributes
+            with torch.cuda.stream(side), ops.streamk_scope(aux["sk_ws"]):  # warm-up: lazy allocations, kernel attributes
                 body(static["pe"], static["pooled"], static["lat"], static["hint"])
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph), ops.streamk_scope(aux["sk_ws"]):
                 body(static["pe"], static["pooled"], static["lat"], static["hint"])
             entry = (graph, static, aux)  # ids / guidance / schedule tensors must outlive the call: the graph reads them
             self._graphs = {key: entry}
@@ -271,6 +275,7 @@ class FluxPipeline:
         if hint is not None:
             static["hint"].copy_(hint)
         graph.replay()
+        entry[2]["sk_ws"].poll()
         out = static["lat"].clone()
         return FluxPipelineOutput(out) if return_dict else (out,)
 

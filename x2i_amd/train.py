@@ -620,7 +620,8 @@ class GraphedDistillStep:
                 # e.g. when the warm-up call ran with optimizer_step=False and nothing had popped the cache
                 self.trainer.proj.__dict__.pop("_conv5x5_cache", None)
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                self.sk_ws = ops.StreamKWorkspace(text_embeddings.device)   # the graph's own stream-K workspace (ops.streamk_scope)
+                with torch.cuda.graph(self.graph), ops.streamk_scope(self.sk_ws):
                     self.loss = self._body(self.static["x"], self.static["lat"], self.static["ts"], self.static["teacher"])
             else:
                 s = self.static

@@ -148,15 +148,18 @@ def run(args):
         # env:// launch, hosts the store the trainers' first collective still needs)
         xdist.barrier_and_destroy()
         return []
-    # resume (train/train_qwenvl.py:404-409): the newest checkpoint under output_dir continues at its step; AdamW moments restart
-    # (the reference's checkpoint holds the projector weights only)
+    # resume (train/train_qwenvl.py:404-409, :447-459, :476-481, :535): the newest checkpoint under output_dir continues at its step
+    # NUMBER, and that is all that continues -- the reference's checkpoint holds the projector weights only, so a restart builds a fresh
+    # AdamW (moments zero, its own step count from 0: bias corrections and moments restart TOGETHER -- ADVICE r3: moments at zero under
+    # a continued step count are uncorrected, 3-6x the nominal update for the first few hundred steps) and a fresh lr_scheduler (the
+    # warm-up runs again).  trainer.step_count therefore stays 0 and the schedule below counts optimizer steps since the restart.
     global_step, losses, graphed = 0, [], None
+    resume_step = 0
     last_step, last_path = latest_checkpoint(args.output_dir)
     if last_path is not None:
         from .checkpoints import load_projector_state_dict
         load_projector_state_dict(proj, last_path)
-        global_step = last_step
-        trainer.step_count = last_step
+        global_step = resume_step = last_step
         if rank == 0 or (groups is not None and rank == groups.train_ranks[0]):
             print(f"resuming from {last_path} at global_step {global_step}", flush=True)
     step = global_step * args.gradient_accumulation_steps
@@ -169,7 +172,7 @@ def run(args):
         sync = step % args.gradient_accumulation_steps == 0                                      # :560
         # the reference builds its scheduler with warm-up and total steps multiplied by the accumulation count and steps it once per
         # optimizer step (train/train_qwenvl.py:476-481, :631): same factor sequence here
-        trainer.lr = args.learning_rate * lr_factor(args.lr_scheduler, global_step, args.lr_warmup_steps * ga, args.max_train_steps * ga)
+        trainer.lr = args.learning_rate * lr_factor(args.lr_scheduler, global_step - resume_step, args.lr_warmup_steps * ga, args.max_train_steps * ga)
         teacher = [batch["KD_teacher_tensor0"], batch["KD_teacher_tensor1"], batch["KD_teacher_tensor2"]]
         if args.use_graph:
             if graphed is None:
@@ -186,6 +189,7 @@ def run(args):
                 print(f"step {global_step}: step_loss {losses[-1]:.4f} lr {trainer.lr:.3e} grad_norm {float(trainer.last_norm[1]):.4e}", flush=True)
                 if global_step % args.checkpointing_steps == 0:
                     print("saving model to", save_checkpoint(proj, args.output_dir, global_step), flush=True)
+    run.last = dict(trainer=trainer, resume_step=resume_step, global_step=global_step)   # (introspection for tests)
     if groups is not None:
         xdist.barrier_and_destroy()
     return losses
