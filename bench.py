@@ -125,8 +125,9 @@ def _interleaved_probe(fns, rounds, per_round):
 
 def _in_step_gemm_rate(B):
     """GEMM FLOPs of the timed job / summed GEMM kernel time, from the COMMITTED rocprofv3 --kernel-trace --stats of this bench
-    (profiles/<tag>_bench_b4_1024_kernel_stats.csv: TotalDurationNs over every gemm* kernel of 1 warm-up + 2 timed passes = 12 denoise
-    steps): the rate of the dominant kernel INSIDE the step, which cannot drift with the state of a probe.  B = 4 only."""
+    (profiles/<tag>_bench_b4_1024_kernel_stats.csv: TotalDurationNs over every gemm* kernel; the number of denoise steps in the trace
+    = the calls of euler_kernel -- 1 eager graph warm-up pass + 1 warm-up + 2 timed replays = 16): the rate of the dominant kernel
+    INSIDE the step, which cannot drift with the state of a probe.  B = 4 only."""
     import csv
     import glob
     if B != 4:
@@ -135,23 +136,20 @@ def _in_step_gemm_rate(B):
     if not files:
         return None
     path = files[-1]
-    t_ns, calls = 0.0, 0
+    t_ns, calls, steps = 0.0, 0, 0
     with open(path) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Name", "")
             if "gemm" in name and "fp8" not in name and "skinny" not in name:
                 t_ns += float(row["TotalDurationNs"])
                 calls += int(row["Calls"])
-    meta = path.replace("_kernel_stats.csv", "_kernel_stats.meta.json")
-    passes = 3
-    if os.path.exists(meta):
-        passes = int(json.load(open(meta)).get("passes", 3))
+            if "euler_kernel" in name:
+                steps = int(row["Calls"])   # one scheduler step per denoise step: counts the eager graph warm-up pass too
     D, St, Si = 3072, 512, 4096
     S = St + Si
     gemm_fl = (2 * B * Si * 64 * D + 2 * B * St * 4096 * D + 19 * B * S * 2 * 12 * D * D + 38 * B * S * 2 * 12 * D * D + 2 * B * Si * D * 64)
     gemm_fl += 2 * B * St * (2048 * 4096 + 4096 * 4096 + 4096 * 768) / 4     # the projector's three linears, once per 4-step pass
-    steps = 4 * passes
-    if t_ns <= 0:
+    if t_ns <= 0 or steps <= 0:
         return None
     rate = gemm_fl * steps / (t_ns * 1e-9)
     return dict(achieved=rate / 1e12, frac=rate / PEAK_BF16, unit="TFLOP/s", gemm_ms_per_denoise_step=t_ns * 1e-6 / steps, gemm_launches=calls,
@@ -204,7 +202,7 @@ def gemm_roofline(B, rounds=6, per_round=8):
                 probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", statistic="median round (frac), fastest (frac_best)",
                            us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times], clock_power=power),
                 in_step=_in_step_gemm_rate(B),
-                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_bf16_kernel",
+                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_kernel (bf16 instantiations)",
                 shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out shapes, 1.39 + 1.74 TFLOP; one persistent "
                        "256^2 launch each, last round cut along K)" % (B * S))
 

@@ -55,7 +55,7 @@ const char* x2i_last_error(void);
  * environment variable X2I_<NAME> and afterwards only changes through x2i_set_option -- nothing on the launch path reads
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
  * "gemm_w4" (1: 4-wave hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output
- * tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
+ * tiles), "gemm_fp8_persist" (1: x2i_gemm_fp8 / x2i_gemm_qkv_fp8 take the persistent four-wave form too; 0: the one-tile e4m3 kernel, bit-identical), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
  * through the CALLER's workspace, x2i_gemm_args.workspace -- bit-identical to the one-tile kernel; 0, or no workspace: the peeled
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
@@ -105,8 +105,11 @@ int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
  * accumulators in the workspace and the next one continues them (same summation order as an undivided tile: bit-identical
  * results).  The workspace is CALLER-OWNED device memory of at least x2i_streamk_workspace_bytes() bytes, 256-byte aligned,
  * ZERO-FILLED ONCE before its first use (the kernels re-arm it themselves), passed in x2i_gemm_args.workspace by every entry point
- * that takes x2i_gemm_args (for the *_pair_* entry points: args0's).  It must not be shared by launches that may run
- * concurrently: one workspace per stream (and per captured graph) -- x2i_amd/ops.py keeps them that way.  Without a workspace
+ * that takes x2i_gemm_args (for the *_pair_* entry points: args0's).  One workspace per stream (and per captured graph), never
+ * shared -- and two workspace-carrying launches must not OVERLAP on one device at all: a launch with chained segments assumes its
+ * workgroups (one per CU) are co-resident; two of them on two streams can starve each other's predecessors until the bounded spin
+ * gives up (marker below).  The caller orders such launches (x2i_amd/ops.py: a stream that takes over waits for the previous one;
+ * graphs captured with a workspace are replayed on one stream).  Without a workspace
  * (NULL / too small = X2I_ERR_ARG) such launches peel the partly filled round into a second launch of the 128^2 kernel: same
  * results, a few percent slower.
  * x2i_streamk_workspace_status: a SYNCHRONISING read of the workspace's give-up marker (a chained segment waits for its

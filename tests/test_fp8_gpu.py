@@ -262,3 +262,116 @@ def test_fp8_full_width_blocks_vs_oracle(mode):
     e8, e16 = rel_l2(o8, ref), rel_l2(o16, ref)
     print(f"full-width 1+1 blocks [{mode}]: fp8 {e8:.3e}  bf16 {e16:.3e}  (rel-L2 vs fp32 oracle)")
     assert e16 < 2e-2 and e8 < 6e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the persistent four-wave e4m3 kernel (gemm256p.hip, F8 = true; K-loop from gen_gemm256f8.py)
+@pytest.fixture
+def opt():
+    from x2i_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        old = _lib.set_option(name, value)
+        saved.setdefault(name, old)
+    yield set_
+    for k, v in saved.items():
+        _lib.set_option(k, v)
+
+
+@pytest.mark.parametrize("kind", ["gelu_e4m3", "gated_residual", "plain", "gelu_bf16"])
+@pytest.mark.parametrize("M,N,K", [(4 * 4608, 3072, 3072), (2 * 4608 + 40, 2048, 1536), (4608, 12288, 3072)])
+def test_persistent_e4m3_gemm_equals_one_tile_kernel(opt, kind, M, N, K):
+    """x2i_gemm_fp8 in the persistent four-wave form (one K = 128 MFMA per accumulator and K-tile, hand-scheduled; chained stream-K
+    for the partly filled last round; pipelined dequantising epilogues) against the round-2 one-tile kernel, bit for bit: the
+    accumulation order over K is the same and the epilogue arithmetic is spelled the same way.  Shapes: the single-block proj_out
+    geometry with a stream-K remainder (864 tiles on 256 CUs), a ragged row count, and the wide GELU launch."""
+    from x2i_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(7)
+    A = (torch.randn((M, K), device=DEV, generator=g) * 1.5).bfloat16()
+    W = (torch.randn((N, K), device=DEV, generator=g) * 0.03).bfloat16()
+    b = torch.randn((N,), device=DEV, generator=g).bfloat16()
+    A8, sa = ops.quantize_rows_fp8(A)
+    W8, sw = ops.quantize_rows_fp8(W)
+    res = torch.randn((M, N), device=DEV, generator=g).bfloat16()
+    gate = torch.randn((1, N), device=DEV, generator=g)
+
+    def run():
+        if kind == "gelu_e4m3":
+            return ops.gemm_fp8(A8, W8, b, a_scale=sa, w_scale=sw, act=ops.ACT_GELU_TANH, out_fp8=True, out_inv_scale=0.75).view(torch.uint8)
+        if kind == "gated_residual":
+            out = res.clone()
+            ops.gemm_fp8(A8, W8, b, out=out, a_scale=sa, w_scale=sw, alpha=1.25, res=out, gate=gate)
+            return out
+        if kind == "gelu_bf16":
+            return ops.gemm_fp8(A8, W8, b, a_scale=sa, w_scale=sw, act=ops.ACT_GELU_TANH)
+        return ops.gemm_fp8(A8, W8, b, a_scale=sa, w_scale=sw)
+    opt("gemm_fp8_persist", 0)
+    want = run()
+    assert _lib.get_option("last_gemm_tile") == 7256
+    opt("gemm_fp8_persist", 1)
+    for it in range(3):
+        got = run()
+        assert _lib.get_option("last_gemm_tile") in (8256, 9256)
+        assert torch.equal(got, want), (kind, it)
+    if (M, N, K) == (4 * 4608, 3072, 3072):
+        assert _lib.get_option("last_gemm_tile") == 9256          # the 96-tile remainder went through the chained stream-K segments
+        opt("gemm_streamk", 0)
+        assert torch.equal(run(), want) and _lib.get_option("last_gemm_tile") == 8256
+    ops.streamk_check(sync=True)
+    if kind == "plain":
+        ref = deq(A8[:64], sa[:64]) @ deq(W8, sw).T + b.float().cpu()
+        assert rel_l2(got[:64], ref) < 4e-3
+
+
+def test_persistent_e4m3_batched_launch_and_fused_qkv_at_full_width(opt):
+    """The model's launches: (1) the batched image-stream geometry (batch items behind a text offset, per-item row scales) and (2)
+    x2i_gemm_qkv_fp8 at H = 24, K = 3072 on the flattened single-block rows -- persistent form vs one-tile kernel, bit for bit."""
+    from x2i_amd import _lib, ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B, St, Si, Kd, N = 4, 512, 4096, 3072, 3072
+    S = St + Si
+    X = (torch.randn((B * S, Kd), device=DEV, generator=g)).bfloat16()
+    X8, sx = ops.quantize_rows_fp8(X)
+    W8, sw = ops.quantize_rows_fp8((torch.randn((N, Kd), device=DEV, generator=g) * 0.03).bfloat16())
+    bias = torch.randn((N,), device=DEV, generator=g).bfloat16()
+    sxi = sx.view(B, S)[:, St:].contiguous()
+    gate = torch.randn((B, N), device=DEV, generator=g)
+    res0 = torch.randn((B, S, N), device=DEV, generator=g).bfloat16()
+
+    def batched():
+        out = res0.clone()
+        ops.gemm_fp8(X8, W8, bias, out=out, M=Si, batch=B, a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd, a_scale=sxi, a_scale_batch_stride=Si,
+                     w_scale=sw, c_batch_stride=S * N, ldc=N, c_offset=St * N, res=out, res_batch_stride=S * N, ldr=N, res_offset=St * N,
+                     gate=gate, gate_batch_stride=N)
+        return out
+    opt("gemm_fp8_persist", 0)
+    want = batched()
+    opt("gemm_fp8_persist", 1)
+    got = batched()
+    assert _lib.get_option("last_gemm_tile") in (8256, 9256) and torch.equal(got, want)
+    assert torch.equal(got[:, :St], res0[:, :St])                      # text rows untouched
+    # fused QKV, flattened rows (2592 tiles: 10 full rounds + a 32-tile stream-K remainder)
+    H = 24
+    D = H * 128
+    Spad = ops.pad128(S)
+    Wq8, swq = ops.quantize_rows_fp8((torch.randn((3 * D, Kd), device=DEV, generator=g) * 0.02).bfloat16())
+    bq = (torch.randn((3 * D,), device=DEV, generator=g) * 0.5).bfloat16()
+    nq, nk = ((1 + 0.2 * torch.randn((128,), device=DEV, generator=g)).bfloat16() for _ in range(2))
+    ang = torch.randn((S, 64), device=DEV, generator=g) * 3
+    cos, sin = torch.cos(ang).repeat_interleave(2, 1).contiguous(), torch.sin(ang).repeat_interleave(2, 1).contiguous()
+
+    def qkv():
+        z = lambda *sh: torch.zeros(sh, device=DEV, dtype=torch.bfloat16)
+        Q, K_, VT = z(B, H, Spad, 128), z(B, H, Spad, 128), z(B, H, 128, Spad)
+        ops.gemm_qkv_fp8(X8, Wq8, bq, Q, K_, VT, nq, nk, cos, sin, M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=sx, w_scale=swq,
+                         q_scale=0.1275)
+        return Q, K_, VT
+    opt("gemm_fp8_persist", 0)
+    w3 = qkv()
+    opt("gemm_fp8_persist", 1)
+    g3 = qkv()
+    assert _lib.get_option("last_gemm_tile") == 9256
+    for a_, b_ in zip(g3, w3):
+        assert torch.equal(a_, b_)
+    ops.streamk_check(sync=True)

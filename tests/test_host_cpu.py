@@ -254,6 +254,10 @@ def test_generated_gemm_loop_is_current():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gen = os.path.join(here, "x2i_amd", "csrc", "gen_gemm256w.py")
     assert subprocess.run([sys.executable, gen, "--check"]).returncode == 0
+    # ... and the e4m3 loop of the same kernel (csrc/gemm256f8_loop.inc <- gen_gemm256f8.py: fragment lifetimes, buffer reuse, SCC and
+    # the M0 / piece pairing are asserted by the generator, lgkmcnt counts derived from the simulated LDS queue)
+    gen8 = os.path.join(here, "x2i_amd", "csrc", "gen_gemm256f8.py")
+    assert subprocess.run([sys.executable, gen8, "--check"]).returncode == 0
 
 
 def test_generated_attention_statement_is_current():

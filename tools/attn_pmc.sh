@@ -28,5 +28,9 @@ for k, e in out.items():
         e["frac_wait_any"] = e.get("SQ_WAIT_ANY", 0) / w
         e["frac_wait_inst"] = e.get("SQ_WAIT_INST_ANY", 0) / w
         e["frac_active"] = e.get("SQ_ACTIVE_INST_ANY", 0) / w
+        # SQ_WAVE_CYCLES counts QUAD-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs.  One wave per SIMD
+        # (the hand-scheduled kernel): SIMD cycles = 4 * wave quad-cycles; two waves per SIMD (ping-pong, 4-wave x 2 workgroups): 2 *
+        waves_per_simd = 1 if k == "w4" else 2
+        e["mfma_busy_frac_of_simd_cycles"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4.0 * w / waves_per_simd)
 print(json.dumps(out, indent=1, sort_keys=True))
 PY

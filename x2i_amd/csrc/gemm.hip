@@ -393,8 +393,36 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   else if (tn <= 16) p.gm = a->K >= 16384 ? 1 : 4;
   else if (tn <= 64) p.gm = 6;
   else p.gm = 2;
+  // persistent four-wave form (gemm256p.hip with the K-loop of gen_gemm256f8.py): one workgroup per CU walks the tile list of all
+  // batch items, the last partly filled round is cut along K and chained through the caller's workspace -- everything the bf16
+  // launches do.  Same accumulation order and epilogue arithmetic as the one-tile kernel below: bit-identical (tested).
+  X2IOptions& wopt = x2i_options();
+  const int ob = out8 ? 1 : 2, oal = out8 ? 15 : 7;
+  kern_t kernp = nullptr;
+  if (wopt.gemm_persist && wopt.gemm_fp8_persist && wopt.gemm_tile == 0 && a->K >= 3 * 128 &&
+      ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) < 0x7f000000LL &&
+      (qd || ((a->ldc & oal) == 0 && (a->c_batch_stride & oal) == 0 && (long long)a->M * a->ldc * ob < 0x7f000000LL)) &&
+      (!res || ((((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)) &&
+      (!qd || (long long)a->batch * a->M <= 0x7fffffffLL))
+    kernp = pick_gemm256p_fp8(a->act, res, out8, qd != nullptr);
+  if (kernp) {
+    int rc = x2i_ensure_dynamic_smem((const void*)kernp, SMEM2P_BYTES);
+    if (rc) return rc;
+    const int cus = x2i_num_cus();
+    const long long tiles = (long long)tm * tn * a->batch;
+    float* sk_slabs = nullptr;
+    unsigned* sk_flags = nullptr;
+    const bool sk = streamk_for(a, tiles, a->K / 128, cus, &sk_slabs, &sk_flags, &rc);
+    if (rc) return rc;
+    p.nbatch = a->batch;
+    p.sk_on = sk ? 1 : 0; p.sk_slabs = sk_slabs; p.sk_flags = sk_flags;
+    hipLaunchKernelGGL(kernp, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, p);
+    wopt.last_gemm_tile = sk ? 9256 : 8256;   // (read-back for tests: persistent e4m3 launch, with / without stream-K)
+    return x2i_check_launch("gemm_fp8 (persistent)");
+  }
   const int rc = x2i_ensure_dynamic_smem((const void*)kern, SMEM2_BYTES);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(tm * tn, a->batch), dim3(512), SMEM2_BYTES, stream, p);
+  wopt.last_gemm_tile = 7256;
   return x2i_check_launch("gemm_fp8");
 }

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(GemmP p) {
       static_for<4>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] *= s * sw[j][r];
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(acc[i][j][r], s * sw[j][r], 0.f);  // (one rounding, never contracted with the bias add: gemm256p.hip spells it the same way)
       });
     });
   }

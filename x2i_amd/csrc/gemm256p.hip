@@ -7,6 +7,7 @@
 #include <type_traits>
 #include "gemm_device.h"
 #include "gemm256w_loop.inc"
+#include "gemm256f8_loop.inc"
 
 namespace x2i_gemm {
 namespace {
@@ -30,13 +31,143 @@ constexpr int P_STAGE_WAVE = 8192;
 // accumulator layout (a lane's four consecutive columns = one 8-byte load; the four column groups of a row share a 128-byte line, so
 // L2 sees every line once), two chunks ahead of its use.  (The first form of this epilogue fetched residual rows by LDS-DMA into the
 // staging buffer, one chunk ahead -- all the look-ahead 8 KiB allow -- and waited ~2 us per chunk for it: 17 us per tile.)
-template <int ACT, bool HASC2, bool RES>
+// e4m3 operands (F8): the accumulators hold sum_k A8 W8; the value every epilogue starts from is
+//     deq(acc) = fma(acc, a_scale[z][m] * (w_scale[n] * alpha), 0)
+// -- spelled as an explicit fma with a zero addend so that the product is rounded ONCE and the bias add that follows can never be
+// contracted into it: the one-tile kernel (gemm256_fp8.hip) spells it the same way, and the two are bit-identical (tested).
+struct DeqCols {
+  float v[8][4];   // w_scale[n] * alpha of this lane's 4 columns per 16-column block
+};
+template <bool F8>
+__device__ __forceinline__ void deq_cols(const GemmP& p, int n_wave, int lane, DeqCols& d) {
+  if constexpr (F8) {
+    const int ng = lane >> 4;
+    static_for<8>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int n = n_wave + j * 16 + ng * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d.v[j][r] = (p.f_sw && n + r < p.N) ? p.f_sw[n + r] * p.f_alpha : p.f_alpha;
+    });
+  }
+}
+// a_scale of rows m_wave + c * 32 + i * 16 + (lane & 15), c = 0..3, i = 0 / 1
+template <bool F8>
+__device__ __forceinline__ void deq_rows(const GemmP& p, int z, int m_wave, int lane, float (&sr)[4][2]) {
+  if constexpr (F8) {
+    const float* sa = p.f_sa ? p.f_sa + (long long)z * p.f_sa_bs : nullptr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m_wave + c * 32 + i * 16 + (lane & 15);
+        sr[c][i] = (sa && m < p.M) ? sa[m] : 1.f;
+      }
+  }
+}
+
+// e4m3 OUTPUT epilogue of one wave (x2i_gemm_fp8 with out_fp8: GELU(ff.net.0 / proj_mlp) written as the next GEMM's A operand), same
+// three-stage pipeline over eight 32-row x 64-column chunks as epilogue_chunked_pipe below, on bytes: a chunk's staging image is
+// [32 rows][64 B] (16-byte piece pc of row r at pc ^ ((r >> 1) & 3): conflict-free 4-byte parks), a lane parks its four consecutive
+// columns as one packed dword, rows leave as 64-byte runs (16-byte stores, 16 rows per wave instruction).  Arithmetic of
+// epilogue_store_fp8 (gemm256_fp8.hip): sat(act(deq(acc) + bias) * out_inv_scale) -> v_cvt_pk_fp8_f32.
+template <int ACT>
+__device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
+                                                           char* stage) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int mlane = lane & 15, ng = lane >> 4;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+  float bv[8][4];
+  static_for<8>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n_wave + j * 16 + ng * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+    if (n + 3 < p.N) {
+      if (p.bias) {
+        const uint2 bb = *(const uint2*)(p.bias + n);
+        bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
+        bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
+      }
+      if (b2) {
+        const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+        bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
+      }
+    }
+  });
+  DeqCols dc;
+  deq_cols<true>(p, n_wave, lane, dc);
+  float sr[4][2];
+  deq_rows<true>(p, z, m_wave, lane, sr);
+  const uint32_t c_bytes = (uint32_t)((long long)(p.M - 1) * p.ldc + p.N);
+  __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)p.C + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
+  // store piece `it` (0 / 1) of a chunk: row it * 16 + (lane >> 2), 16-byte piece (lane & 3) ^ swizzle(row)
+  const int srow = lane >> 2, spc = lane & 3;
+  uint32_t voff[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + srow;
+      const int n = n_wave + h * 64 + ((spc ^ ((row >> 1) & 3)) << 4);
+      voff[h][it] = (n + 15 < p.N) ? (uint32_t)((long long)(m_wave + row) * p.ldc + n) : 0x80000000u;
+    }
+  asm volatile("" ::: "memory");
+  auto stage_a = [&](auto qc, auto jc, int which) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int j = decltype(jc)::value;
+    constexpr int h = q >> 2, c = q & 3;
+    char* buf = stage + which * 2048;
+    static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
+        t = fmaf(t, sr[c][i] * dc.v[h * 4 + j][r], 0.f);
+        v[r] = __builtin_amdgcn_fmed3f(apply_act(t + bv[h * 4 + j][r], ACT) * p.f_oinv, -448.f, 448.f);
+      }
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+      const int row = i * 16 + mlane;
+      *(int*)(buf + row * 64 + ((j ^ ((row >> 1) & 3)) << 4) + (ng << 2)) = pk;
+    });
+  };
+  u32x4 d[2];
+  static_for<4>([&](auto jc) { stage_a(std::integral_constant<int, 0>{}, jc, 0); });
+  static_for<8>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int h = q >> 2, c = q & 3;
+    char* buf = stage + (q & 1) * 2048;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) d[it] = *(const u32x4*)(buf + it * 1024 + lane * 16);
+    const uint32_t soff = (uint32_t)((long long)c * 32 * p.ldc);
+    static_for<2>([&](auto hc) {
+      constexpr int hf = decltype(hc)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (q + 1 < 8) {
+        stage_a(std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2 * hf>{}, (q + 1) & 1);
+        stage_a(std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2 * hf + 1>{}, (q + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_raw_buffer_store_b128(d[hf], c_rsrc, voff[h][hf], soff, 0);
+    });
+  });
+}
+
+template <int ACT, bool HASC2, bool RES, bool F8 = false>
 __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
                                                       char* stage) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   const int mlane = lane & 15, ng = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
+  DeqCols dc;
+  deq_cols<F8>(p, n_wave, lane, dc);
+  float sr[4][2];
+  deq_rows<F8>(p, z, m_wave, lane, sr);
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
 #ifdef X2I_ABLATION
   if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer, tools/gemm_unit_timeline.py)
@@ -119,6 +250,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
       for (int r = 0; r < 4; ++r) {
         float t;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
+        if constexpr (F8) t = fmaf(t, sr[c][i] * dc.v[h * 4 + j][r], 0.f);
         v[r] = apply_act(t + bv[h * 4 + j][r], ACT);
       }
       if constexpr (RES) {
@@ -180,6 +312,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
 //   v:     four 64-token x 64-dim chunks ([64 rows][128 B], chunk ch of row r at ch ^ ((r >> 3) ^ (r >> 1)) & 7: conflict-free for the
 //          row-wise 8-byte parks AND the column-wise 4-byte gathers); a lane gathers two adjacent dims of 8 consecutive tokens and
 //          writes two 16-byte token runs of V^T, 8 lanes cover a 128-byte line.
+template <bool F8 = false>
 __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
                                                      char* stage) {
   // every per-lane offset below is cheap to recompute; hidden from loop-invariant code motion, or hipcc computes the lot once in front
@@ -201,6 +334,10 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
   };
   const TokMap tmap = tok_map(p, z, m_wave);
   auto token = [&](int m, int& b, int& st) { tok_of(tmap, m - m_wave, b, st); };  // rows m_wave <= m < m_wave + 128
+  DeqCols dc;
+  deq_cols<F8>(p, n_wave, lane, dc);
+  float sr[4][2];
+  deq_rows<F8>(p, z, m_wave, lane, sr);
   if (sec < 2) {
     const int c = lane & 15, rsub = lane >> 4;  // 8-dim chunk of the head; row of the pass
     float w[8];
@@ -245,6 +382,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
           for (int r = 0; r < 4; ++r) {
             float t;
             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c2][rr][j][r]));
+            if constexpr (F8) t = fmaf(t, sr[c2][rr] * dc.v[h * 4 + j][r], 0.f);
             a[r] = t + bias_of(h * 4 + j, r);
           }
           *(uint2*)(buf + mlane * 256 + (((h * 8 + j * 2 + (ng >> 1)) ^ mlane) << 4) + ((ng & 1) << 3)) =
@@ -319,6 +457,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
             for (int r = 0; r < 4; ++r) {
               float t;
               asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c2][rr][j][r]));
+              if constexpr (F8) t = fmaf(t, sr[c2][rr] * dc.v[h * 4 + j][r], 0.f);
               a[r] = t + bias_of(h * 4 + j, r);
             }
             *(uint2*)(stage + row * 128 + (((j * 2 + (ng >> 1)) ^ fsw(row)) << 4) + ((ng & 1) << 3)) =
@@ -403,8 +542,13 @@ __device__ __forceinline__ GemmP prob(const GemmP2& a, int sel) {
 // PAIR: a GROUPED launch of two problems with the same K and the same epilogue kind (the image-stream and the text-stream linear of
 // a double block: same layer type, different weights, 8 : 1 in rows): one tile list, problem 1's tiles behind problem 0's, so the
 // small problem's tiles ride in the rounds of the large one instead of under-filling a launch of their own.
-template <int ACT, bool RES, bool HASC2, bool QKV = false, bool PAIR = false>
-__global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
+// F8: e4m3 operands (x2i_gemm_fp8 / x2i_gemm_qkv_fp8) -- the same unit list, stream-K chain, LDS images and epilogue pipelines around the
+// K-loop of gen_gemm256f8.py (one K = 128 MFMA per accumulator and K-tile, fragments in v128..v255); every byte offset below is
+// computed with the element size ES.  OUT8: e4m3 output (epilogue_chunked_pipe_e4m3).
+template <int ACT, bool RES, bool HASC2, bool QKV = false, bool PAIR = false, bool F8 = false, bool OUT8 = false>
+__global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
+  constexpr int ES = F8 ? 1 : 2;            // bytes per operand element
+  constexpr int KT = F8 ? 128 : BK;         // elements per K-tile (128 bytes of a row either way)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][A image 32 KiB | W image 32 KiB][4 waves x 8 KiB staging]
   const GemmP& p = first(pp);  // launch-wide fields (K, nbatch of problem 0, stream-K workspace) live in problem 0's descriptor
   const int tid = threadIdx.x;
@@ -415,7 +559,7 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
   int TT = TT0;
   if constexpr (PAIR) TT += second(pp).tilesM * second(pp).tilesN * second(pp).nbatch;
   const int G = gridDim.x, w = blockIdx.x;
-  const int nk = p.K / BK;
+  const int nk = p.K / KT;
 
   auto tile_of = [&](int vb, int& sel, int& z, int& m0, int& n0) {  // the XCD-aware patch order of gemm256.hip, applied to the virtual block id
     sel = PAIR ? min(max(vb - TT0 + 1, 0), 1) : 0;
@@ -435,15 +579,15 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
     n0 = ((bid % per_group) / gsize) * BN2;
   };
   const int khl = lane >> 5, r8 = (lane >> 2) & 7, cphys = lane & 3;
-  const int kel = khl * 32 + ((cphys ^ (3 * (wave & 1))) << 3);  // group parity = wave parity (4 pieces per row-group step)
+  const int kby = khl * 64 + ((cphys ^ (3 * (wave & 1))) << 4);  // byte within the K-tile line; group parity = wave parity (4 pieces per row-group step)
   auto offsets = [&](int sel, int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {  // (W is shared by the batch items: w_bs == 0)
     const GemmP& q = prob(pp, sel);
     const long long zoff = (long long)z * q.a_bs;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int row = (jj * 4 + wave) * 8 + r8;
-      va[jj] = (m0 + row < q.M) ? (uint32_t)((zoff + (long long)(m0 + row) * q.lda + kel) * 2) : 0x80000000u;
-      vw[jj] = (n0 + row < q.N) ? (uint32_t)(((long long)(n0 + row) * q.ldw + kel) * 2) : 0x80000000u;
+      va[jj] = (m0 + row < q.M) ? (uint32_t)((zoff + (long long)(m0 + row) * q.lda) * ES + kby) : 0x80000000u;
+      vw[jj] = (n0 + row < q.N) ? (uint32_t)(((long long)(n0 + row) * q.ldw) * ES + kby) : 0x80000000u;
     }
   };
   auto uni = [](auto v) { return (decltype(v))__builtin_amdgcn_readfirstlane((int)v); };  // (workgroup-uniform by construction; makes it provable)
@@ -454,11 +598,11 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
   };
   auto a_rsrc_of = [&](int sel) {
     const GemmP& q = prob(pp, sel);
-    return mk_rsrc(q.A, (uint32_t)(((long long)(q.nbatch - 1) * q.a_bs + (long long)(q.M - 1) * q.lda + q.K) * 2));  // < 2 GB (launcher)
+    return mk_rsrc(q.A, (uint32_t)(((long long)(q.nbatch - 1) * q.a_bs + (long long)(q.M - 1) * q.lda + q.K) * ES));  // < 2 GB (launcher)
   };
   auto w_rsrc_of = [&](int sel) {
     const GemmP& q = prob(pp, sel);
-    return mk_rsrc(q.W, (uint32_t)(((long long)(q.N - 1) * q.ldw + q.K) * 2));
+    return mk_rsrc(q.W, (uint32_t)(((long long)(q.N - 1) * q.ldw + q.K) * ES));
   };
   // ---- this workgroup's unit list: S whole tiles (vb = w + s*G) and, with stream-K, up to two segments of the last round's tiles
   int S = TT / G;
@@ -538,13 +682,21 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
   uint32_t va[8], vw[8], na[8], nw[8];
   offsets(sel, z, m0, n0, va, vw);
   __amdgpu_buffer_rsrc_t a_rsrc = a_rsrc_of(sel), w_rsrc = w_rsrc_of(sel);
-  bf16x8_t fr[32];  // wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31
+  bf16x8_t fr[F8 ? 1 : 32];  // bf16: wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31 (e4m3: fragments are v128..v255 inside the statements)
   uint32_t s_koff, s_it, s_so;
-  int k0b = cur.k0 * (BK * 2);
-  asm volatile(X2I_GEMM256P_PRO
-               : X2I_GEMM256P_OPS_FRAG0_OUT(fr), [koff] "=&s"(s_koff)
-               : X2I_GEMM256W_OPS_VOFF(va, vw), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [k0b] "s"(k0b)
-               : "memory", "scc", "m0");
+  int k0b = cur.k0 * 128;       // bytes per K-tile and row
+  const uint32_t unit_scale = 0x7f7f7f7fu;   // E8M0 2^0 in every byte: the MX block scales of the e4m3 MFMA are all 1
+  if constexpr (F8) {
+    asm volatile(X2I_GEMM256F8_PRO
+                 : [koff] "=&s"(s_koff)
+                 : X2I_GEMM256W_OPS_VOFF(va, vw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [k0b] "s"(k0b)
+                 : "memory", "scc", "m0");
+  } else {
+    asm volatile(X2I_GEMM256P_PRO
+                 : X2I_GEMM256P_OPS_FRAG0_OUT(fr), [koff] "=&s"(s_koff)
+                 : X2I_GEMM256W_OPS_VOFF(va, vw), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [k0b] "s"(k0b)
+                 : "memory", "scc", "m0");
+  }
   for (int ui = 0;; ++ui) {
     const Unit nxt = unit(ui + 1);
     const bool has_next = nxt.vb >= 0;
@@ -559,7 +711,7 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) na[jj] = nw[jj] = 0x80000000u;  // behind the last unit: every piece out of range (zero fill, no fetch)
     }
-    const int nk0b = nxt.k0 * (BK * 2), len = cur.len;
+    const int nk0b = nxt.k0 * 128, len = cur.len;
     f32x4_t acc[2][4][2][4];
     const int fromp = min(cur.k0, 1);  // (integer arithmetic, not a comparison: hipcc materialises an i1 in a VGPR, which cannot feed "s")
     if (fromp) {
@@ -592,13 +744,21 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
     unsigned long long* tdbg = (p.act2 >= 79 && tid == 0 && w < 16) ? (unsigned long long*)p.bias2 + w * 64 : nullptr;
     if (tdbg && ui < 31) tdbg[2 * ui] = __builtin_amdgcn_s_memrealtime();
 #endif
-    asm volatile(X2I_GEMM256P_MAIN
-                 : X2I_GEMM256P_OPS_ACC_IO(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
-                   [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
-                 : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nra] "s"(na_rsrc),
-                   [nrw] "s"(nw_rsrc), [nk] "s"(len),
-                   [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
-                 : "memory", "scc", "m0");
+    if constexpr (F8) {
+      asm volatile(X2I_GEMM256F8_MAIN
+                   : X2I_GEMM256P_OPS_ACC_IO(acc), [la] "+v"(la), [lw] "+v"(lw), [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
+                   : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nra] "s"(na_rsrc),
+                     [nrw] "s"(nw_rsrc), [nk] "s"(len), [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs), [sc] "v"(unit_scale)
+                   : "memory", "scc", "m0", X2I_GEMM256F8_FRAG_CLOBBERS);
+    } else {
+      asm volatile(X2I_GEMM256P_MAIN
+                   : X2I_GEMM256P_OPS_ACC_IO(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), [la] "+v"(la), [lw] "+v"(lw),
+                     [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
+                   : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nra] "s"(na_rsrc),
+                     [nrw] "s"(nw_rsrc), [nk] "s"(len),
+                     [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
+                   : "memory", "scc", "m0");
+    }
 #ifdef X2I_ABLATION
     if (tdbg && ui < 31) tdbg[2 * ui + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -620,8 +780,9 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
         asm volatile("" ::X2I_GEMM256P_OPS_ACC_IN(acc));
       } else
 #endif
-      if constexpr (QKV) epilogue_qkv_chunked(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
-      else epilogue_chunked_pipe<ACT, HASC2, RES>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      if constexpr (QKV) epilogue_qkv_chunked<F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      else if constexpr (OUT8) epilogue_chunked_pipe_e4m3<ACT>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      else epilogue_chunked_pipe<ACT, HASC2, RES, F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
     }
     if (!has_next) break;
     cur = nxt; sel = nsel; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
@@ -629,33 +790,48 @@ __global__ __launch_bounds__(256) void gemm256p_bf16_kernel(GemmArg<PAIR> pp) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) va[jj] = na[jj], vw[jj] = nw[jj];
   }
-  asm volatile(X2I_GEMM256P_DRAIN ::: "memory");
+  asm volatile(X2I_GEMM256P_DRAIN ::: "memory");   // (the e4m3 loop's drain is the same two instructions)
 }
 
 }  // namespace
 
-kern_t pick_gemm256p_qkv() { return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true>; }
+kern_t pick_gemm256p_qkv() { return gemm256p_kernel<X2I_ACT_NONE, false, false, true>; }
 
 // grouped (two-problem) forms: the layer types of a double-stream block
 kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2) {
-  if (qkv) return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, true, true>;
-  if (c2) return (act == X2I_ACT_NONE && !res) ? (kern2_t)gemm256p_bf16_kernel<X2I_ACT_NONE, false, true, false, true> : nullptr;
-  if (res) return act == X2I_ACT_NONE ? (kern2_t)gemm256p_bf16_kernel<X2I_ACT_NONE, true, false, false, true> : nullptr;
-  if (act == X2I_ACT_GELU_TANH) return gemm256p_bf16_kernel<X2I_ACT_GELU_TANH, false, false, false, true>;
-  if (act == X2I_ACT_NONE) return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false, false, true>;
+  if (qkv) return gemm256p_kernel<X2I_ACT_NONE, false, false, true, true>;
+  if (c2) return (act == X2I_ACT_NONE && !res) ? (kern2_t)gemm256p_kernel<X2I_ACT_NONE, false, true, false, true> : nullptr;
+  if (res) return act == X2I_ACT_NONE ? (kern2_t)gemm256p_kernel<X2I_ACT_NONE, true, false, false, true> : nullptr;
+  if (act == X2I_ACT_GELU_TANH) return gemm256p_kernel<X2I_ACT_GELU_TANH, false, false, false, true>;
+  if (act == X2I_ACT_NONE) return gemm256p_kernel<X2I_ACT_NONE, false, false, false, true>;
+  return nullptr;
+}
+
+// e4m3 operands: the epilogue set of gemm256_fp8.hip
+kern_t pick_gemm256p_fp8(int act, bool res, bool out8, bool qkv) {
+  if (qkv) return (!res && !out8 && act == X2I_ACT_NONE) ? (kern_t)gemm256p_kernel<X2I_ACT_NONE, false, false, true, false, true> : nullptr;
+  if (out8) {
+    if (res) return nullptr;
+    if (act == X2I_ACT_NONE) return gemm256p_kernel<X2I_ACT_NONE, false, false, false, false, true, true>;
+    if (act == X2I_ACT_GELU_TANH) return gemm256p_kernel<X2I_ACT_GELU_TANH, false, false, false, false, true, true>;
+    return nullptr;
+  }
+  if (res) return act == X2I_ACT_NONE ? (kern_t)gemm256p_kernel<X2I_ACT_NONE, true, false, false, false, true> : nullptr;
+  if (act == X2I_ACT_NONE) return gemm256p_kernel<X2I_ACT_NONE, false, false, false, false, true>;
+  if (act == X2I_ACT_GELU_TANH) return gemm256p_kernel<X2I_ACT_GELU_TANH, false, false, false, false, true>;
   return nullptr;
 }
 
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2) {
   if (f32) return nullptr;
-  if (res) return (act == X2I_ACT_NONE && !c2) ? (kern_t)gemm256p_bf16_kernel<X2I_ACT_NONE, true, false> : nullptr;
-  if (c2) return act == X2I_ACT_NONE ? (kern_t)gemm256p_bf16_kernel<X2I_ACT_NONE, false, true> : nullptr;
+  if (res) return (act == X2I_ACT_NONE && !c2) ? (kern_t)gemm256p_kernel<X2I_ACT_NONE, true, false> : nullptr;
+  if (c2) return act == X2I_ACT_NONE ? (kern_t)gemm256p_kernel<X2I_ACT_NONE, false, true> : nullptr;
   switch (act) {
-    case X2I_ACT_NONE: return gemm256p_bf16_kernel<X2I_ACT_NONE, false, false>;
-    case X2I_ACT_GELU_TANH: return gemm256p_bf16_kernel<X2I_ACT_GELU_TANH, false, false>;
-    case X2I_ACT_GELU_ERF: return gemm256p_bf16_kernel<X2I_ACT_GELU_ERF, false, false>;
-    case X2I_ACT_SILU: return gemm256p_bf16_kernel<X2I_ACT_SILU, false, false>;
-    case X2I_ACT_RELU: return gemm256p_bf16_kernel<X2I_ACT_RELU, false, false>;
+    case X2I_ACT_NONE: return gemm256p_kernel<X2I_ACT_NONE, false, false>;
+    case X2I_ACT_GELU_TANH: return gemm256p_kernel<X2I_ACT_GELU_TANH, false, false>;
+    case X2I_ACT_GELU_ERF: return gemm256p_kernel<X2I_ACT_GELU_ERF, false, false>;
+    case X2I_ACT_SILU: return gemm256p_kernel<X2I_ACT_SILU, false, false>;
+    case X2I_ACT_RELU: return gemm256p_kernel<X2I_ACT_RELU, false, false>;
   }
   return nullptr;
 }

@@ -482,7 +482,8 @@ kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop,
 kern_t pick_gemm256p_qkv();                                 // ... with the fused QKV epilogue (x2i_gemm_qkv_bf16)
 kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
 constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
-kern_t pick_gemm256_fp8(int act, bool res, bool out8);  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
+kern_t pick_gemm256_fp8(int act, bool res, bool out8);
+kern_t pick_gemm256p_fp8(int act, bool res, bool out8, bool qkv);  // ... in the persistent four-wave form (gemm256p.hip, gen_gemm256f8.py)  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
 #ifdef X2I_ABLATION
 kern_t pick_gemm256w_var(int var);  // A/B schedules of the 4-wave K-loop (option gemm_w4 = 1 + var), plain epilogue only
 kern_t pick_gemm256u(int act, bool res, bool f32, bool c2, int abl);  // k-half-unit form + measurement-only variants

@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K-loop of the persistent four-wave e4m3 GEMM (gemm256p.hip, F8 = true) -> gemm256f8_loop.inc.
+
+Same tile (256 x 256, four waves, 128 x 128 wave tiles in the accumulator file), LDS images, DMA pieces and buffer ring as the bf16
+kernel (gen_gemm256w.py) -- a K-tile is 128 BYTES of every operand row in both, so everything that moves bytes is shared -- but the
+matrix instruction is `v_mfma_scale_f32_16x16x128_f8f6f4` (unit E8M0 block scales): ONE instruction per accumulator and K-tile,
+64 per K-tile and wave (32 cycles each: the same 2048 matrix-pipe cycles as the bf16 kernel's 128 x 16, for twice the K depth).
+Its A / B operands are 8-register tuples = the two 16-byte k-halves of a fragment row (one ds_read_b128 each), so there is no
+k-half double buffering: the wave holds the WHOLE fragment set of the current K-tile (W[0..7], A[0..7]: 128 VGPRs, hand-assigned
+v128..v255 -- an asm operand cannot be split into the two halves a fragment is read in -- and clobbered) and replaces each fragment
+in place as soon as its last MFMA of the tile has issued:
+
+    MFMA k = 8 i + j uses A[i], W[j]          A[i] is dead behind MFMA 8 i + 7,  W[j] behind MFMA 56 + j
+
+  gap 0         A[7] of THIS tile (its register was busy until the previous tile's last MFMA)
+  gap 7 / 8     every fragment of this tile is in registers: s_waitcnt lgkmcnt(0), barrier -> the tile's LDS buffer is free
+  gaps 9..40    the 16 LDS-DMA pieces of tile t+2 into that buffer (A first: it is read first), M0 write and piece in separate gaps
+  gap 41 / 42   s_waitcnt vmcnt(16) (tile t+1 has landed; the 16 pieces just issued stay in flight), barrier, read addresses flip
+  gaps 43..56   A[0..6] of tile t+1, each behind its last use;  gaps 56..63: W[j] of tile t+1 behind MFMA 56 + j
+  next tile     counted lgkmcnt waits in front of MFMA 0 / 2 / 4 / 6 (W[j] arrives 8 MFMAs = 256 cycles after its request)
+
+Two barriers per K-tile (four in the bf16 loop), prefetch distance a whole K-tile (2048 cycles).  Persistent form only: PRO (first
+two K-tiles of a workgroup's first unit), MAIN (one unit: PRE = fragments of its first K-tile, then len bodies; the last two fetch
+the NEXT unit's first two K-tiles; nothing stays in registers between two statements except the accumulators, so the epilogue has the
+whole VGPR file), DRAIN.  Wait counts are derived by simulating the stream; hazards are asserted (check()).
+`python gen_gemm256f8.py` rewrites gemm256f8_loop.inc (committed; tests/test_host_cpu.py regenerates and compares).
+"""
+import os
+import sys
+
+NF = 8
+FB = 128          # first fragment register: W[j] = v[FB + 8j : +7], A[i] = v[FB + 64 + 8i : +7]
+
+
+def acc(i, j):
+    return f"%[c{i * NF + j}]"
+
+
+def W(j, half=None):
+    b = FB + 8 * j
+    return f"v[{b}:{b + 7}]" if half is None else f"v[{b + 4 * half}:{b + 4 * half + 3}]"
+
+
+def A(i, half=None):
+    b = FB + 64 + 8 * i
+    return f"v[{b}:{b + 7}]" if half is None else f"v[{b + 4 * half}:{b + 4 * half + 3}]"
+
+
+# events: ("RA", i) / ("RW", j): both halves of a fragment; cur=True reads the CURRENT tile's buffer (A[7] at gap 0)
+def slots(kind):
+    """kind: 'A' normal body, 'B1' / 'B2' the last two K-tiles of a unit (B2 reads no next-tile fragments)."""
+    s = {}
+
+    def put(k, *ev):
+        s.setdefault(k, []).extend(ev)
+
+    put(0, ("RA", 7))
+    put(1, ("TL",))
+    put(7, ("LGK0",))
+    put(8, ("BAR",))
+    for jj in range(16):
+        op, n = ("A", jj) if jj < 8 else ("W", jj - 8)
+        put(9 + 2 * jj, ("M0", op, n))
+        put(10 + 2 * jj, ("D", op, n))
+    put(41, ("XD",))
+    if kind != "B2":
+        put(41, ("VM",))
+        put(42, ("BAR",))
+    put(42, ("XA",), ("XW",))
+    if kind != "B2":
+        for i in range(5):
+            put(43 + i, ("RA", i))
+        put(49, ("RA", 5))
+        put(56, ("RA", 6))
+        for j in range(8):
+            put(56 + j, ("RW", j))
+    if kind == "A":
+        put(60, ("CNT", 0))
+        put(61, ("CNT", 1))
+    return s
+
+
+def check(s, kind):
+    pos = {}
+    for k in sorted(s):
+        for n, ev in enumerate(s[k]):
+            pos.setdefault(ev, (k, n))
+    bars = sorted((k, n) for k in s for n, ev in enumerate(s[k]) if ev == ("BAR",))
+    # the current tile's A[7] is read behind the previous tile's MFMA 63, i.e. anywhere in this body, and before MFMA 56 needs it
+    assert pos[("RA", 7)][0] < 40 and pos[("LGK0",)][0] < 8, "A[1] (MFMA 8) relies on the full wait"
+    assert pos[("RA", 7)] < pos[("LGK0",)] < bars[0]
+    for op in "AW":
+        for n in range(8):
+            assert bars[0] < pos[("M0", op, n)] and pos[("M0", op, n)][0] < pos[("D", op, n)][0], "M0 write and its piece must sit in different gaps"
+            assert pos[("D", op, n)] < pos[("XD",)]
+    m0s = sorted((pos[e], e) for e in pos if e[0] in ("M0", "D"))
+    for (p0, e0), (p1, e1) in zip(m0s[::2], m0s[1::2]):
+        assert e0[0] == "M0" and e1[0] == "D" and e0[1:] == e1[1:], (e0, e1)
+    assert pos[("RA", 7)] < pos[("XA",)]
+    if kind != "B2":
+        assert len(bars) == 2 and pos[("VM",)] < bars[1]
+        assert max(pos[("D", op, n)] for op in "AW" for n in range(8)) < pos[("VM",)], "the wait count assumes all 16 new pieces are younger"
+        for i in range(7):
+            assert pos[("RA", i)][0] >= 8 * i + 7, "A[%d] overwritten before its last MFMA" % i
+            assert bars[1] < pos[("RA", i)] and pos[("XA",)] < pos[("RA", i)]
+        for j in range(8):
+            assert pos[("RW", j)][0] >= 56 + j, "W[%d] overwritten before its last MFMA" % j
+            assert bars[1] < pos[("RW", j)] and pos[("XW",)] < pos[("RW", j)]
+    if kind == "A":
+        assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0", "XD") or e == ("CNT", 0)), "SCC must survive to the branch"
+
+
+def emit(ev, st):
+    kind = ev[0]
+    mode = st["mode"]
+    if kind in ("RA", "RW"):
+        n = ev[1]
+        reg, addr = (A, "%[la]") if kind == "RA" else (W, "%[lw]")
+        st["ds"] += [(kind, n, 0), (kind, n, 1)]
+        return [f"ds_read_b128 {reg(n, 0)}, {addr}" + (f" offset:{n * 2048}" if n else ""),
+                f"ds_read_b128 {reg(n, 1)}, {addr} offset:{n * 2048 + 512}"]
+    if kind == "TL":
+        if mode == "B1":
+            return ["s_mov_b32 %[koff], %[nk0b]"]
+        if mode == "B2":
+            return ["s_add_u32 %[koff], %[nk0b], 128"]
+        return []
+    if kind == "LGK0":
+        st["ds"] = []
+        return ["s_waitcnt lgkmcnt(0)"]
+    if kind == "BAR":
+        return ["s_barrier"]
+    if kind == "M0":
+        off = (32768 if ev[1] == "W" else 0) + ev[2] * 4096
+        return [f"s_add_u32 m0, %[dma], {off}" if off else "s_mov_b32 m0, %[dma]"]
+    if kind == "D":
+        nxt = mode in ("B1", "B2")
+        v = ("n" if nxt else "v") + ev[1].lower() + str(ev[2])
+        r = ("nr" if nxt else "r") + ev[1].lower()
+        st["vm"] += 1
+        return [f"buffer_load_dwordx4 %[{v}], %[{r}], %[koff] offen lds"]
+    if kind == "XD":
+        return ["s_xor_b32 %[dma], %[dma], 0x10000"] + (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" else [])
+    if kind == "VM":
+        assert st["vm"] == 16
+        return ["s_waitcnt vmcnt(16)"]
+    if kind == "XA":
+        return ["v_xor_b32 %[la], 0x10000, %[la]"]
+    if kind == "XW":
+        return ["v_xor_b32 %[lw], 0x10000, %[lw]"]
+    if kind == "CNT":
+        return [["s_sub_u32 %[it], %[it], 1", "s_cmp_lg_u32 %[it], 0"][ev[1]]]
+    raise ValueError(ev)
+
+
+def need(st, what):
+    """s_waitcnt so that the fragment reads named in `what` (list of (kind, n)) have returned."""
+    idx = [i for i, (k, n, _) in enumerate(st["ds"]) if (k, n) in what]
+    if not idx:
+        return []
+    cnt = len(st["ds"]) - 1 - max(idx)
+    assert cnt <= 15
+    st["ds"] = st["ds"][max(idx) + 1:] if cnt == 0 else st["ds"]   # (entries older than the awaited one have returned too: keep the list simple)
+    return [f"s_waitcnt lgkmcnt({cnt})"]
+
+
+def body(kind, st, zero=False):
+    """64 MFMAs of one K-tile with the events of slots(kind) in the gaps.  st['ds'] carries the fragment reads still outstanding
+    from the previous body (or PRE): A[0..6], W[0..7] in that order."""
+    s = slots(kind)
+    check(s, kind)
+    st["mode"], st["vm"] = kind, 0
+    L = []
+    waited = set()
+    for k in range(64):
+        i, j = k >> 3, k & 7
+        # operands of this MFMA must be in registers: wait for W in pairs (MFMA 0 / 2 / 4 / 6), for A[i] at the head of its row
+        want = []
+        if i == 0 and j % 2 == 0:
+            want += [("RW", j), ("RW", j + 1)]
+        if j == 0:
+            want += [("RA", i)]
+        want = [w for w in want if w not in waited and any((k_, n_) == w for k_, n_, _ in st["ds"])]
+        if want:
+            L += need(st, want)
+            waited.update(want)
+        c = "0" if zero else acc(i, j)
+        L.append(f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(i, j)}, {W(j)}, {A(i)}, {c}, %[sc], %[sc] op_sel_hi:[0,0,0]")
+        for ev in s.get(k, []):
+            if ev[0] == "LGK0":
+                waited = set()
+            L += emit(ev, st)
+    return L
+
+
+def pre_reads(st):
+    L = []
+    st["ds"] = []
+    for i in range(7):
+        L += emit(("RA", i), st)
+    for j in range(8):
+        L += emit(("RW", j), st)
+    return L
+
+
+def generate():
+    # PRO: K-tiles k0 / k0 + 1 of the workgroup's first unit -> buffers 0 / 1
+    P = ["s_nop 4", "s_mov_b32 %[koff], %[k0b]"]
+    for b in range(2):
+        for op, base in (("a", 0), ("w", 32768)):
+            for jj in range(8):
+                P += [f"s_add_u32 m0, %[dma], {b * 65536 + base + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[v{op}{jj}], %[r{op}], %[koff] offen lds"]
+        if b == 0:
+            P += ["s_add_u32 %[koff], %[k0b], 128"]
+    # MAIN
+    st = dict(ds=[], vm=0, mode="A")
+    PRE = ["s_nop 4", "s_waitcnt vmcnt(16)", "s_barrier"] + pre_reads(st)
+    ds_after_pre = list(st["ds"])
+    bodies = {}
+    tails = {}
+    for kind, zero in (("A0", True), ("A", False), ("B1", False), ("B2", False)):
+        st["ds"] = list(ds_after_pre)
+        bodies[kind] = body("A" if kind == "A0" else kind, st, zero=zero)
+        tails[kind] = list(st["ds"])
+    # every body that is followed by another one must leave the same outstanding reads as PRE (same order): the waits of the next
+    # body were derived from that list
+    assert tails["A"] == ds_after_pre == tails["B1"] == tails["A0"], (tails, ds_after_pre)
+    assert tails["B2"] == []
+    MC = PRE + ["s_add_u32 %[koff], %[k0b], 256", "s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[zs], 0", "s_cbranch_scc1 5f",
+                "s_cmp_lg_u32 %[it], 0", "s_cbranch_scc0 2f", "s_branch 1f", "5:"]
+    MC += bodies["A0"] + ["s_cbranch_scc0 2f", "1:"] + bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
+    D = ["s_waitcnt vmcnt(0)", "s_barrier"]
+    return P, MC, D
+
+
+DOC = """// operands of the e4m3 persistent loop (all named; fragments are NOT operands: v128..v255, clobbered):
+//   c0..c63   "+a"  f32x4  accumulators, c[i*8 + j] = rows 16i.., columns 16j.. of the wave tile
+//   va0..7, vw0..7 / na0..7, nw0..7  "v"  per-piece byte offsets of this lane's 16 bytes in this / the next unit (0x80000000 = zeros)
+//   la, lw    "+v"  LDS byte address of this lane's A / W fragment read in the buffer of the unit's first K-tile
+//   ra, rw, nra, nrw  "s"  buffer descriptors;  dma "+s" LDS byte address of this wave's first A piece in that buffer
+//   nk "s" K-tiles of the unit (>= 3 from zero, >= 2 continuing); k0b / nk0b "s" byte offset (128 per K-tile) of this / the next unit's
+//   first K-tile within a row; zs "s" != 0: start from zero (the first K-tile takes C = 0);  sc "v" = 0x7f7f7f7f (unit E8M0 scales)
+//   koff, it  "=&s" scratch
+"""
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm256f8_loop.inc")
+    P, MC, D = generate()
+    txt = ["// GENERATED by gen_gemm256f8.py -- do not edit; the schedule table lives in the generator.", DOC]
+    for name, L in (("X2I_GEMM256F8_PRO", P), ("X2I_GEMM256F8_MAIN", MC), ("X2I_GEMM256F8_DRAIN", D)):
+        txt.append(f"// {name}: {len(L)} lines")
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{l}\\n" \\' for l in L[:-1]]
+        txt.append(f'  "{L[-1]}\\n"')
+        txt.append("")
+    clob = ", ".join(f'"v{r}"' for r in range(FB, 256))
+    txt.append(f"#define X2I_GEMM256F8_FRAG_CLOBBERS {clob}")
+    txt.append("")
+    data = "\n".join(txt)
+    if "--check" in sys.argv:
+        cur = open(out).read() if os.path.exists(out) else ""
+        sys.exit(0 if cur == data else 1)
+    with open(out, "w") as fh:
+        fh.write(data)
+    print(f"wrote {out}")
+
+
+if __name__ == "__main__":
+    main()

@@ -33,11 +33,19 @@ def _stream():
 # per captured graph (streamk_scope, entered by whoever captures: FluxPipeline, GraphedDistillStep) -- launches that can run
 # concurrently never share one.  Inside a capture with no scope there is NO workspace: the launch keeps whole tiles + the peeled
 # tail (same results).
+# A launch that carries a workspace ALSO assumes what every persistent launch with chained segments assumes: its workgroups (one per CU)
+# are co-resident, so a segment's predecessor is always running or done.  Two such launches overlapping on two streams can each hold
+# part of the CUs while waiting for workgroups that cannot start -- the bounded spin then gives up (marker, undefined results; found
+# by tests/test_gemm_w4_gpu.py in round 4: separate workspaces alone do not make overlap safe).  Hence: eager launches are ORDERED
+# across streams here (a stream that takes over waits for the stream that issued the previous workspace-carrying GEMM), and a graph
+# captured under streamk_scope must not be replayed concurrently with other GEMM launches on its device (FluxPipeline and
+# GraphedDistillStep replay on the caller's one stream); streamk_check() turns a violation into an exception.
 import threading
 import weakref
 
 SK_ERR_SLOT = 256  # csrc/gemm_device.h: flags[SK_ERR_SLOT] = a chained segment gave up waiting for its predecessor
 _sk_eager = {}
+_sk_last_stream = {}   # device index -> torch stream of the last eager workspace-carrying GEMM
 _sk_all = weakref.WeakSet()
 _sk_tls = threading.local()
 _SK_EAGER_MAX = 8
@@ -95,7 +103,12 @@ def _sk_workspace():
         return ws
     if torch.cuda.is_current_stream_capturing():
         return None
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    dev, cur = torch.cuda.current_device(), torch.cuda.current_stream()
+    last = _sk_last_stream.get(dev)
+    if last is not None and last.cuda_stream != cur.cuda_stream:
+        cur.wait_stream(last)          # never two chained stream-K launches in flight on one device (see the header comment)
+    _sk_last_stream[dev] = cur
+    key = (dev, cur.cuda_stream)
     ws = _sk_eager.get(key)
     if ws is None:
         if len(_sk_eager) >= _SK_EAGER_MAX:   # streams come and go: drop the oldest (their launches are long enqueued; torch frees by stream order)
