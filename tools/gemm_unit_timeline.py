@@ -10,6 +10,41 @@ from x2i_amd import ops  # noqa: E402
 
 DEV = "cuda"
 g = torch.Generator(device=DEV).manual_seed(0)
+
+
+def show(t, nwg=3):
+    for w in range(nwg):
+        row = t[w]
+        n = int((row[:, 0] > 0).sum())
+        t0 = int(row[0, 0])
+        dur = [(int(row[i, 1]) - int(row[i, 0])) / 100 for i in range(n)]
+        gap = [(int(row[i + 1, 0]) - int(row[i, 1])) / 100 for i in range(n - 1)]
+        print(f"wg {w}: {n} units; K-loop us: " + " ".join(f"{d:.1f}" for d in dur))
+        print("        gaps us: " + " ".join(f"{d:.2f}" for d in gap) + f"   total {(int(row[n - 1, 1]) - t0) / 100:.1f} us")
+
+
+if "--fp8" in sys.argv:
+    # the persistent e4m3 kernel (gen_gemm256f8.py): the two roofline launches
+    for (M, N, K, kind) in ((18432, 12288, 3072, "gelu_e4m3"), (18432, 3072, 15360, "res"), (18432, 12288, 3072, "plain")):
+        A8, sa = ops.quantize_rows_fp8(torch.randn((M, K), device=DEV, generator=g).bfloat16())
+        W8, sw = ops.quantize_rows_fp8((torch.randn((N, K), device=DEV, generator=g) * 0.02).bfloat16())
+        dbg = torch.zeros((16 * 64,), device=DEV, dtype=torch.int64)
+        out = torch.empty((M, N), device=DEV, dtype=ops.FP8 if kind == "gelu_e4m3" else torch.bfloat16)
+        gate = torch.randn((1, N), device=DEV, generator=g)
+        for mode, what in ((79, "no epilogue"), (80, "with its epilogue")):
+            for it in range(4):
+                dbg.zero_()
+                if kind == "gelu_e4m3":
+                    ops.gemm_fp8(A8, W8, None, out=out, a_scale=sa, w_scale=sw, act=1, out_fp8=True, _act2=mode, _bias2=dbg.view(torch.float32))
+                elif kind == "res":
+                    ops.gemm_fp8(A8, W8, None, out=out, w_scale=sw, res=out, gate=gate, _act2=mode, _bias2=dbg.view(torch.float32))
+                else:
+                    ops.gemm_fp8(A8, W8, None, out=out, a_scale=sa, w_scale=sw, _act2=mode, _bias2=dbg.view(torch.float32))
+            torch.cuda.synchronize()
+            print(f"== e4m3 M={M} N={N} K={K} {kind}: {what}   ({K // 128} K-tiles per tile; 100 % matrix pipe = {K // 128 * 2048 / 2.4e3:.1f} us at 2.4 GHz)")
+            show(dbg.view(16, 32, 2).cpu())
+    sys.exit(0)
+
 M, N, K = 18432, 12288, 3072
 A = torch.randn((M, K), device=DEV, generator=g).bfloat16()
 W = (torch.randn((N, K), device=DEV, generator=g) * 0.02).bfloat16()

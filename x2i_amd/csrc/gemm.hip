@@ -386,6 +386,9 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   p.f_sa = f->a_scale; p.f_sa_bs = f->a_scale_batch_stride; p.f_sw = f->w_scale; p.f_alpha = f->alpha; p.f_oinv = f->out_inv_scale;
   p.f_out8 = out8 ? 1 : 0;
   p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr;
+#ifdef X2I_ABLATION
+  p.act2 = a->act2;   // (measurement library: the unit-timeline hooks of gemm256p.hip, tools/gemm_unit_timeline.py --fp8)
+#endif
   const int tm = (a->M + BM2 - 1) / BM2, tn = (a->N + BN2 - 1) / BN2;
   p.tilesM = tm; p.tilesN = tn;
   const X2IOptions& opt = x2i_options();

@@ -76,6 +76,9 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int mlane = lane & 15, ng = lane >> 4;
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+#ifdef X2I_ABLATION
+  if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer)
+#endif
   float bv[8][4];
   static_for<8>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -685,7 +688,6 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
   bf16x8_t fr[F8 ? 1 : 32];  // bf16: wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31 (e4m3: fragments are v128..v255 inside the statements)
   uint32_t s_koff, s_it, s_so;
   int k0b = cur.k0 * 128;       // bytes per K-tile and row
-  const uint32_t unit_scale = 0x7f7f7f7fu;   // E8M0 2^0 in every byte: the MX block scales of the e4m3 MFMA are all 1
   if constexpr (F8) {
     asm volatile(X2I_GEMM256F8_PRO
                  : [koff] "=&s"(s_koff)
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
       asm volatile(X2I_GEMM256F8_MAIN
                    : X2I_GEMM256P_OPS_ACC_IO(acc), [la] "+v"(la), [lw] "+v"(lw), [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it)
                    : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc), [nra] "s"(na_rsrc),
-                     [nrw] "s"(nw_rsrc), [nk] "s"(len), [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs), [sc] "v"(unit_scale)
+                     [nrw] "s"(nw_rsrc), [nk] "s"(len), [k0b] "s"(k0b), [nk0b] "s"(nk0b), [zs] "s"(zs)
                    : "memory", "scc", "m0", X2I_GEMM256F8_FRAG_CLOBBERS);
     } else {
       asm volatile(X2I_GEMM256P_MAIN

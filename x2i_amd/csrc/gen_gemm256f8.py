@@ -3,21 +3,25 @@
 
 Same tile (256 x 256, four waves, 128 x 128 wave tiles in the accumulator file), LDS images, DMA pieces and buffer ring as the bf16
 kernel (gen_gemm256w.py) -- a K-tile is 128 BYTES of every operand row in both, so everything that moves bytes is shared -- but the
-matrix instruction is `v_mfma_scale_f32_16x16x128_f8f6f4` (unit E8M0 block scales): ONE instruction per accumulator and K-tile,
-64 per K-tile and wave (32 cycles each: the same 2048 matrix-pipe cycles as the bf16 kernel's 128 x 16, for twice the K depth).
-Its A / B operands are 8-register tuples = the two 16-byte k-halves of a fragment row (one ds_read_b128 each), so there is no
-k-half double buffering: the wave holds the WHOLE fragment set of the current K-tile (W[0..7], A[0..7]: 128 VGPRs, hand-assigned
-v128..v255 -- an asm operand cannot be split into the two halves a fragment is read in -- and clobbered) and replaces each fragment
-in place as soon as its last MFMA of the tile has issued:
+matrix instruction is `v_mfma_f32_16x16x128_f8f6f4` (e4m3 x e4m3, K = 128; the un-scaled encoding = unit block scales, one
+instruction word less per MFMA than v_mfma_scale_*): ONE instruction per accumulator and K-tile, 64 per K-tile and wave (32 cycles
+each: the same 2048 matrix-pipe cycles as the bf16 kernel's 128 x 16, for twice the K depth).  Its A / B operands are 8-register
+tuples = the two 16-byte k-halves of a fragment row (one ds_read_b128 each), so there is no k-half double buffering: the wave holds
+the WHOLE fragment set of the current K-tile (W[0..7], A[0..7]: 128 VGPRs, hand-assigned v128..v255 -- an asm operand cannot be split
+into the two halves a fragment is read in -- and clobbered) and replaces each fragment in place once its last MFMA has issued.
 
-    MFMA k = 8 i + j uses A[i], W[j]          A[i] is dead behind MFMA 8 i + 7,  W[j] behind MFMA 56 + j
+MFMA order: two COLUMN halves.  k = 32 h + 4 i + jj multiplies A[i] with W[4 h + jj]: W[0..3] are dead behind MFMA 31 and are
+re-read half a tile before the next tile needs them; A[i] is dead behind MFMA 35 + 4 i; W[4..7] and A[7] (dead only at the very
+end) are read at the HEAD of the next tile, 28+ MFMAs before their first use.  (The first form of this loop ran row-major, k = 8 i + j:
+W[j] was dead behind MFMA 56 + j and wanted again 8 MFMAs later, all four waves re-reading 64 KiB of LDS inside 256 cycles: 0.44 ->
+0.48 of the 5 PF peak only.)
 
-  gap 0         A[7] of THIS tile (its register was busy until the previous tile's last MFMA)
-  gap 7 / 8     every fragment of this tile is in registers: s_waitcnt lgkmcnt(0), barrier -> the tile's LDS buffer is free
-  gaps 9..40    the 16 LDS-DMA pieces of tile t+2 into that buffer (A first: it is read first), M0 write and piece in separate gaps
-  gap 41 / 42   s_waitcnt vmcnt(16) (tile t+1 has landed; the 16 pieces just issued stay in flight), barrier, read addresses flip
-  gaps 43..56   A[0..6] of tile t+1, each behind its last use;  gaps 56..63: W[j] of tile t+1 behind MFMA 56 + j
-  next tile     counted lgkmcnt waits in front of MFMA 0 / 2 / 4 / 6 (W[j] arrives 8 MFMAs = 256 cycles after its request)
+  gaps 0..4     A[7], W[4..7] of THIS tile (from the current buffer)
+  gap 11 / 12   every fragment of this tile is in registers: s_waitcnt lgkmcnt(0), barrier -> the tile's LDS buffer is free
+  gaps 13..44   the 16 LDS-DMA pieces of tile t+2 into that buffer, M0 write and piece in separate gaps
+  gap 45 / 46   s_waitcnt vmcnt(16) (tile t+1 has landed; the 16 pieces just issued stay in flight), barrier, read addresses flip
+  gaps 47..60   W[0..3], A[0..6] of tile t+1, each behind its last use
+  next tile     counted lgkmcnt waits in front of MFMA 0 (W[0..3], A[0]), 4 (A[1]), 8 (A[2]); the full wait at gap 11 covers the rest
 
 Two barriers per K-tile (four in the bf16 loop), prefetch distance a whole K-tile (2048 cycles).  Persistent form only: PRO (first
 two K-tiles of a workgroup's first unit), MAIN (one unit: PRE = fragments of its first K-tile, then len bodies; the last two fetch
@@ -46,7 +50,25 @@ def A(i, half=None):
     return f"v[{b}:{b + 7}]" if half is None else f"v[{b + 4 * half}:{b + 4 * half + 3}]"
 
 
-# events: ("RA", i) / ("RW", j): both halves of a fragment; cur=True reads the CURRENT tile's buffer (A[7] at gap 0)
+def mfma_operands(k):
+    """MFMA k of a K-tile -> (i, j): row fragment A[i], column fragment W[j]."""
+    h, i, jj = k >> 5, (k >> 2) & 7, k & 3
+    return i, 4 * h + jj
+
+
+def last_use(kind, n):
+    return max(k for k in range(64) if mfma_operands(k)[0 if kind == "RA" else 1] == n)
+
+
+def first_use(kind, n):
+    return min(k for k in range(64) if mfma_operands(k)[0 if kind == "RA" else 1] == n)
+
+
+HEAD = [("RA", 7), ("RW", 4), ("RW", 5), ("RW", 6), ("RW", 7)]          # read at the head of their own tile
+TAIL = [("RW", 0), ("RW", 1), ("RW", 2), ("RW", 3)] + [("RA", i) for i in range(7)]   # read at the end of the previous tile
+
+
+# events: ("RA", i) / ("RW", j): both halves of a fragment
 def slots(kind):
     """kind: 'A' normal body, 'B1' / 'B2' the last two K-tiles of a unit (B2 reads no next-tile fragments)."""
     s = {}
@@ -54,29 +76,27 @@ def slots(kind):
     def put(k, *ev):
         s.setdefault(k, []).extend(ev)
 
-    put(0, ("RA", 7))
-    put(1, ("TL",))
-    put(7, ("LGK0",))
-    put(8, ("BAR",))
+    for g, ev in enumerate(HEAD):
+        put(g, ev)
+    put(5, ("TL",))
+    put(11, ("LGK0",))
+    put(12, ("BAR",))
     for jj in range(16):
         op, n = ("A", jj) if jj < 8 else ("W", jj - 8)
-        put(9 + 2 * jj, ("M0", op, n))
-        put(10 + 2 * jj, ("D", op, n))
-    put(41, ("XD",))
+        put(13 + 2 * jj, ("M0", op, n))
+        put(14 + 2 * jj, ("D", op, n))
+    put(45, ("XD",))
     if kind != "B2":
-        put(41, ("VM",))
-        put(42, ("BAR",))
-    put(42, ("XA",), ("XW",))
+        put(45, ("VM",))
+        put(46, ("BAR",))
+    put(46, ("XA",), ("XW",))
     if kind != "B2":
-        for i in range(5):
-            put(43 + i, ("RA", i))
-        put(49, ("RA", 5))
-        put(56, ("RA", 6))
-        for j in range(8):
-            put(56 + j, ("RW", j))
+        for g, ev in enumerate(TAIL[:10]):
+            put(47 + g, ev)              # W[0..3] (dead behind MFMA 31), A[0..5] (A[5] behind 55)
+        put(60, TAIL[10])                # A[6] behind MFMA 59
     if kind == "A":
-        put(60, ("CNT", 0))
-        put(61, ("CNT", 1))
+        put(61, ("CNT", 0))
+        put(62, ("CNT", 1))
     return s
 
 
@@ -86,9 +106,9 @@ def check(s, kind):
         for n, ev in enumerate(s[k]):
             pos.setdefault(ev, (k, n))
     bars = sorted((k, n) for k in s for n, ev in enumerate(s[k]) if ev == ("BAR",))
-    # the current tile's A[7] is read behind the previous tile's MFMA 63, i.e. anywhere in this body, and before MFMA 56 needs it
-    assert pos[("RA", 7)][0] < 40 and pos[("LGK0",)][0] < 8, "A[1] (MFMA 8) relies on the full wait"
-    assert pos[("RA", 7)] < pos[("LGK0",)] < bars[0]
+    for ev in HEAD:      # fragments of the CURRENT tile read at its head: before their first MFMA (with room for the LDS latency), before
+        assert pos[ev][0] + 8 <= first_use(*ev) and pos[ev] < pos[("LGK0",)] < bars[0] and pos[ev] < pos[("XA",)]   # the full wait and the flips
+    assert pos[("LGK0",)][0] < first_use("RA", 3), "A[3] and later rely on the full wait (A[0..2] have counted waits)"
     for op in "AW":
         for n in range(8):
             assert bars[0] < pos[("M0", op, n)] and pos[("M0", op, n)][0] < pos[("D", op, n)][0], "M0 write and its piece must sit in different gaps"
@@ -96,16 +116,12 @@ def check(s, kind):
     m0s = sorted((pos[e], e) for e in pos if e[0] in ("M0", "D"))
     for (p0, e0), (p1, e1) in zip(m0s[::2], m0s[1::2]):
         assert e0[0] == "M0" and e1[0] == "D" and e0[1:] == e1[1:], (e0, e1)
-    assert pos[("RA", 7)] < pos[("XA",)]
     if kind != "B2":
         assert len(bars) == 2 and pos[("VM",)] < bars[1]
         assert max(pos[("D", op, n)] for op in "AW" for n in range(8)) < pos[("VM",)], "the wait count assumes all 16 new pieces are younger"
-        for i in range(7):
-            assert pos[("RA", i)][0] >= 8 * i + 7, "A[%d] overwritten before its last MFMA" % i
-            assert bars[1] < pos[("RA", i)] and pos[("XA",)] < pos[("RA", i)]
-        for j in range(8):
-            assert pos[("RW", j)][0] >= 56 + j, "W[%d] overwritten before its last MFMA" % j
-            assert bars[1] < pos[("RW", j)] and pos[("XW",)] < pos[("RW", j)]
+        for ev in TAIL:
+            assert pos[ev][0] >= last_use(*ev), "%s%d overwritten before its last MFMA" % ev
+            assert bars[1] < pos[ev] and pos[("XA",)] < pos[ev] and pos[("XW",)] < pos[ev]
     if kind == "A":
         assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0", "XD") or e == ("CNT", 0)), "SCC must survive to the branch"
 
@@ -154,41 +170,34 @@ def emit(ev, st):
 
 
 def need(st, what):
-    """s_waitcnt so that the fragment reads named in `what` (list of (kind, n)) have returned."""
+    """s_waitcnt so that the fragment reads named in `what` (list of (kind, n)) have returned (LDS reads return in order; the
+    counter has four bits, so a count above 15 becomes the stricter 15)."""
     idx = [i for i, (k, n, _) in enumerate(st["ds"]) if (k, n) in what]
     if not idx:
         return []
-    cnt = len(st["ds"]) - 1 - max(idx)
-    assert cnt <= 15
-    st["ds"] = st["ds"][max(idx) + 1:] if cnt == 0 else st["ds"]   # (entries older than the awaited one have returned too: keep the list simple)
+    cnt = min(15, len(st["ds"]) - 1 - max(idx))
     return [f"s_waitcnt lgkmcnt({cnt})"]
 
 
 def body(kind, st, zero=False):
     """64 MFMAs of one K-tile with the events of slots(kind) in the gaps.  st['ds'] carries the fragment reads still outstanding
-    from the previous body (or PRE): A[0..6], W[0..7] in that order."""
+    from the previous body (or PRE): TAIL, in that order."""
     s = slots(kind)
     check(s, kind)
     st["mode"], st["vm"] = kind, 0
     L = []
-    waited = set()
+    full = False
     for k in range(64):
-        i, j = k >> 3, k & 7
-        # operands of this MFMA must be in registers: wait for W in pairs (MFMA 0 / 2 / 4 / 6), for A[i] at the head of its row
-        want = []
-        if i == 0 and j % 2 == 0:
-            want += [("RW", j), ("RW", j + 1)]
-        if j == 0:
-            want += [("RA", i)]
-        want = [w for w in want if w not in waited and any((k_, n_) == w for k_, n_, _ in st["ds"])]
-        if want:
-            L += need(st, want)
-            waited.update(want)
+        i, j = mfma_operands(k)
+        if not full:
+            want = {0: [("RW", 0), ("RW", 1), ("RW", 2), ("RW", 3), ("RA", 0)], 4: [("RA", 1)], 8: [("RA", 2)]}.get(k, [])
+            if want:
+                L += need(st, want)
         c = "0" if zero else acc(i, j)
-        L.append(f"v_mfma_scale_f32_16x16x128_f8f6f4 {acc(i, j)}, {W(j)}, {A(i)}, {c}, %[sc], %[sc] op_sel_hi:[0,0,0]")
+        L.append(f"v_mfma_f32_16x16x128_f8f6f4 {acc(i, j)}, {W(j)}, {A(i)}, {c}")
         for ev in s.get(k, []):
             if ev[0] == "LGK0":
-                waited = set()
+                full = True
             L += emit(ev, st)
     return L
 
@@ -196,10 +205,8 @@ def body(kind, st, zero=False):
 def pre_reads(st):
     L = []
     st["ds"] = []
-    for i in range(7):
-        L += emit(("RA", i), st)
-    for j in range(8):
-        L += emit(("RW", j), st)
+    for ev in TAIL:
+        L += emit(ev, st)
     return L
 
 
@@ -239,7 +246,7 @@ DOC = """// operands of the e4m3 persistent loop (all named; fragments are NOT o
 //   la, lw    "+v"  LDS byte address of this lane's A / W fragment read in the buffer of the unit's first K-tile
 //   ra, rw, nra, nrw  "s"  buffer descriptors;  dma "+s" LDS byte address of this wave's first A piece in that buffer
 //   nk "s" K-tiles of the unit (>= 3 from zero, >= 2 continuing); k0b / nk0b "s" byte offset (128 per K-tile) of this / the next unit's
-//   first K-tile within a row; zs "s" != 0: start from zero (the first K-tile takes C = 0);  sc "v" = 0x7f7f7f7f (unit E8M0 scales)
+//   first K-tile within a row; zs "s" != 0: start from zero (the first K-tile takes C = 0)
 //   koff, it  "=&s" scratch
 """
 

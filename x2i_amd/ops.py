@@ -501,7 +501,7 @@ def quantize_rows_fp8(x, static_inv_scale=None):
 
 def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_batch_stride=0, lda=None, a_offset=0, a_scale=None,
              a_scale_batch_stride=0, w_scale=None, alpha=1.0, c_batch_stride=0, ldc=None, c_offset=0, act=ACT_NONE, gate=None,
-             gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, res_offset=0, out_fp8=False, out_inv_scale=1.0):
+             gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, res_offset=0, out_fp8=False, out_inv_scale=1.0, _act2=0, _bias2=None):
     """C = epi(a_scale[m] * w_scale[n] * alpha * A8 W8^T) on e4m3 operands (include/x2i.h: x2i_gemm_fp8)."""
     lib = _lib.load()
     _req(A8, FP8, "A8")
@@ -530,7 +530,8 @@ def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_
     a.res = (res.data_ptr() + res_offset * 2) if res is not None else None
     a.res_batch_stride = res_batch_stride
     a.ldr = ldc if ldr is None else ldr
-    a.bias2, a.bias2_batch_stride, a.w_batch_stride = None, 0, 0
+    a.bias2, a.bias2_batch_stride, a.w_batch_stride = (_bias2.data_ptr() if _bias2 is not None else None), 0, 0   # (_act2 / _bias2: tools only)
+    a.act2 = _act2
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act, a.out_f32 = act, 0
     _set_ws(a)
