@@ -402,7 +402,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   X2IOptions& wopt = x2i_options();
   const int ob = out8 ? 1 : 2, oal = out8 ? 15 : 7;
   kern_t kernp = nullptr;
-  if (wopt.gemm_persist && wopt.gemm_fp8_persist && wopt.gemm_tile == 0 && a->K >= 3 * 128 &&
+  if (wopt.gemm_persist && wopt.gemm_fp8_persist && wopt.gemm_tile == 0 && a->K >= 3 * 128 && (((uintptr_t)f->w_scale) & 15) == 0 &&
       ((long long)(a->batch - 1) * a->a_batch_stride + (long long)a->M * a->lda) < 0x7f000000LL &&
       (qd || ((a->ldc & oal) == 0 && (a->c_batch_stride & oal) == 0 && (long long)a->M * a->ldc * ob < 0x7f000000LL)) &&
       (!res || ((((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL)) &&

@@ -196,16 +196,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(GemmP p) {
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
 
-  // ---- dequantisation: acc *= a_scale[m] * w_scale[n] * alpha (lane owns rows m_wave + i*16 + (lane & 15), columns n + 0..3)
+  // ---- dequantisation + bias: acc <- fma(acc * (w_scale[n] * alpha), a_scale[m], bias[n] + bias2[z][n]) -- a multiply and an explicit fma,
+  // exactly as the persistent form (gemm256p.hip) spells it (bit-identical, tested); the shared epilogues below then add a zero bias
+  // (lane owns rows m_wave + i*16 + (lane & 15), columns n + 0..3)
+  GemmP pe = p;
+  pe.bias = nullptr;
+  pe.bias2 = nullptr;
   {
     const int mrow = m0 + wm * 128 + (lane & 15), ncol = n0 + wn * 64 + (lane >> 4) * 4;
     const float* sa = p.f_sa ? p.f_sa + (long long)z * p.f_sa_bs : nullptr;
-    float sw[4][4];
+    const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+    float sw[4][4], bb[4][4];
     static_for<4>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       const int n = ncol + j * 16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sw[j][r] = (p.f_sw && n + r < p.N) ? p.f_sw[n + r] * p.f_alpha : p.f_alpha;
+      for (int r = 0; r < 4; ++r) {
+        const bool in = n + r < p.N;
+        sw[j][r] = (p.f_sw && in) ? p.f_sw[n + r] * p.f_alpha : p.f_alpha;
+        bb[j][r] = (p.bias && in) ? bf16_to_f32(p.bias[n + r]) : 0.f;
+        if (b2 && in) bb[j][r] += b2[n + r];
+      }
     });
     static_for<8>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -214,21 +225,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_fp8_kernel(GemmP p) {
       static_for<4>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(acc[i][j][r], s * sw[j][r], 0.f);  // (one rounding, never contracted with the bias add: gemm256p.hip spells it the same way)
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(acc[i][j][r] * sw[j][r], s, bb[j][r]);
       });
     });
   }
   __syncthreads();  // every wave is done reading the operand images before they are reused as staging space
   if constexpr (ACT == X2I_ACT_NONE && !RES && !OUT8) {
     if (p.q_on) {  // fused per-head RMSNorm + RoPE + head-major / transposed stores (x2i_gemm_qkv_fp8), same code as the bf16 kernel
-      epilogue_qkv<8, 4, 512>(p, acc, z, m0, n0, wm, wn, lane, tid, smem);
+      epilogue_qkv<8, 4, 512>(pe, acc, z, m0, n0, wm, wn, lane, tid, smem);
       return;
     }
   }
   if constexpr (OUT8) {
-    epilogue_store_fp8<ACT>(p, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
+    epilogue_store_fp8<ACT>(pe, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
   } else {
-    epilogue_store_lds<ACT, RES, false, 8>(p, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
+    epilogue_store_lds<ACT, RES, false, 8>(pe, acc, z, m0 + wm * 128, n0 + wn * 64, lane, smem + wave * EPI_WAVE_BYTES);
   }
 }
 

@@ -32,36 +32,33 @@ constexpr int P_STAGE_WAVE = 8192;
 // L2 sees every line once), two chunks ahead of its use.  (The first form of this epilogue fetched residual rows by LDS-DMA into the
 // staging buffer, one chunk ahead -- all the look-ahead 8 KiB allow -- and waited ~2 us per chunk for it: 17 us per tile.)
 // e4m3 operands (F8): the accumulators hold sum_k A8 W8; the value every epilogue starts from is
-//     deq(acc) = fma(acc, a_scale[z][m] * (w_scale[n] * alpha), 0)
-// -- spelled as an explicit fma with a zero addend so that the product is rounded ONCE and the bias add that follows can never be
-// contracted into it: the one-tile kernel (gemm256_fp8.hip) spells it the same way, and the two are bit-identical (tested).
-struct DeqCols {
-  float v[8][4];   // w_scale[n] * alpha of this lane's 4 columns per 16-column block
+//     deq(acc) + bias = fma(acc * (w_scale[n] * alpha), a_scale[z][m], bias[n])
+// -- a multiply and an explicitly spelled fma (two instructions per element; nothing left for the compiler to contract one way
+// here and another way there): the one-tile kernel (gemm256_fp8.hip) spells it the same way, and the two are bit-identical (tested).
+// The scales are fetched BEFORE the unit's K-loop statement (deq_load: branch-free vector loads, rows / columns beyond the
+// problem read a clamped address -- their results are dropped by the stores), so their latency hides behind the K-loop.
+template <bool F8> struct Deq {};
+template <> struct Deq<true> {
+  float sw[8][4];   // w_scale[n] * alpha of this lane's 4 columns per 16-column block
+  float sr[4][2];   // a_scale of rows m_wave + c * 32 + i * 16 + (lane & 15)
 };
 template <bool F8>
-__device__ __forceinline__ void deq_cols(const GemmP& p, int n_wave, int lane, DeqCols& d) {
+__device__ __forceinline__ void deq_load(const GemmP& p, int z, int m_wave, int n_wave, int lane, Deq<F8>& d) {
   if constexpr (F8) {
-    const int ng = lane >> 4;
+    const int ng = lane >> 4, mlane = lane & 15;
     static_for<8>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       const int n = n_wave + j * 16 + ng * 4;
+      f32x4_t v = {1.f, 1.f, 1.f, 1.f};
+      if (p.f_sw) v = *(const f32x4_t*)(p.f_sw + (n < p.N ? n : 0));   // (N % 8 == 0 and 16-byte aligned scales: launcher)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d.v[j][r] = (p.f_sw && n + r < p.N) ? p.f_sw[n + r] * p.f_alpha : p.f_alpha;
+      for (int r = 0; r < 4; ++r) d.sw[j][r] = v[r] * p.f_alpha;
     });
-  }
-}
-// a_scale of rows m_wave + c * 32 + i * 16 + (lane & 15), c = 0..3, i = 0 / 1
-template <bool F8>
-__device__ __forceinline__ void deq_rows(const GemmP& p, int z, int m_wave, int lane, float (&sr)[4][2]) {
-  if constexpr (F8) {
     const float* sa = p.f_sa ? p.f_sa + (long long)z * p.f_sa_bs : nullptr;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m_wave + c * 32 + i * 16 + (lane & 15);
-        sr[c][i] = (sa && m < p.M) ? sa[m] : 1.f;
-      }
+      for (int i = 0; i < 2; ++i) d.sr[c][i] = sa ? sa[min(m_wave + c * 32 + i * 16 + mlane, p.M - 1)] : 1.f;
   }
 }
 
@@ -70,9 +67,9 @@ __device__ __forceinline__ void deq_rows(const GemmP& p, int z, int m_wave, int 
 // [32 rows][64 B] (16-byte piece pc of row r at pc ^ ((r >> 1) & 3): conflict-free 4-byte parks), a lane parks its four consecutive
 // columns as one packed dword, rows leave as 64-byte runs (16-byte stores, 16 rows per wave instruction).  Arithmetic of
 // epilogue_store_fp8 (gemm256_fp8.hip): sat(act(deq(acc) + bias) * out_inv_scale) -> v_cvt_pk_fp8_f32.
-template <int ACT>
+template <int ACT, bool UNIT_OUT>
 __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                           char* stage) {
+                                                           char* stage, const Deq<true>& dq) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int mlane = lane & 15, ng = lane >> 4;
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
@@ -97,10 +94,6 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
       }
     }
   });
-  DeqCols dc;
-  deq_cols<true>(p, n_wave, lane, dc);
-  float sr[4][2];
-  deq_rows<true>(p, z, m_wave, lane, sr);
   const uint32_t c_bytes = (uint32_t)((long long)(p.M - 1) * p.ldc + p.N);
   __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)p.C + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
   // store piece `it` (0 / 1) of a chunk: row it * 16 + (lane >> 2), 16-byte piece (lane & 3) ^ swizzle(row)
@@ -127,8 +120,9 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
       for (int r = 0; r < 4; ++r) {
         float t;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
-        t = fmaf(t, sr[c][i] * dc.v[h * 4 + j][r], 0.f);
-        v[r] = __builtin_amdgcn_fmed3f(apply_act(t + bv[h * 4 + j][r], ACT) * p.f_oinv, -448.f, 448.f);
+        t = apply_act(fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]), ACT);
+        if constexpr (!UNIT_OUT) t *= p.f_oinv;   // (out_inv_scale == 1, the model's setting: the multiply is skipped -- x * 1 is x)
+        v[r] = __builtin_amdgcn_fmed3f(t, -448.f, 448.f);
       }
       int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
       pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
@@ -162,15 +156,11 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
 
 template <int ACT, bool HASC2, bool RES, bool F8 = false>
 __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                      char* stage) {
+                                                      char* stage, const Deq<F8>& dq) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   const int mlane = lane & 15, ng = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
-  DeqCols dc;
-  deq_cols<F8>(p, n_wave, lane, dc);
-  float sr[4][2];
-  deq_rows<F8>(p, z, m_wave, lane, sr);
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
 #ifdef X2I_ABLATION
   if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer, tools/gemm_unit_timeline.py)
@@ -253,8 +243,8 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
       for (int r = 0; r < 4; ++r) {
         float t;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
-        if constexpr (F8) t = fmaf(t, sr[c][i] * dc.v[h * 4 + j][r], 0.f);
-        v[r] = apply_act(t + bv[h * 4 + j][r], ACT);
+        if constexpr (F8) v[r] = apply_act(fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]), ACT);
+        else v[r] = apply_act(t + bv[h * 4 + j][r], ACT);
       }
       if constexpr (RES) {
         const u32x2 r2 = rres[q % 3][i][j];
@@ -317,7 +307,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
 //          writes two 16-byte token runs of V^T, 8 lanes cover a 128-byte line.
 template <bool F8 = false>
 __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                     char* stage) {
+                                                     char* stage, const Deq<F8>& dq) {
   // every per-lane offset below is cheap to recompute; hidden from loop-invariant code motion, or hipcc computes the lot once in front
   // of the persistent loop and then spills it (73 registers, reloaded from scratch between this epilogue's stores)
   asm volatile("" : "+v"(lane));
@@ -337,10 +327,6 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
   };
   const TokMap tmap = tok_map(p, z, m_wave);
   auto token = [&](int m, int& b, int& st) { tok_of(tmap, m - m_wave, b, st); };  // rows m_wave <= m < m_wave + 128
-  DeqCols dc;
-  deq_cols<F8>(p, n_wave, lane, dc);
-  float sr[4][2];
-  deq_rows<F8>(p, z, m_wave, lane, sr);
   if (sec < 2) {
     const int c = lane & 15, rsub = lane >> 4;  // 8-dim chunk of the head; row of the pass
     float w[8];
@@ -385,8 +371,8 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
           for (int r = 0; r < 4; ++r) {
             float t;
             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c2][rr][j][r]));
-            if constexpr (F8) t = fmaf(t, sr[c2][rr] * dc.v[h * 4 + j][r], 0.f);
-            a[r] = t + bias_of(h * 4 + j, r);
+            if constexpr (F8) a[r] = fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c2][rr], bias_of(h * 4 + j, r));
+            else a[r] = t + bias_of(h * 4 + j, r);
           }
           *(uint2*)(buf + mlane * 256 + (((h * 8 + j * 2 + (ng >> 1)) ^ mlane) << 4) + ((ng & 1) << 3)) =
               make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
@@ -460,8 +446,8 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
             for (int r = 0; r < 4; ++r) {
               float t;
               asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c2][rr][j][r]));
-              if constexpr (F8) t = fmaf(t, sr[c2][rr] * dc.v[h * 4 + j][r], 0.f);
-              a[r] = t + bias_of(h * 4 + j, r);
+              if constexpr (F8) a[r] = fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c2][rr], bias_of(h * 4 + j, r));
+              else a[r] = t + bias_of(h * 4 + j, r);
             }
             *(uint2*)(stage + row * 128 + (((j * 2 + (ng >> 1)) ^ fsw(row)) << 4) + ((ng & 1) << 3)) =
                 make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
@@ -741,6 +727,8 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
                  : [vo] "v"(slab_vo), [rs] "s"(s_rsrc), [fromp] "s"(fromp)
                  : "memory", "scc");
     const int zs = 1 - fromp;
+    Deq<F8> dq;   // e4m3: the dequantisation scales of this unit's rows / columns, requested in front of its K-loop
+    deq_load<F8>(prob(pp, sel), z, m0 + wm * 128, n0 + wn * 128, lane, dq);
 #ifdef X2I_ABLATION
     // measurement only: 100 MHz timestamps of every unit's K-loop (start, end) of the first 4 workgroups and one per XCD, into p.bias2
     unsigned long long* tdbg = (p.act2 >= 79 && tid == 0 && w < 16) ? (unsigned long long*)p.bias2 + w * 64 : nullptr;
@@ -782,9 +770,11 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
         asm volatile("" ::X2I_GEMM256P_OPS_ACC_IN(acc));
       } else
 #endif
-      if constexpr (QKV) epilogue_qkv_chunked<F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
-      else if constexpr (OUT8) epilogue_chunked_pipe_e4m3<ACT>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
-      else epilogue_chunked_pipe<ACT, HASC2, RES, F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage);
+      if constexpr (QKV) epilogue_qkv_chunked<F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage, dq);
+      else if constexpr (OUT8) {
+        if (p.f_oinv == 1.f) epilogue_chunked_pipe_e4m3<ACT, true>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage, dq);
+        else epilogue_chunked_pipe_e4m3<ACT, false>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage, dq);
+      } else epilogue_chunked_pipe<ACT, HASC2, RES, F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage, dq);
     }
     if (!has_next) break;
     cur = nxt; sel = nsel; z = nz; m0 = nm0; n0 = nn0; k0b = nk0b;
