@@ -55,7 +55,11 @@ const char* x2i_last_error(void);
  * environment variable X2I_<NAME> and afterwards only changes through x2i_set_option -- nothing on the launch path reads
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
  * "gemm_w4" (1: 4-wave hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output
- * tiles), "gemm_fp8_persist" (1: x2i_gemm_fp8 / x2i_gemm_qkv_fp8 take the persistent four-wave form too; 0: the one-tile e4m3 kernel, bit-identical), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
+ * tiles), "gemm_fp8_persist" (1: x2i_gemm_fp8 / x2i_gemm_qkv_fp8 take the persistent four-wave form too; 0: the one-tile e4m3 kernel, bit-identical),
+ * "gemm_fx" (1: a gated-residual launch whose batch ITEM has fewer 256^2 output tiles than the chip has CUs, with K >= 6144, is cut along K
+ * over all CUs -- every part summed from zero in parallel, the parts of a tile added in a fixed order by the workgroup that holds the last
+ * one; needs the workspace.  Decided and cut by the item's shape alone, so a sample's result does not depend on its batch; deterministic;
+ * NOT bit-identical to the whole-tile kernels (another association of the K sum, same tolerance).  0: whole tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
  * through the CALLER's workspace, x2i_gemm_args.workspace -- bit-identical to the one-tile kernel; 0, or no workspace: the peeled
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked

@@ -76,7 +76,7 @@ static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   p.f_sa = p.f_sw = nullptr; p.f_sa_bs = 0; p.f_alpha = p.f_oinv = 1.f; p.f_out8 = 0;
-  p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr;
+  p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr; p.fx_v0 = 0;
   if (qd) {
     p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps; p.q_qs = qd->q_scale == 0.f ? 1.f : qd->q_scale;
     p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
@@ -118,6 +118,38 @@ static bool streamk_for(const x2i_gemm_args* a, long long tiles, int nkt, int cu
   return x2i_streamk_workspace(a, slabs, flags, rc);   // the caller's workspace (include/x2i.h); none: whole tiles / peeled tail
 }
 
+// Parallel split with fix-up (gemm256p.hip, FX): for launches that cannot fill the chip with whole 256^2 tiles -- fewer tiles per batch
+// item than CUs -- and whose K is deep enough to cut (>= 96 K-tiles): the gated-residual linears of a small batch (single-block
+// proj_out, K = 15360; ff.net.2 / ff_context.net.2, K = 12288; infer/inference_qwenvl.py:233-237 samples at batch 1).  The decision and
+// the cuts depend on ONE batch item's shape only, never on the batch: a sample's result is the same whatever rides with it.
+// a1: the second problem of a grouped launch (or null); *v0 = workgroups per XCD (of cus / 8) that share problem 0's tiles.
+static bool fx_for(const x2i_gemm_args* a0, const x2i_gemm_args* a1, int cus, int* v0, float** slabs, unsigned** flags, int* rc) {
+  const X2IOptions& opt = x2i_options();
+  *rc = X2I_OK;
+  if (!(opt.gemm_fx && opt.gemm_streamk && opt.gemm_tile == 0 && cus <= SK_MAX_TILES && a0->workspace)) return false;
+  const int nk = a0->K / BK;
+  if (nk < 96 || !a0->res || a0->act != X2I_ACT_NONE || a0->C2 || a0->out_f32) return false;
+  if (a1 && (a1->batch != a0->batch || !a1->res || a1->act != X2I_ACT_NONE || a1->C2 || a1->out_f32)) return false;
+  const long long T0 = (long long)((a0->M + BM2 - 1) / BM2) * ((a0->N + BN2 - 1) / BN2);
+  const long long T1 = a1 ? (long long)((a1->M + BM2 - 1) / BM2) * ((a1->N + BN2 - 1) / BN2) : 0;
+  const long long Ts = T0 + T1;
+  if (Ts >= cus || Ts * 5 < cus) return false;                 // whole tiles fill the chip / too few tiles: more than five parts per tile
+  // the split is per XCD (an XCD's cus / 8 workgroups share the K-tile space of the item tiles the tile order gives that XCD)
+  if ((cus & 7) || (T0 & 7) || (T1 & 7)) return false;
+  const int gx = cus >> 3;
+  int va = gx;
+  if (a1) {
+    va = (int)((gx * T0 + Ts / 2) / Ts);
+    if (va < 1 || va >= gx) return false;
+  }
+  const int vb = gx - va;
+  auto share_ok = [&](long long T, int v) { return (T >> 3) <= v && (T >> 3) * 6 >= v; };   // one finisher per tile; at most six parts per tile
+  if (!share_ok(T0, va) || (a1 && !share_ok(T1, vb))) return false;
+  if (!x2i_streamk_workspace(a0, slabs, flags, rc)) return false;
+  *v0 = va;
+  return true;
+}
+
 // Two GEMMs of the same kind in ONE persistent launch (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16): problem 1's tiles follow problem
 // 0's in the tile list.  Same results as two launches (each output tile is computed exactly as before); taken when both problems
 // are served by the persistent kernel, have the same K and the same epilogue kind; otherwise the two launches are issued one
@@ -148,11 +180,23 @@ int x2i_launch_gemm_pair(const x2i_gemm_args* a0, const x2i_qkv_desc* q0, const 
     p.nbatch = as[i]->batch;
     tiles += (long long)p.tilesM * p.tilesN * p.nbatch;
   }
-  int rc = x2i_ensure_dynamic_smem((const void*)kern, SMEM2P_BYTES);
-  if (rc) return rc;
   const int cus = x2i_num_cus();
   float* sk_slabs = nullptr;
   unsigned* sk_flags = nullptr;
+  int rc = X2I_OK, v0 = 0;
+  if (!q0 && fx_for(a0, a1, cus, &v0, &sk_slabs, &sk_flags, &rc)) {   // small batch: the two problems' tiles cut along K over all CUs
+    kern2_t kfx = pick_gemm256p_pair_fx();
+    rc = x2i_ensure_dynamic_smem((const void*)kfx, SMEM2P_BYTES);
+    if (rc) return rc;
+    pp.p[0].fx_v0 = v0;
+    for (int i = 0; i < 2; ++i) pp.p[i].sk_slabs = sk_slabs, pp.p[i].sk_flags = sk_flags;   // (the epilogue of either problem reads the slabs)
+    hipLaunchKernelGGL(kfx, dim3((unsigned)cus), dim3(256), SMEM2P_BYTES, stream, pp);
+    opt.last_gemm_tile = 3256;  // (read-back for tests: grouped launch, parallel split with fix-up)
+    return x2i_check_launch("gemm_pair (fx)");
+  }
+  if (rc) return rc;
+  rc = x2i_ensure_dynamic_smem((const void*)kern, SMEM2P_BYTES);
+  if (rc) return rc;
   const bool sk = streamk_for(a0, tiles, a0->K / BK, cus, &sk_slabs, &sk_flags, &rc);
   if (rc) return rc;
   pp.p[0].sk_on = sk ? 1 : 0; pp.p[0].sk_slabs = sk_slabs; pp.p[0].sk_flags = sk_flags;
@@ -208,6 +252,28 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // convolutions with >= 256 output channels: the full-line kernel's implicit-GEMM form (option conv256 = 0: 128^2 tiles, A/B)
   bool conv256 = false;
   if (conv && a->N >= 256 && a->N % 8 == 0 && tiles256 >= min256 && a->M >= 1024 && opt.conv256) conv256 = use256 = true;
+  // small batches: a launch whose batch item has fewer 256^2 tiles than the chip has CUs, with a deep K, is cut along K over all CUs
+  // (parallel split with fix-up, fx_for above); decided by the item's shape alone
+  if (!conv && !qd && fast && kern2 && opt.gemm_w4 == 1 && persistent_ok(a, nullptr)) {
+    const int cus = x2i_num_cus();
+    float* fslabs = nullptr;
+    unsigned* fflags = nullptr;
+    int frc = X2I_OK, v0 = 0;
+    if (fx_for(a, nullptr, cus, &v0, &fslabs, &fflags, &frc)) {
+      kern_t kfx = pick_gemm256p_fx();
+      int rc = x2i_ensure_dynamic_smem((const void*)kfx, SMEM2P_BYTES);
+      if (rc) return rc;
+      GemmP pm = p;
+      pm.tilesM = (a->M + BM2 - 1) / BM2; pm.tilesN = (a->N + BN2 - 1) / BN2;
+      pm.gm = pick_gm(pm.tilesN, a->K);
+      pm.nbatch = a->batch;
+      pm.fx_v0 = v0; pm.sk_slabs = fslabs; pm.sk_flags = fflags;
+      hipLaunchKernelGGL(kfx, dim3((unsigned)cus), dim3(256), SMEM2P_BYTES, stream, pm);
+      opt.last_gemm_tile = 3256;
+      return x2i_check_launch("gemm (fx)");
+    }
+    if (frc) return frc;
+  }
   if (force == 128) use256 = false;
   if (force == 256 && !conv) use256 = true;
   if (conv && !conv256) use256 = false;
@@ -385,7 +451,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   }
   p.f_sa = f->a_scale; p.f_sa_bs = f->a_scale_batch_stride; p.f_sw = f->w_scale; p.f_alpha = f->alpha; p.f_oinv = f->out_inv_scale;
   p.f_out8 = out8 ? 1 : 0;
-  p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr;
+  p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr; p.fx_v0 = 0;
 #ifdef X2I_ABLATION
   p.act2 = a->act2;   // (measurement library: the unit-timeline hooks of gemm256p.hip, tools/gemm_unit_timeline.py --fp8)
 #endif

@@ -154,9 +154,12 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
   });
 }
 
-template <int ACT, bool HASC2, bool RES, bool F8 = false>
+// FXADD: the accumulators hold only the LAST K range of the tile (parallel split with fix-up); `npre` other workgroups have parked the
+// sums of the earlier ranges in slabs fx_slab0, fx_slab0 + 8, ... (accumulator layout, [64 tiles][256 threads][16 B]); they are fetched a
+// chunk ahead, summed in slab order and added to the accumulators in front of the bias: out = epi((p_0 + p_1 + ...) + acc).
+template <int ACT, bool HASC2, bool RES, bool F8 = false, bool FXADD = false>
 __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                      char* stage, const Deq<F8>& dq) {
+                                                      char* stage, const Deq<F8>& dq, int fx_slab0 = 0, int npre = 0, int tid = 0) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   const int mlane = lane & 15, ng = lane >> 4;
@@ -202,6 +205,24 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
 #pragma unroll
     for (int i = 0; i < 2; ++i) roff[i] = (uint32_t)(((long long)(m_wave + i * 16 + mlane) * p.ldr + n_wave + ng * 4) * 2);
   }
+  // fix-up partials: window of two chunks, rp[q & 1][i][j] = sum over the predecessors' slabs of accumulator tile (2c + i, 4h + j)
+  f32x4_t rp[FXADD ? 2 : 1][2][4];
+  auto load_part = [&](auto qc) {
+    if constexpr (FXADD) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int h = q >> 2, c = q & 3;
+      const float* base = p.sk_slabs + (long long)fx_slab0 * (SK_SLAB_BYTES / 4) + tid * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* src = base + ((2 * c + i) * 8 + 4 * h + j) * 1024;
+          f32x4_t sum = *(const f32x4_t*)src;
+          for (int u = 1; u < npre; ++u) sum += *(const f32x4_t*)(src + (long long)u * 8 * (SK_SLAB_BYTES / 4));   // (the XCD's workgroups, hence their slabs, are 8 apart)
+          rp[q & 1][i][j] = sum;
+        }
+    }
+  };
   u32x2 rres[RES ? 3 : 1][2][4];   // residual window: chunk q lives in rres[q % 3]
   auto load_res = [&](auto qc) {
     if constexpr (RES) {
@@ -243,6 +264,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
       for (int r = 0; r < 4; ++r) {
         float t;
         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
+        if constexpr (FXADD) t = rp[q & 1][i][j][r] + t;
         if constexpr (F8) v[r] = apply_act(fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]), ACT);
         else v[r] = apply_act(t + bv[h * 4 + j][r], ACT);
       }
@@ -269,6 +291,8 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
     constexpr int s_ = decltype(sc)::value;
     stage_a(std::integral_constant<int, s_ / NPASS>{}, jc, s_ % NPASS, s_ & 1);
   };
+  load_part(std::integral_constant<int, 0>{});
+  load_part(std::integral_constant<int, 1>{});
   load_res(std::integral_constant<int, 0>{});
   load_res(std::integral_constant<int, 1>{});
   static_for<4>([&](auto jc) { run_a(std::integral_constant<int, 0>{}, jc); });
@@ -279,6 +303,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
     char* buf = stage + (s_ & 1) * 4096;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (RES && s_ + 2 < NST) load_res(std::integral_constant<int, s_ + 2>{});   // (window slot of chunk s-1, consumed by A(s-1))
+    if constexpr (FXADD && s_ + 2 < NST) load_part(std::integral_constant<int, s_ + 2>{});   // (slot of chunk s, consumed by A(s) in step s - 1; HASC2 is never combined with FXADD)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A(s)'s writes have landed (and B(s-1)'s reads returned long ago)
 #pragma unroll
     for (int it = 0; it < 4; ++it) d[it] = *(const u32x4*)(buf + it * 1024 + lane * 16);   // B(s)
@@ -504,6 +529,8 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
 // undivided tile -- bit-identical results, no reduction of partial sums).
 struct Unit {
   int vb, k0, len, slab;  // slab = index of the split tile (partial-accumulator slab and progress flag); -1: whole tile
+  int kind = 0, tag = 0;  // FX units: kind 1 = park this range's sums in slab[workgroup] (flag <- tag), 2 = finish the tile: add the `slab`
+                          // parked ranges of the workgroups in front (flags == tag), epilogue; tag = batch item + 1
 };
 
 template <bool PAIR> using GemmArg = std::conditional_t<PAIR, GemmP2, GemmP>;
@@ -523,7 +550,7 @@ __device__ __forceinline__ GemmP prob(const GemmP2& a, int sel) {
   X2I_F(out_f32) X2I_F(tilesM) X2I_F(tilesN) X2I_F(cH) X2I_F(cW) X2I_F(cCin) X2I_F(cOW) X2I_F(cKW) X2I_F(cStride) X2I_F(cPad) X2I_F(cUp)
   X2I_F(q_on) X2I_F(q_H) X2I_F(q_Spad) X2I_F(q_tok_off) X2I_F(q_rpb) X2I_F(q_row0) X2I_F(gm) X2I_F(q_eps) X2I_F(q_qs) X2I_F(q_nq) X2I_F(q_nk)
   X2I_F(q_cos) X2I_F(q_sin) X2I_F(q_Q) X2I_F(q_K) X2I_F(q_VT) X2I_F(f_sa) X2I_F(f_sa_bs) X2I_F(f_sw) X2I_F(f_alpha) X2I_F(f_oinv) X2I_F(f_out8)
-  X2I_F(nbatch) X2I_F(sk_on) X2I_F(sk_slabs) X2I_F(sk_flags)
+  X2I_F(nbatch) X2I_F(sk_on) X2I_F(sk_slabs) X2I_F(sk_flags) X2I_F(fx_v0)
 #undef X2I_F
   return q;
 }
@@ -534,7 +561,13 @@ __device__ __forceinline__ GemmP prob(const GemmP2& a, int sel) {
 // F8: e4m3 operands (x2i_gemm_fp8 / x2i_gemm_qkv_fp8) -- the same unit list, stream-K chain, LDS images and epilogue pipelines around the
 // K-loop of gen_gemm256f8.py (one K = 128 MFMA per accumulator and K-tile, fragments in v128..v255); every byte offset below is
 // computed with the element size ES.  OUT8: e4m3 output (epilogue_chunked_pipe_e4m3).
-template <int ACT, bool RES, bool HASC2, bool QKV = false, bool PAIR = false, bool F8 = false, bool OUT8 = false>
+// FX: parallel split with fix-up for launches whose tiles cannot fill the chip (fewer tiles per batch item than CUs, deep K): the tiles of
+// ONE batch item are cut along K so that every workgroup has (about) the same number of K-tiles (see the per-XCD rule below), every part
+// starts its accumulators from zero -- no workgroup waits for another one's K-loop -- and the workgroup that finishes a tile adds the parked
+// sums of its other parts in its epilogue (FXADD).  The cuts depend on the item's tile count, K and G only and every item is cut the same
+// way: a sample's result does not depend on the batch it rides in.  NOT bit-identical to the one-tile kernels (the K sum is associated
+// differently); deterministic.
+template <int ACT, bool RES, bool HASC2, bool QKV = false, bool PAIR = false, bool F8 = false, bool OUT8 = false, bool FX = false>
 __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
   constexpr int ES = F8 ? 1 : 2;            // bytes per operand element
   constexpr int KT = F8 ? 128 : BK;         // elements per K-tile (128 bytes of a row either way)
@@ -593,6 +626,52 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
     const GemmP& q = prob(pp, sel);
     return mk_rsrc(q.W, (uint32_t)(((long long)(q.N - 1) * q.ldw + q.K) * ES));
   };
+  // ---- FX: what this workgroup does for ONE batch item (the same for every item): fx_cnt units, unit u = K-tiles [fx_k0, fx_k0 + fx_len) of
+  // the XCD's tile fx_t0 + u * fx_tstep of problem fx_sel; fx_kind 1 = park the sums (P), 2 = finish the tile (F: add fx_npre parked parts)
+  int fx_sel = 0, fx_Tp = 0, fx_nbz = 0, fx_kind = 0, fx_cnt = 0, fx_t0 = 0, fx_tstep = 1, fx_k0 = 0, fx_len = 0, fx_npre = 0, fx_modeB = 0, fx_slab_base = 0;
+  const int fx_x = w & 7;
+  if constexpr (FX) {
+    // Per XCD: workgroup w runs on XCD w & 7 (round-robin dispatch) and the tile order gives that XCD the tiles bid = 8 t + (w & 7) of an
+    // item (tile_of: its L2 then holds their operand panels).  The XCD's G / 8 workgroups share THOSE Tx tiles, v of them per problem:
+    //   v < 2 Tx  ("B"): workgroup t < Tx multiplies K-tiles [0, c) of tile t and finishes it; the other nt = v - Tx workgroups multiply
+    //                    the tails [c, nk) of tiles j, j + nt, ... one after the other and park them; c = nk tw / (tw + 1), tw = ceil(Tx / nt):
+    //                    a tail workgroup's tw tails take as long as a head, and every head's tail is parked before the head needs it
+    //   v >= 2 Tx ("A"): tile t is cut into v / Tx (the first v % Tx tiles: one more) equal parts, one workgroup each; the last part finishes
+    // Every workgroup of an XCD sweeps K in step with the others on the same tile row (the heads all start at K-tile 0), so the A panel
+    // of a tile row is fetched once per XCD -- a tile-major stream-K cut (every workgroup at another K offset) ran 5-40 % SLOWER than
+    // whole tiles: profiles/r04g_fx_bench_streamk_cut.log.
+    const int wi = w >> 3, Gx = G >> 3;
+    const int v0 = p.fx_v0;                     // of the XCD's Gx workgroups, v0 take problem 0's tiles
+    fx_sel = PAIR ? min(max(wi - v0 + 1, 0), 1) : 0;
+    const GemmP& q = prob(pp, fx_sel);
+    const int li = wi - fx_sel * v0, v = fx_sel ? Gx - v0 : v0;
+    fx_Tp = q.tilesM * q.tilesN;
+    fx_nbz = q.nbatch;
+    fx_slab_base = fx_sel * (first(pp).tilesM * first(pp).tilesN);
+    const int Tx = fx_Tp >> 3;                  // (tiles per item: a multiple of 8, launcher)
+    if (v < 2 * Tx) {
+      fx_modeB = 1;
+      const int nt = v - Tx;                    // (0: every workgroup takes a whole tile)
+      const int tw = nt > 0 ? (Tx + nt - 1) / nt : 0;
+      const int c = nt > 0 ? min(max(nk * tw / (tw + 1), 3), nk - 3) : nk;
+      if (li < Tx) {
+        fx_kind = 2; fx_cnt = 1; fx_t0 = li; fx_k0 = 0; fx_len = c; fx_npre = nt > 0 ? 1 : 0;
+      } else {
+        const int j = li - Tx;
+        fx_kind = 1; fx_t0 = j; fx_tstep = nt; fx_cnt = (Tx - j + nt - 1) / nt; fx_k0 = c; fx_len = nk - c;
+      }
+    } else {
+      const int base = v / Tx, extra = v - base * Tx;     // tiles t < extra: base + 1 parts
+      const int cutw = extra * (base + 1);
+      const int t = li < cutw ? li / (base + 1) : extra + (li - cutw) / base;
+      const int P = t < extra ? base + 1 : base;
+      const int j = li < cutw ? li - t * (base + 1) : (li - cutw) - (t - extra) * base;
+      const int k_lo = (int)((long long)nk * j / P), k_hi = (int)((long long)nk * (j + 1) / P);
+      fx_cnt = 1; fx_t0 = t; fx_k0 = k_lo; fx_len = k_hi - k_lo;
+      fx_kind = j == P - 1 ? 2 : 1;
+      fx_npre = P - 1;
+    }
+  }
   // ---- this workgroup's unit list: S whole tiles (vb = w + s*G) and, with stream-K, up to two segments of the last round's tiles
   int S = TT / G;
   auto hasXlen = [](const Unit& u) { return u.len > 0; };
@@ -624,8 +703,23 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
     S += 1;  // no splitting: the last round's tiles are whole tiles of the first workgroups
   }
   const int hasH = segH.len > 0, hasX = segX.len > 0;
-  const int n_units = S + hasH + hasX;
+  const int n_units = FX ? fx_cnt * fx_nbz : S + hasH + hasX;
   auto unit = [&](int i) -> Unit {
+    if constexpr (FX) {
+      if (i >= n_units) return Unit{-1, 0, 0, -1};
+      const int zi = i / fx_cnt, uu = i - zi * fx_cnt;
+      const int tile = (fx_t0 + uu * fx_tstep) * 8 + fx_x;
+      Unit u;
+      u.vb = fx_sel * TT0 + zi * fx_Tp + tile;
+      u.k0 = fx_k0;
+      u.len = fx_len;
+      // P: the slab this range is parked in -- "B": the tile's (a tail workgroup parks several per item), "A": the workgroup's;
+      // F: the first of the fx_npre slabs to add (they are 8 apart in "A": the XCD's workgroups)
+      u.slab = fx_modeB ? fx_slab_base + tile : (fx_kind == 1 ? w : w - 8 * fx_npre);
+      u.kind = fx_kind;
+      u.tag = zi + 1;
+      return Unit{uni(u.vb), uni(u.k0), uni(u.len), uni(u.slab), uni(u.kind), uni(u.tag)};
+    }
     Unit u{w + (i - hasH) * G, 0, nk, -1};
     if (i >= n_units) u = Unit{-1, 0, 0, -1};
     else if (hasH && i == 0) u = segH;
@@ -701,7 +795,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
     }
     const int nk0b = nxt.k0 * 128, len = cur.len;
     f32x4_t acc[2][4][2][4];
-    const int fromp = min(cur.k0, 1);  // (integer arithmetic, not a comparison: hipcc materialises an i1 in a VGPR, which cannot feed "s")
+    const int fromp = FX ? 0 : min(cur.k0, 1);  // (integer arithmetic, not a comparison: hipcc materialises an i1 in a VGPR, which cannot feed "s"); FX ranges always start from zero
     if (fromp) {
       // continue a tile: wait until the predecessor has published K-tiles [0, k0) (flag == k0) -- bounded, so that a lost
       // predecessor leaves a marker instead of a hung GPU
@@ -752,7 +846,47 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
 #ifdef X2I_ABLATION
     if (tdbg && ui < 31) tdbg[2 * ui + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (cur.k0 + cur.len < nk) {
+    auto spin_until = [&](unsigned* flag, unsigned want) {   // (thread 0) bounded, so that a lost partner leaves a marker instead of a hung GPU
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1 << 22)) {
+          __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    };
+    if constexpr (FX) {
+      if (cur.kind == 1) {
+        // park this range's sums; the slab is free once the finisher of the previous item's tile has reset its flag
+        if (tid == 0) spin_until(p.sk_flags + cur.slab, 0u);
+        __syncthreads();
+        __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(cur.slab);
+        asm volatile(X2I_GEMM256P_STORE_PARTIAL
+                     : [so] "=&s"(s_so)
+                     : X2I_GEMM256P_OPS_ACC_IN(acc), [vo] "v"(slab_vo), [rs] "s"(s_rsrc)
+                     : "memory", "scc");
+        __syncthreads();
+        // (relaxed: the slab went out as write-through stores drained inside the statement; a RELEASE here would write back the XCD's whole L2)
+        if (tid == 0) __hip_atomic_store(p.sk_flags + cur.slab, (unsigned)cur.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        // finish the tile: fx_npre other workgroups have parked (or are about to park) the other K ranges
+        const int npre = fx_npre;
+        if (npre > 0) {
+          if (tid == 0) {
+            for (int q = 0; q < npre; ++q) spin_until(p.sk_flags + (cur.slab + 8 * q), (unsigned)cur.tag);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          epilogue_chunked_pipe<ACT, HASC2, RES, F8, true>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage, dq, cur.slab, npre, tid);
+          __syncthreads();   // every wave has read the slabs: hand them back
+          if (tid == 0)
+            for (int q = 0; q < npre; ++q) __hip_atomic_store(p.sk_flags + (cur.slab + 8 * q), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          epilogue_chunked_pipe<ACT, HASC2, RES, F8>(prob(pp, sel), acc, z, m0 + wm * 128, n0 + wn * 128, lane, stage, dq);
+        }
+      }
+    } else if (cur.k0 + cur.len < nk) {
       // hand the accumulators to the next segment of this tile: write-through stores, drained inside the statement; the flag
       // (K-tiles accumulated so far) goes out behind a workgroup barrier
       __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(cur.slab);
@@ -813,6 +947,9 @@ kern_t pick_gemm256p_fp8(int act, bool res, bool out8, bool qkv) {
   if (act == X2I_ACT_GELU_TANH) return gemm256p_kernel<X2I_ACT_GELU_TANH, false, false, false, false, true>;
   return nullptr;
 }
+
+kern_t pick_gemm256p_fx() { return gemm256p_kernel<X2I_ACT_NONE, true, false, false, false, false, false, true>; }
+kern2_t pick_gemm256p_pair_fx() { return gemm256p_kernel<X2I_ACT_NONE, true, false, false, true, false, false, true>; }
 
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2) {
   if (f32) return nullptr;

@@ -43,6 +43,9 @@ struct GemmP {
   int nbatch, sk_on;
   float* sk_slabs;
   unsigned* sk_flags;
+  // parallel split with fix-up ("FX", gemm256p.hip): fx_v0 = workgroups per XCD (of G / 8) that share the K-tile space of problem 0's
+  // tiles of one batch item on that XCD; the others share problem 1's (grouped launches).  0: off
+  int fx_v0;
 };
 struct GemmP2 { GemmP p[2]; };                  // grouped launch of the persistent kernel (gemm256p.hip)
 constexpr int SK_MAX_TILES = 256;               // split tiles per launch (< number of CUs)
@@ -480,7 +483,9 @@ kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop, persistent over output tiles (gemm256p.hip)
 kern_t pick_gemm256p_qkv();                                 // ... with the fused QKV epilogue (x2i_gemm_qkv_bf16)
-kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
+kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);
+kern_t pick_gemm256p_fx();        // gated-residual epilogue, parallel split with fix-up (launches that cannot fill the chip with whole tiles)
+kern2_t pick_gemm256p_pair_fx();  // ... grouped form     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
 constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);
 kern_t pick_gemm256p_fp8(int act, bool res, bool out8, bool qkv);  // ... in the persistent four-wave form (gemm256p.hip, gen_gemm256f8.py)  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
