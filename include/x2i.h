@@ -167,6 +167,7 @@ int x2i_ln_modulate_fp8(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64
 typedef struct x2i_conv_desc {
   int32_t H, W, Cin, KH, KW, stride, pad;
   int32_t up; /* 1: F.interpolate(scale_factor=2, mode="nearest") fused in front of the conv (diffusers Upsample2D) */
+  int32_t pad_w; /* padding along W; negative: the same as `pad` (which then pads both dimensions, nn.Conv2d(padding=int)) */
 } x2i_conv_desc;
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
 
@@ -183,6 +184,18 @@ int64_t x2i_groupnorm_scratch_floats(int32_t B, int32_t G);
 int x2i_groupnorm_nhwc_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight,
                             const void* bias, float eps, int32_t act, const float* pre_add, const void* post_add,
                             float* partial, x2i_stream_t stream);
+
+/* The same GroupNorm with its statistics taken from cached per-channel moments: x2i_groupnorm_moments_f32 writes moments f32
+ * [B][C][2] = (sum over pixels of x, of x^2) of an NHWC bf16 tensor (scratch: x2i_groupnorm_moments_scratch_floats(B, C) floats), and
+ * x2i_groupnorm_nhwc_from_moments_bf16 normalises x + pre_add with the group statistics derived from them (sum (x + v) = S1 + HW v,
+ * sum (x + v)^2 = S2 + 2 v S1 + HW v^2) -- no statistics pass over x.  For ResnetBlock2D's norm2 in the ControlNeXt branch: its input is
+ * conv1(...) + time_emb_proj(silu(temb)) (diffusers ResnetBlock2D; lightcontrol_flux.py:620-640, forward :741), and conv1's output depends
+ * on the hint only, so its moments are taken once per hint and the per-step statistics cost nothing.  `partial` as above. */
+int64_t x2i_groupnorm_moments_scratch_floats(int32_t B, int32_t C);
+int x2i_groupnorm_moments_f32(const void* x, int32_t B, int64_t HW, int32_t C, float* moments, float* scratch, x2i_stream_t stream);
+int x2i_groupnorm_nhwc_from_moments_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight,
+                                         const void* bias, float eps, int32_t act, const float* moments, const float* pre_add,
+                                         const void* post_add, float* partial, x2i_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * F.scaled_dot_product_attention(q, k, v, dropout_p=0, is_causal=False) for head_dim 128 (diffusers

@@ -86,6 +86,6 @@ def test_struct_layout_matches_the_compiled_abi(tmp_path):
 def test_every_entry_point_is_listed_in_the_integration_table():
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(x2i_\w+)\s*\(", HDR, flags=re.M))
-    missing = [n for n in sorted(declared) if "`%s`" % n not in md and n != "x2i_groupnorm_scratch_floats"]
+    missing = [n for n in sorted(declared) if "`%s`" % n not in md and n not in ("x2i_groupnorm_scratch_floats", "x2i_groupnorm_moments_scratch_floats")]
     assert not missing, missing
     assert "x2i_flux_" not in HDR  # no phantom handle API in the contract

@@ -70,6 +70,28 @@ def test_groupnorm_nhwc(C, G, act):
     assert rel_l2(out.permute(0, 3, 1, 2), ref) < 5e-3
 
 
+@pytest.mark.parametrize("C,G,H,W", [(128, 4, 38, 50), (256, 8, 16, 16), (128, 32, 20, 12), (512, 32, 9, 7)])
+def test_groupnorm_from_cached_channel_moments(C, G, H, W):
+    """ResnetBlock2D norm2 on conv1(...) + time-embedding term (diffusers ResnetBlock2D; lightcontrol_flux.py:620-640): with conv1's output
+    fixed per hint, its per-channel moments (x2i_groupnorm_moments_f32) give the group statistics of x + v for every v without a pass
+    over x.  Against torch's group_norm on x + v, for several v on ONE moment set, and against the two-pass kernel."""
+    from x2i_amd import ops
+    B = 3
+    x = bf(seeded((B, C, H, W), 11, 1.5) + 0.4)
+    w, b = bf(1 + 0.1 * seeded((C,), 12)), bf(0.1 * seeded((C,), 13))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    mom = ops.groupnorm_moments(xn)
+    ref_m = torch.stack([x.float().sum((2, 3)), (x.float() ** 2).sum((2, 3))], -1)
+    assert torch.allclose(mom.cpu(), ref_m, rtol=2e-5, atol=1e-3)
+    for k in range(3):
+        pre = seeded((B, C), 20 + k, 0.7 * k)        # k = 0: no shift at all
+        out = ops.groupnorm_nhwc_from_moments(xn, mom, w.to(DEV), b.to(DEV), G, 1e-6, act=ops.ACT_SILU, pre_add=pre.to(DEV))
+        ref = F.silu(F.group_norm(x.float() + pre[:, :, None, None], G, w.float(), b.float(), 1e-6))
+        assert rel_l2(out.permute(0, 3, 1, 2), ref) < 5e-3
+        two = ops.groupnorm_nhwc(xn, w.to(DEV), b.to(DEV), G, 1e-6, act=ops.ACT_SILU, pre_add=pre.to(DEV))
+        assert rel_l2(out, two) < 2e-3
+
+
 def _load_cnext(seed, out_channels=3072):
     from x2i_amd.lightcontrol import ControlNeXtModel
     sd = OF.random_controlnext_state_dict(seed=seed, out_channels=out_channels)
@@ -86,6 +108,47 @@ def test_controlnext_vs_reference_golden():
     assert rel_l2(o["out"], t["out"]) < 3e-2  # reference ran fp32 weights
     ref = OF.controlnext_forward({k: rb(v) for k, v in sd.items()}, "", rb(t["hint"]), t["timestep"])
     assert rel_l2(o["out"], ref["out"]) < 2e-2
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (128, 64)])
+def test_composed_conv_chains_equal_the_chained_form_incl_borders(H, W):
+    """Round 4: ResnetBlock2D.conv2 (+ shortcut) -> Downsample2D.conv evaluated as ONE 5x5 stride-2 convolution each (lightcontrol.py
+    `_Composed`).  Zero padding of the INTERMEDIATE is reproduced exactly by the first-row / first-column / first-pixel corrections, so
+    the composed form must agree with the chained form everywhere -- border outputs included -- up to bf16 rounding, and with the fp32
+    oracle at the same tolerance as the chained form.  Non-square hint, batch 2, two timesteps on one prepared hint."""
+    m, sd = _load_cnext(31)
+    g = torch.Generator().manual_seed(5)
+    hint = (torch.rand((2, 3, H, W), generator=g) * 2 - 1)
+    outs = {}
+    for compose in (False, True):
+        m.compose = compose
+        prep = m.prepare_hint(hint.to(DEV))
+        assert ("d0" in prep) == compose
+        outs[compose] = [m.forward_nhwc(prep, torch.tensor([t])).float().cpu() for t in (0.25, 0.9)]
+    for k, tval in enumerate((0.25, 0.9)):
+        a, b = outs[True][k], outs[False][k]
+        e = rel_l2(a, b)
+        # the control output grid is (H/16, W/16): its first row / column / pixel descend from the corrected border outputs of both chains
+        eb = max(rel_l2(a[:, 0], b[:, 0]), rel_l2(a[:, :, 0], b[:, :, 0]), rel_l2(a[:, 0, 0], b[:, 0, 0]))
+        ref = OF.controlnext_forward({kk: rb(v) for kk, v in sd.items()}, "", rb(hint), torch.tensor([tval]).expand(2))["out"].permute(0, 2, 3, 1)
+        print(f"H={H} W={W} t={tval}: composed vs chained rel-L2 {e:.2e} (first row / column / pixel {eb:.2e}); vs fp32 oracle: composed "
+              f"{rel_l2(a, ref):.2e}, chained {rel_l2(b, ref):.2e}")
+        assert e < 1.5e-2 and eb < 2e-2
+        assert rel_l2(a, ref) < 2e-2 and rel_l2(a, ref) < 1.5 * rel_l2(b, ref) + 2e-3
+    m.compose = True
+
+
+def test_composed_tap_weights_are_the_convolution_of_the_kernels():
+    """_compose_taps against torch: composing a 3x3 stride-2 conv with a 3x3 conv (interior pixels, where padding plays no part)."""
+    from x2i_amd.lightcontrol import _compose_taps
+    g = torch.Generator().manual_seed(9)
+    wd = bf(torch.randn((128, 3, 3, 128), generator=g) * 0.05)
+    wc = bf(torch.randn((128, 3, 3, 128), generator=g) * 0.05)
+    w5 = _compose_taps(wd.to(DEV), wc.to(DEV)).float().cpu().view(128, 5, 5, 128)
+    x = torch.randn((1, 128, 13, 13), generator=g)
+    y2 = F.conv2d(F.conv2d(x, wc.float().permute(0, 3, 1, 2)), wd.float().permute(0, 3, 1, 2), stride=2)
+    y1 = F.conv2d(x, w5.permute(0, 3, 1, 2), stride=2)
+    assert y1.shape == y2.shape and rel_l2(y1, y2) < 4e-3          # one bf16 rounding of the composed taps
 
 
 def test_transformer_with_control_vs_reference_golden():

@@ -40,7 +40,7 @@ class GemmArgs(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
-                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32)]
+                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32), ("pad_w", C.c_int32)]
 
 
 class QkvDesc(C.Structure):
@@ -71,6 +71,8 @@ SIGNATURES = {
                             _f32, _vp],
     "x2i_conv_stem_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "x2i_groupnorm_nhwc_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
+    "x2i_groupnorm_moments_f32": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
+    "x2i_groupnorm_nhwc_from_moments_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
     "x2i_attention_e4m3out": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _f32, _vp],
     "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
@@ -135,6 +137,8 @@ def load():
     lib.x2i_groupnorm_scratch_floats.argtypes = [_i32, _i32]
     lib.x2i_groupnorm_scratch_floats.restype = C.c_int64
     lib.x2i_is_ablation_build.restype = C.c_int
+    lib.x2i_groupnorm_moments_scratch_floats.argtypes = [_i32, _i32]
+    lib.x2i_groupnorm_moments_scratch_floats.restype = C.c_int64
     lib.x2i_streamk_workspace_bytes.argtypes = []
     lib.x2i_streamk_workspace_bytes.restype = C.c_int64
     for name, argtypes in SIGNATURES.items():

@@ -250,6 +250,16 @@ int x2i_groupnorm_nhwc_bf16(const void* x, void* y, int32_t B, int64_t HW, int32
   return x2i_launch_groupnorm(x, y, B, HW, C, G, weight, bias, eps, act, pre_add, post_add, partial, (hipStream_t)stream);
 }
 
+int64_t x2i_groupnorm_moments_scratch_floats(int32_t B, int32_t C) { return x2i_groupnorm_moments_scratch(B, C); }
+int x2i_groupnorm_moments_f32(const void* x, int32_t B, int64_t HW, int32_t C, float* moments, float* scratch, x2i_stream_t stream) {
+  return x2i_launch_groupnorm_moments(x, B, HW, C, moments, scratch, (hipStream_t)stream);
+}
+int x2i_groupnorm_nhwc_from_moments_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight, const void* bias,
+                                         float eps, int32_t act, const float* moments, const float* pre_add, const void* post_add, float* partial,
+                                         x2i_stream_t stream) {
+  return x2i_launch_groupnorm_from_moments(x, y, B, HW, C, G, weight, bias, eps, act, moments, pre_add, post_add, partial, (hipStream_t)stream);
+}
+
 int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
                        int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
   return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream);

@@ -100,24 +100,31 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
       }
     }
   }
+  // block reduction in three short steps (the first form had G threads walk all 256 entries with two integer divisions each: ~10 us per
+  // block, which made this HBM-bound pass run at 1.6 TB/s -- profiles/r04i_bench_config5_kernel_stats.csv): (1) the threads that hold the
+  // same chunk are cpp apart: thread c < cpp sums them (ppi <= 32 entries); (2) chunk-half sums -> LDS; (3) thread g < G sums the chunk
+  // halves of its group (cpg / 4 consecutive halves; a 4-channel group is exactly one half).  Fixed order: deterministic.
   red[threadIdx.x][0] = s0;
   red[threadIdx.x][1] = q0;
   red[threadIdx.x][2] = s1;
   red[threadIdx.x][3] = q1;
   __syncthreads();
-  if (threadIdx.x < G) {
-    const int cpg = C / G;  // channels per group: 4 or a multiple of 8
+  __shared__ float half[512][2];  // [chunk * 2 + half][sum, sum of squares]; cpp <= 256
+  if ((int)threadIdx.x < cpp) {
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+    for (int t = threadIdx.x; t < 256; t += cpp) {
+      a0 += red[t][0]; b0 += red[t][1]; a1 += red[t][2]; b1 += red[t][3];
+    }
+    half[threadIdx.x * 2][0] = a0; half[threadIdx.x * 2][1] = b0;
+    half[threadIdx.x * 2 + 1][0] = a1; half[threadIdx.x * 2 + 1][1] = b1;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int hpg = (C / G) / 4;  // chunk halves per group (channels per group: 4 or a multiple of 8)
     float a = 0.f, bq = 0.f;
-    for (int t = 0; t < 256; ++t) {
-      const int c0 = (t % cpp) * 8;
-      if (c0 / cpg == (int)threadIdx.x) {
-        a += red[t][0];
-        bq += red[t][1];
-      }
-      if ((c0 + 4) / cpg == (int)threadIdx.x) {
-        a += red[t][2];
-        bq += red[t][3];
-      }
+    for (int h = 0; h < hpg; ++h) {
+      a += half[threadIdx.x * hpg + h][0];
+      bq += half[threadIdx.x * hpg + h][1];
     }
     float* o = partial + (long long)gridDim.y * G * 2 + (((long long)b * GN_SLABS + slab) * G + threadIdx.x) * 2;
     o[0] = a;
@@ -152,6 +159,82 @@ __global__ __launch_bounds__(256) void gn_finish_kernel(float* __restrict__ part
     const float var = fmaxf(q / n - m * m, 0.f);
     partial[((long long)b * G + g) * 2] = m;
     partial[((long long)b * G + g) * 2 + 1] = rsqrtf(var + eps);
+  }
+}
+
+// Per-channel moments of an NHWC tensor: mom[b][c] = (sum_p x, sum_p x^2).  GroupNorm statistics of x + v[b][c] for ANY per-channel
+// vector v follow from them without touching x again (gn_finish_moments_kernel): ResnetBlock2D's norm2 runs on conv1(...) + the time
+// embedding term (lightcontrol_flux.py:620-640, diffusers ResnetBlock2D), and in the ControlNeXt branch conv1's output does not depend on
+// the timestep -- its moments are taken once per hint, and the statistics pass over the 64 MB-per-image tensor leaves the denoising loop.
+// grid (GN_SLABS, B): partial moments per slab, then gn_moments_finish_kernel (grid B) sums the slabs in a fixed order.
+__global__ __launch_bounds__(256) void gn_moments_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long long HW, int C) {
+  __shared__ float red[256][17];
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int cpp = C / 8, ppi = 256 / cpp;
+  const int chunk = threadIdx.x % cpp, psub = threadIdx.x / cpp;
+  const long long per = (HW + GN_SLABS - 1) / GN_SLABS;
+  const long long p0 = (long long)slab * per, p1 = min(HW, p0 + per);
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  const bf16_t* xb = x + (long long)b * HW * C + chunk * 8;
+  for (long long pp = p0 + psub; pp < p1; pp += ppi) {
+    const bf16x8_t v = *(const bf16x8_t*)(xb + pp * C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = bf16_to_f32((bf16_t)v[j]);
+      s[j] += f;
+      q[j] = fmaf(f, f, q[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = s[j], red[threadIdx.x][8 + j] = q[j];
+  __syncthreads();
+  // thread t < C: channel t = chunk (t / 8), element t % 8: sum over the ppi threads that hold this chunk
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int ch = c >> 3, j = c & 7;
+    float a = 0.f, bq = 0.f;
+    for (int t = ch; t < 256; t += cpp) a += red[t][j], bq += red[t][8 + j];
+    float* o = part + (((long long)b * GN_SLABS + slab) * C + c) * 2;
+    o[0] = a;
+    o[1] = bq;
+  }
+}
+__global__ __launch_bounds__(256) void gn_moments_finish_kernel(const float* __restrict__ part, float* __restrict__ mom, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, q = 0.f;
+    for (int sl = 0; sl < GN_SLABS; ++sl) {
+      const float* pp = part + (((long long)b * GN_SLABS + sl) * C + c) * 2;
+      a += pp[0];
+      q += pp[1];
+    }
+    mom[((long long)b * C + c) * 2] = a;
+    mom[((long long)b * C + c) * 2 + 1] = q;
+  }
+}
+// stats[b][g] = (mean, rstd) of x + v over group g from the channel moments: sum (x + v) = S1 + HW v, sum (x + v)^2 = S2 + 2 v S1 + HW v^2
+__global__ __launch_bounds__(256) void gn_finish_moments_kernel(const float* __restrict__ mom, const float* __restrict__ pre_add, float* __restrict__ stats,
+                                                                long long HW, int C, int G, float eps) {
+  __shared__ float cs[2048][2];
+  const int b = blockIdx.x;
+  const float n1 = (float)HW;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float s1 = mom[((long long)b * C + c) * 2], s2 = mom[((long long)b * C + c) * 2 + 1];
+    const float v = pre_add ? pre_add[(long long)b * C + c] : 0.f;
+    cs[c][0] = fmaf(n1, v, s1);
+    cs[c][1] = fmaf(n1 * v, v, fmaf(2.f * v, s1, s2));
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int cpg = C / G;
+    float a = 0.f, q = 0.f;
+    for (int c = threadIdx.x * cpg; c < ((int)threadIdx.x + 1) * cpg; ++c) a += cs[c][0], q += cs[c][1];
+    const float n = n1 * (float)cpg;
+    const float m = a / n;
+    const float var = fmaxf(q / n - m * m, 0.f);
+    stats[((long long)b * G + threadIdx.x) * 2] = m;
+    stats[((long long)b * G + threadIdx.x) * 2 + 1] = rsqrtf(var + eps);
   }
 }
 
@@ -294,6 +377,35 @@ int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int
   if (rc) return rc;
   const long long total = HW * (C / 8);
   long long blocks = (total + 511) / 512;  // two chunks per thread per iteration
+  const long long cap = 8192 / B > 256 ? 8192 / B : 256;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,
+                     (const bf16_t*)w, (const bf16_t*)b, act, pre_add, (const bf16_t*)post_add, partial);
+  return x2i_check_launch("groupnorm_apply");
+}
+
+long long x2i_groupnorm_moments_scratch(int B, int C) { return (long long)B * GN_SLABS * C * 2; }
+
+int x2i_launch_groupnorm_moments(const void* x, int B, long long HW, int C, float* moments, float* scratch, hipStream_t stream) {
+  if (!x || !moments || !scratch) return x2i_set_error(X2I_ERR_ARG, "groupnorm_moments: null pointer");
+  if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || C > 2048) return x2i_set_error(X2I_ERR_SHAPE, "groupnorm_moments: unsupported C=%d (need C/8 | 256)", C);
+  hipLaunchKernelGGL(gn_moments_partial_kernel, dim3(GN_SLABS, B), dim3(256), 0, stream, (const bf16_t*)x, scratch, HW, C);
+  int rc = x2i_check_launch("groupnorm_moments_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_moments_finish_kernel, dim3(B), dim3(256), 0, stream, scratch, moments, C);
+  return x2i_check_launch("groupnorm_moments_finish");
+}
+
+int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
+                                      const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream) {
+  if (!x || !y || !w || !b || !partial || !moments) return x2i_set_error(X2I_ERR_ARG, "groupnorm_from_moments: null pointer");
+  if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || C > 2048 || G <= 0 || G > 32 || C % G || !((C / G) % 8 == 0 || (C / G) == 4))
+    return x2i_set_error(X2I_ERR_SHAPE, "groupnorm_from_moments: unsupported C=%d G=%d", C, G);
+  hipLaunchKernelGGL(gn_finish_moments_kernel, dim3(B), dim3(256), 0, stream, moments, pre_add, partial, HW, C, G, eps);
+  int rc = x2i_check_launch("groupnorm_finish_moments");
+  if (rc) return rc;
+  const long long total = HW * (C / 8);
+  long long blocks = (total + 511) / 512;
   const long long cap = 8192 / B > 256 ? 8192 / B : 256;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,

@@ -71,7 +71,7 @@ static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = 0;
   p.gm = 4;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
@@ -216,11 +216,13 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
     const int up = cd->up ? 1 : 0;
-    const int OH = ((cd->H << up) + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = ((cd->W << up) + 2 * cd->pad - cd->KW) / cd->stride + 1;
+    const int pad_w = cd->pad_w < 0 ? cd->pad : cd->pad_w;
+    if (cd->KH * cd->KW > 32) return x2i_set_error(X2I_ERR_SHAPE, "conv: at most 32 filter taps (KH=%d KW=%d)", cd->KH, cd->KW);
+    const int OH = ((cd->H << up) + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = ((cd->W << up) + 2 * pad_w - cd->KW) / cd->stride + 1;
     if (a->M != OH * OW || a->K != cd->KH * cd->KW * cd->Cin)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: M=%d K=%d do not match OH*OW=%d, KH*KW*Cin=%d", a->M, a->K, OH * OW, cd->KH * cd->KW * cd->Cin);
     if ((long long)cd->H * cd->W * cd->Cin * 2 >= 0x7f000000LL) return x2i_set_error(X2I_ERR_SHAPE, "conv: image too large");
-    p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad; p.cUp = up;
+    p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad; p.cPadW = pad_w; p.cUp = up;
   }
   p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
   const bool fast = (a->K % BK == 0) && (conv || a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) &&
@@ -440,7 +442,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = 0;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = 0;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   if (qd) {

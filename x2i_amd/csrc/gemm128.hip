@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       const int m = m0 + row;
       const int oy = m / p.cOW, ox = m - oy * p.cOW;
       c_oy[j] = oy * p.cStride - p.cPad;
-      c_ox[j] = ox * p.cStride - p.cPad;
+      c_ox[j] = ox * p.cStride - p.cPadW;
       c_cl[j] = clog * 8;
       c_base[j] = ((c_oy[j] * p.cW + c_ox[j]) * p.cCin + c_cl[j]) * 2;
       uint32_t mask = 0;

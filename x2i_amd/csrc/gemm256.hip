@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
       const int m = m0 + row;
       const int oy = m / p.cOW, ox = m - oy * p.cOW;
       c_oy[jj] = oy * p.cStride - p.cPad;
-      c_ox[jj] = ox * p.cStride - p.cPad;
+      c_ox[jj] = ox * p.cStride - p.cPadW;
       c_base[jj] = ((c_oy[jj] * p.cW + c_ox[jj]) * p.cCin + kel) * 2;
       uint32_t mask = 0;
       if (m < p.M) {

@@ -24,6 +24,7 @@ struct GemmP {
   int tilesM, tilesN;
   // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
+  int cPadW;                                       // padding along W (cPad: along H)
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0;
   int gm;

@@ -19,6 +19,10 @@ int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void*
 long long x2i_groupnorm_scratch(int B, int G);
 int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps,
                          int act, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
+long long x2i_groupnorm_moments_scratch(int B, int C);
+int x2i_launch_groupnorm_moments(const void* x, int B, long long HW, int C, float* moments, float* scratch, hipStream_t stream);
+int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
+                                      const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                          long long o_bs, float scale, hipStream_t stream, int out8 = 0, float oinv = 1.f, float* lse = nullptr);
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,

@@ -10,6 +10,17 @@ Activations are NHWC bf16; convolutions with Cin >= 64 are implicit GEMMs on the
 [Cout][ky][kx][Cin]); GroupNorm / ReLU / SiLU / time-embedding adds / residuals are fused around them.
 Everything up to the first ResnetBlock's conv1 does not depend on the timestep and is cached per hint image
 (`prepare_hint`): 135 of the 437 GFLOP per model per image are paid once per sample instead of once per step.
+
+Round 4: the two places where the reference chains LINEAR maps without a nonlinearity between them are evaluated as one
+convolution each (`_Composed`): ResnetBlock2D's `conv2(...) + shortcut(x)` is followed directly by Downsample2D's 3x3 stride-2 conv
+(lightcontrol_flux.py:741-743), so   down(conv2(n) + b2 + sc(x))  =  [down o conv2](n)  +  [down o sc](x)  +  down(bias fields),
+where down o conv2 is a 5x5 stride-2 convolution (25 taps on the quarter-size output grid instead of 9 on the full-size grid plus 9 on
+the quarter-size one: 1.8x fewer FLOPs, and the full-size tensor between the two is never written), down o sc a 3x3 stride-2 one
+(res 1) or timestep-independent and cached per hint (res 0, identity shortcut), and the bias terms constant maps.  Zero padding is
+reproduced exactly: the only outputs where `down`'s padding of the INTERMEDIATE differs from padding the input are the first output row
+and column, and those are corrected by three small launches (a 1x5, a 5x1 and a 1x1 convolution on the first input row / column / pixel)
+that take back the terms the padded intermediate would not have contributed.  Not bit-identical to the chained form (the intermediate's
+bf16 rounding is gone, the composed taps are rounded to bf16 once); same tolerance against the fp32 oracle.
 """
 import torch
 import torch.nn as nn
@@ -37,6 +48,77 @@ class _Conv(nn.Module):
         if self._packed is None or self._packed[1] != key:  # load_state_dict / in-place updates / moves invalidate the copy
             self._packed = (self.weight.permute(0, 2, 3, 1).reshape(self.weight.shape[0], -1).contiguous(), key)
         return self._packed[0]
+
+
+def _compose_taps(wd, wc):
+    """Weights of (conv with taps wd) o (conv with taps wc), stride of the first factor applied outside: wd bf16 [Co, KH1, KW1, Mid] and
+    wc bf16 [Mid, KH2, KW2, Ci] (both in the packed (ky, kx, c) order) -> bf16 [Co, (KH1 + KH2 - 1) * (KW1 + KW2 - 1) * Ci] with
+    W[co, ky + jy, kx + jx, ci] = sum_mid wd[co, ky, kx, mid] * wc[mid, jy, jx, ci].  ONE MFMA GEMM against a shifted, zero-filled
+    copy of wc (the copy is index plumbing; the arithmetic is fp32 accumulation of exact bf16 products, rounded to bf16 once)."""
+    co, kh1, kw1, mid = wd.shape
+    _, kh2, kw2, ci = wc.shape
+    kh, kw = kh1 + kh2 - 1, kw1 + kw2 - 1
+    wt = torch.zeros((kh, kw, ci, kh1, kw1, mid), device=wd.device, dtype=torch.bfloat16)
+    wct = wc.permute(1, 2, 3, 0)  # [jy, jx, ci, mid]
+    for ky in range(kh1):
+        for kx in range(kw1):
+            for jy in range(kh2):
+                for jx in range(kw2):
+                    wt[ky + jy, kx + jx, :, ky, kx, :] = wct[jy, jx]
+    c = ops.gemm(wd.reshape(co, kh1 * kw1 * mid).contiguous(), wt.reshape(kh * kw * ci, kh1 * kw1 * mid), None, out_f32=True)
+    return ops.to_bf16(c)
+
+
+class _Composed:
+    """Per-net composed weights of one `ResnetBlock2D.conv2 (+ shortcut) -> Downsample2D.conv` chain (see the module docstring):
+    w5 = down o conv2 (5x5, stride 2, pad 2), the three first-row / first-column / first-pixel corrections (stored NEGATED where they are
+    subtracted: the conv epilogue adds), wsc = down o conv_shortcut (3x3 stride 2) when the block has one, and the constant map of the
+    bias terms on the output grid."""
+
+    def __init__(self, res, down, oh, ow):
+        cd, cc = down.conv, res.conv2
+        wd = cd.packed().view(cd.weight.shape[0], 3, 3, -1)          # [co, ky, kx, mid]
+        wc = cc.packed().view(cc.weight.shape[0], 3, 3, -1)          # [mid, jy, jx, ci]
+        self.co, self.mid, self.ci = wd.shape[0], wd.shape[3], wc.shape[3]
+        self.w5 = _compose_taps(wd, wc)
+        # the intermediate's zero padding: output row 0 must not see `down`'s ky = 0 taps (they sit on padding), but the composed 5x5
+        # applies them to conv2 evaluated one row above the image, which reaches input row 0 through conv2's last row of taps (jy = 2).
+        # Same for column 0; the (ky, kx) = (0, 0) tap is taken back twice and returned once.
+        self.w_top = torch.neg(_compose_taps(wd[:, 0:1].contiguous(), wc[:, 2:3].contiguous()))            # 1 x 5
+        self.w_left = torch.neg(_compose_taps(wd[:, :, 0:1].contiguous(), wc[:, :, 2:3].contiguous()))     # 5 x 1
+        self.w_corner = _compose_taps(wd[:, 0:1, 0:1].contiguous(), wc[:, 2:3, 2:3].contiguous())          # 1 x 1
+        self.wsc = None
+        fields = [cc.bias]
+        if hasattr(res, "conv_shortcut"):
+            ws = res.conv_shortcut.packed().view(self.mid, 1, 1, -1)
+            self.wsc = _compose_taps(wd, ws)                                                               # 3 x 3, stride 2, pad 1
+            fields.append(res.conv_shortcut.bias)
+        # down(bias fields) + down's own bias: `down` applied to constant images (zero padded like any other input): exact at the borders
+        m = None
+        for i, f in enumerate(fields):
+            const = f.view(1, 1, 1, self.mid).expand(1, 2 * oh, 2 * ow, self.mid).contiguous()
+            m = ops.conv2d_nhwc(const, cd.packed(), cd.bias if i == 0 else None, 2 * oh, 2 * ow, self.mid, self.co, 3, 3, 2, 1, res=m)
+        self.bias_map = m                                                                                  # [1, oh, ow, co]
+
+    def apply(self, n, h, w, base, out=None):
+        """[down o conv2](n) + base on the (h/2, w/2) grid; n bf16 [B, h, w, ci]; base bf16 [B or 1, h/2, w/2, co] (everything else that
+        `down` sees: bias map, shortcut / identity path)."""
+        B = n.shape[0]
+        oh, ow, ci, co = h // 2, w // 2, self.ci, self.co
+        bs = 0 if base.shape[0] == 1 else oh * ow * co
+        d = ops.conv2d_nhwc(n, self.w5, None, h, w, ci, co, 5, 5, 2, 2, res=base, res_batch_stride=bs, out=out)
+        # first output row: a 1 x 5 stride-2 convolution over input row 0, added in place (negated weights)
+        ops.conv2d_nhwc(n, self.w_top, None, 1, w, ci, co, 1, 5, 2, 0, pad_w=2, B=B, a_batch_stride=h * w * ci, out=d, c_batch_stride=oh * ow * co,
+                        res=d, res_batch_stride=oh * ow * co)
+        # first output column: a 5 x 1 stride-2 convolution over input column 0 (gathered: the conv reads contiguous NHWC), written with
+        # the output grid's row pitch so that result oy lands on pixel (oy, 0)
+        col = n[:, :, 0:1, :].contiguous()
+        ops.conv2d_nhwc(col, self.w_left, None, h, 1, ci, co, 5, 1, 2, 2, pad_w=0, out=d, c_batch_stride=oh * ow * co, ldc=ow * co, res=d,
+                        res_batch_stride=oh * ow * co, ldr=ow * co)
+        # first pixel: the (0, 0) tap was taken back by both corrections
+        ops.gemm(n, self.w_corner, None, out=d, M=1, batch=B, a_batch_stride=h * w * ci, lda=ci, c_batch_stride=oh * ow * co, ldc=co, res=d,
+                 res_batch_stride=oh * ow * co, ldr=co)
+        return d
 
 
 class _Affine(nn.Module):
@@ -103,6 +185,8 @@ class ControlNeXtModel(nn.Module):
                         4: _Affine(256, device)})
         self.mid_convs = _Sparse({0: mid0, 1: _Conv(256, control_out_channels, 2, device)})
         self._hint_cache = None
+        self.compose = True        # conv2 -> Downsample2D chains as one convolution each (module docstring); False: the chained form (A/B)
+        self._composed_cache = None
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
@@ -110,7 +194,17 @@ class ControlNeXtModel(nn.Module):
             if isinstance(m, _Conv):
                 m._packed = None
         self._hint_cache = None
+        self._composed_cache = None
         return r
+
+    def _composed(self, h, w):
+        """The two composed chains for a (h, w) = (H/2, W/2) grid; rebuilt when a weight changes (load_state_dict, .to())."""
+        convs = [self.down_res[0].conv2, self.down_sample[0].conv, self.down_res[1].conv2, self.down_res[1].conv_shortcut, self.down_sample[1].conv]
+        key = (h, w) + tuple((c.weight._version, c.weight.data_ptr(), c.bias._version, c.bias.data_ptr()) for c in convs)
+        if self._composed_cache is None or self._composed_cache[0] != key:
+            self._composed_cache = (key, _Composed(self.down_res[0], self.down_sample[0], h // 2, w // 2),
+                                    _Composed(self.down_res[1], self.down_sample[1], h // 4, w // 4))
+        return self._composed_cache[1], self._composed_cache[2]
 
     # ---- timestep-independent prefix (cached per hint tensor)
     @torch.no_grad()
@@ -130,12 +224,23 @@ class ControlNeXtModel(nn.Module):
         r = self.down_res[0]
         n = ops.groupnorm_nhwc(x0, r.norm1.weight, r.norm1.bias, self.groups[0], 1e-6, act=ACT_SILU)
         h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 128, 3, 3, 1, 1)
-        return dict(x0=x0, h1=h1, h=h, w=w, B=B, round_bf16=sample.dtype == torch.bfloat16)
+        # norm2 of this block normalises h1 + time_emb_proj(...): h1 does not depend on the timestep, so its per-channel moments are taken
+        # here, once per hint, and the denoising loop never runs a statistics pass over the [B, H/2, W/2, 128] tensor again
+        prep = dict(x0=x0, h1=h1, h1_moments=ops.groupnorm_moments(h1), h=h, w=w, B=B, round_bf16=sample.dtype == torch.bfloat16)
+        if self.compose:
+            # down_sample[0] of (the block's identity shortcut + the bias fields): the timestep-independent part of what it will see
+            ca, _ = self._composed(h, w)
+            d = self.down_sample[0].conv
+            prep["d0"] = ops.conv2d_nhwc(x0, d.packed(), None, h, w, 128, 128, 3, 3, 2, 1, res=ca.bias_map, res_batch_stride=0)
+        return prep
 
-    def _resblock_tail(self, r, x_in, h1, temb_act, G, h, w, cin, cout):
+    def _resblock_tail(self, r, x_in, h1, temb_act, G, h, w, cin, cout, h1_moments=None):
         """ResnetBlock2D after conv1: h = h1 + time_emb_proj(silu(temb)); h = conv2(silu(GN(h))); out = shortcut(x) + h."""
         tproj = ops.skinny_linear(temb_act, r.time_emb_proj.weight, r.time_emb_proj.bias, act_in=ACT_SILU)  # [B, cout] f32
-        n = ops.groupnorm_nhwc(h1, r.norm2.weight, r.norm2.bias, G, 1e-6, act=ACT_SILU, pre_add=tproj)
+        if h1_moments is not None:
+            n = ops.groupnorm_nhwc_from_moments(h1, h1_moments, r.norm2.weight, r.norm2.bias, G, 1e-6, act=ACT_SILU, pre_add=tproj)
+        else:
+            n = ops.groupnorm_nhwc(h1, r.norm2.weight, r.norm2.bias, G, 1e-6, act=ACT_SILU, pre_add=tproj)
         if hasattr(r, "conv_shortcut"):
             sc = ops.conv2d_nhwc(x_in, r.conv_shortcut.packed(), r.conv_shortcut.bias, h, w, cin, cout, 1, 1, 1, 0)
         else:
@@ -156,17 +261,34 @@ class ControlNeXtModel(nn.Module):
         te = self.time_embedding
         e1 = ops.skinny_linear(tp, te.linear_1.weight, te.linear_1.bias, act_out=ACT_SILU)
         emb = ops.skinny_linear(e1, te.linear_2.weight, te.linear_2.bias)  # [B,256] f32
-        x = self._resblock_tail(self.down_res[0], prep["x0"], prep["h1"], emb, self.groups[0], h, w, 128, 128)
-        d = self.down_sample[0].conv
-        x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 128, 128, 3, 3, 2, 1)
-        h, w = h // 2, w // 2
-        r = self.down_res[1]
-        n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
-        h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
-        x = self._resblock_tail(r, x, h1, emb, self.groups[1], h, w, 128, 256)
-        d = self.down_sample[1].conv
-        x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 256, 256, 3, 3, 2, 1)
-        h, w = h // 2, w // 2
+        if self.compose and "d0" in prep:
+            ca, cb = self._composed(h, w)
+            r = self.down_res[0]
+            tproj = ops.skinny_linear(emb, r.time_emb_proj.weight, r.time_emb_proj.bias, act_in=ACT_SILU)
+            n = ops.groupnorm_nhwc_from_moments(prep["h1"], prep["h1_moments"], r.norm2.weight, r.norm2.bias, self.groups[0], 1e-6, act=ACT_SILU,
+                                                pre_add=tproj)
+            x = ca.apply(n, h, w, prep["d0"])                      # = down_sample[0](conv2(n) + x0): [B, h/2, w/2, 128]
+            h, w = h // 2, w // 2
+            r = self.down_res[1]
+            n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
+            h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
+            tproj = ops.skinny_linear(emb, r.time_emb_proj.weight, r.time_emb_proj.bias, act_in=ACT_SILU)
+            n = ops.groupnorm_nhwc(h1, r.norm2.weight, r.norm2.bias, self.groups[1], 1e-6, act=ACT_SILU, pre_add=tproj)
+            t1 = ops.conv2d_nhwc(x, cb.wsc, None, h, w, 128, 256, 3, 3, 2, 1, res=cb.bias_map, res_batch_stride=0)   # down o shortcut + biases
+            x = cb.apply(n, h, w, t1)                               # = down_sample[1](conv2(n) + conv_shortcut(x)): [B, h/2, w/2, 256]
+            h, w = h // 2, w // 2
+        else:
+            x = self._resblock_tail(self.down_res[0], prep["x0"], prep["h1"], emb, self.groups[0], h, w, 128, 128, h1_moments=prep.get("h1_moments"))
+            d = self.down_sample[0].conv
+            x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 128, 128, 3, 3, 2, 1)
+            h, w = h // 2, w // 2
+            r = self.down_res[1]
+            n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
+            h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
+            x = self._resblock_tail(r, x, h1, emb, self.groups[1], h, w, 128, 256)
+            d = self.down_sample[1].conv
+            x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 256, 256, 3, 3, 2, 1)
+            h, w = h // 2, w // 2
         m = self.mid_convs[0]
         y = ops.conv2d_nhwc(x, m[0].packed(), m[0].bias, h, w, 256, 256, 3, 3, 1, 1, act=ACT_RELU)
         y = ops.groupnorm_nhwc(y, m[2].weight, m[2].bias, 8, 1e-5)

@@ -402,20 +402,24 @@ from ._lib import ACT_RELU, ConvDesc  # noqa: E402
 
 
 def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=None, act=ACT_NONE, bias2=None, res=None,
-                c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None, up=False):
-    """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout]."""
+                c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None, up=False, pad_w=None, B=None,
+                a_batch_stride=None, a_offset=0):
+    """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout].
+    pad_w: padding along W when it differs from `pad` (along H).  B / a_batch_stride / a_offset: the input is a window of `H` rows of a
+    larger NHWC tensor (elements between two images / in front of the window)."""
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")
     _req(w_packed, torch.bfloat16, "w")
-    B = x.shape[0]
+    B = x.shape[0] if B is None else B
     u = 2 if up else 1  # nearest-neighbour x2 upsampling fused in front of the conv
+    pw = pad if pad_w is None else pad_w
     OH = (H * u + 2 * pad - KH) // stride + 1
-    OW = (W * u + 2 * pad - KW) // stride + 1
+    OW = (W * u + 2 * pw - KW) // stride + 1
     if out is None:
         out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=torch.bfloat16)
     a = GemmArgs()
-    a.A = x.data_ptr()
-    a.a_batch_stride = H * W * Cin
+    a.A = x.data_ptr() + 2 * a_offset
+    a.a_batch_stride = H * W * Cin if a_batch_stride is None else a_batch_stride
     a.lda = Cin
     a.W = w_packed.data_ptr()
     a.ldw = KH * KW * Cin
@@ -434,7 +438,7 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     a.act = act
     a.out_f32 = 0
     a.w_batch_stride = 0
-    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, 1 if up else 0)
+    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, 1 if up else 0, -1 if pad_w is None else pad_w)
     check(lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(d), _stream()), "conv2d_nhwc")
     return out
 
@@ -466,6 +470,36 @@ def groupnorm_nhwc(x, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add
         _gn_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
     check(lib.x2i_groupnorm_nhwc_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), eps, act, _p(pre_add), _p(post_add),
                                       _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc")
+    return out
+
+
+def groupnorm_moments(x):
+    """Per-channel moments f32 [B, C, 2] = (sum x, sum x^2) over the pixels of an NHWC bf16 tensor (x2i_groupnorm_moments_f32): cached
+    by the caller, they give groupnorm_nhwc_from_moments its statistics for any per-channel pre_add without another pass over x."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    mom = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(int(lib.x2i_groupnorm_moments_scratch_floats(B, Cc)), device=x.device, dtype=torch.float32)
+    check(lib.x2i_groupnorm_moments_f32(_p(x), B, HW, Cc, _p(mom), _p(scratch), _stream()), "groupnorm_moments")
+    return mom
+
+
+def groupnorm_nhwc_from_moments(x, moments, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add=None, out=None):
+    """groupnorm_nhwc(x, ..., pre_add=...) with the statistics derived from groupnorm_moments(x) instead of a pass over x."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    _req(moments, torch.float32, "moments")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    out = torch.empty_like(x) if out is None else out
+    n = lib.x2i_groupnorm_scratch_floats(B, G)
+    key = (x.device, n)
+    if key not in _gn_scratch:
+        _gn_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.x2i_groupnorm_nhwc_from_moments_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), eps, act, _p(moments), _p(pre_add),
+                                                   _p(post_add), _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc_from_moments")
     return out
 
 
