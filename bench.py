@@ -387,6 +387,9 @@ def main(argv=None):
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     launched = "WORLD_SIZE" in os.environ
+    if not args.selftest_launcher and torch.cuda.is_available() and args.gpus > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s); refusing to start ranks that have no device of their own"
+                         % (args.gpus, torch.cuda.device_count()))
     if args.gpus > 1 and not launched:
         sys.exit(relaunch_under_torchrun(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
