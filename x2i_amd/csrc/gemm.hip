@@ -251,6 +251,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   const long long min256 = opt.gemm_min256;
   // batched launches with few rows per item (text stream, 512 rows per sample) keep 128^2 tiles below three full rounds
   bool use256 = !conv && a->N >= 256 && (tiles256 >= 768 ? a->M >= 256 : (tiles256 >= min256 && a->M >= 1024));
+  // ... except WIDE outputs (N >= 8192: ff_context.net.0 when it is not grouped with the image stream, i.e. in the e4m3 configurations):
+  // from 192 tiles up the persistent 256^2 kernel with its stream-K remainder wins (202 -> 145 us at batch 4, 90 -> 70 us at batch 2,
+  // profiles/r04o_text_gemm_probe.log); the deep-K, narrow-N text launches (ff_context.net.2, to_add_out) stay on 128^2 tiles.  Both kernels
+  // sum in the same order (bit-identical), so this choice may depend on the batch.
+  if (!conv && !use256 && a->N >= 8192 && a->M >= 512 && tiles256 >= 192 && opt.gemm_w4 == 1 && opt.gemm_persist) use256 = true;
   // convolutions with >= 256 output channels: the full-line kernel's implicit-GEMM form (option conv256 = 0: 128^2 tiles, A/B)
   bool conv256 = false;
   if (conv && a->N >= 256 && a->N % 8 == 0 && tiles256 >= min256 && a->M >= 1024 && opt.conv256) conv256 = use256 = true;

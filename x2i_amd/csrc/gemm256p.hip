@@ -113,19 +113,28 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
     constexpr int j = decltype(jc)::value;
     constexpr int h = q >> 2, c = q & 3;
     char* buf = stage + which * 2048;
+    // all eight accumulators of the quarter first (the reads are volatile asm -- see the bf16 form -- and a volatile statement between
+    // two elements pins their order: with the read inside the element loop the eight dependent chains -- multiply, fma, GELU's exp and
+    // rcp, clamp -- ran strictly one after the other, ~11 cycles per instruction; read up front, the compiler interleaves them)
+    float x[8];
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
-        t = apply_act(fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]), ACT);
-        if constexpr (!UNIT_OUT) t *= p.f_oinv;   // (out_inv_scale == 1, the model's setting: the multiply is skipped -- x * 1 is x)
-        v[r] = __builtin_amdgcn_fmed3f(t, -448.f, 448.f);
-      }
-      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-      pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+      for (int r = 0; r < 4; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x[i * 4 + r]) : "a"(acc[h][c][i][j][r]));
+    });
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e] * dq.sw[h * 4 + j][e & 3], dq.sr[c][e >> 2], bv[h * 4 + j][e & 3]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e], ACT);   // (a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if constexpr (!UNIT_OUT) x[e] *= p.f_oinv;   // (out_inv_scale == 1, the model's setting: the multiply is skipped -- x * 1 is x)
+      x[e] = __builtin_amdgcn_fmed3f(x[e], -448.f, 448.f);
+    }
+    static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[i * 4], x[i * 4 + 1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[i * 4 + 2], x[i * 4 + 3], pk, true);
       const int row = i * 16 + mlane;
       *(int*)(buf + row * 64 + ((j ^ ((row >> 1) & 3)) << 4) + (ng << 2)) = pk;
     });
@@ -257,17 +266,30 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
     constexpr int j = decltype(jc)::value;
     constexpr int h = q >> 2, c = q & 3;
     char* buf = stage + which * 4096;
+    float x[8];   // (the quarter's eight accumulators first, then eight independent chains; GELU breadth first: see the e4m3 form)
+    static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x[i * 4 + r]) : "a"(acc[h][c][i][j][r]));
+    });
+    static_for<2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = x[i * 4 + r];
+        if constexpr (FXADD) t = rp[q & 1][i][j][r] + t;
+        if constexpr (F8) t = fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]);
+        else t = t + bv[h * 4 + j][r];
+        x[i * 4 + r] = t;
+      }
+    });
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e], ACT);   // (a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t;
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(acc[h][c][i][j][r]));
-        if constexpr (FXADD) t = rp[q & 1][i][j][r] + t;
-        if constexpr (F8) v[r] = apply_act(fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]), ACT);
-        else v[r] = apply_act(t + bv[h * 4 + j][r], ACT);
-      }
+      for (int r = 0; r < 4; ++r) v[r] = x[i * 4 + r];
       if constexpr (RES) {
         const u32x2 r2 = rres[q % 3][i][j];
         v[0] = fmaf(gv[h * 4 + j][0], v[0], __uint_as_float(r2[0] << 16));
