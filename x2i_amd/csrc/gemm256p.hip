@@ -120,7 +120,12 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x[i * 4 + r]) : "a"(acc[h][c][i][j][r]));
+      for (int r = 0; r < 4; ++r) {
+        float t;   // (through a local: a variable that appears ONLY as an asm operand inside a lambda is not captured by clang)
+        const float a = acc[h][c][i][j][r];
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(a));
+        x[i * 4 + r] = t;
+      }
     });
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e] * dq.sw[h * 4 + j][e & 3], dq.sr[c][e >> 2], bv[h * 4 + j][e & 3]);
@@ -270,7 +275,12 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x[i * 4 + r]) : "a"(acc[h][c][i][j][r]));
+      for (int r = 0; r < 4; ++r) {
+        float t;   // (through a local: a variable that appears ONLY as an asm operand inside a lambda is not captured by clang)
+        const float a = acc[h][c][i][j][r];
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(a));
+        x[i * 4 + r] = t;
+      }
     });
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
