@@ -380,6 +380,9 @@ def main(argv=None):
     ap.add_argument("--no-fp8-lines", action="store_true", help="skip the extra fp8_mlp / fp8_all measurements attached to the bf16 line")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the live roofline probe (for rocprofv3 --kernel-trace runs whose GEMM total must contain the timed job only)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="initialise the RCCL process group and run the all-gather / barrier / max-over-ranks path even at one rank (under a "
+                         "launcher with --nproc-per-node 1, or plain): exercises the N > 1 code path on a one-GPU box")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU stand-in workload over gloo: exercises the launcher / collective / timing / JSON path without a GPU (tests only)")
     args = ap.parse_args(argv)
@@ -405,9 +408,15 @@ def main(argv=None):
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.rccl_selftest
+    if use_dist:
         import datetime
         import torch.distributed as dist
+        if not launched:   # plain `python bench.py --rccl-selftest`: a one-rank group on 127.0.0.1
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if stub:
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
         else:
@@ -469,11 +478,11 @@ def main(argv=None):
             return pipe(prompt_embeds=embeds, pooled_prompt_embeds=pooled, num_inference_steps=N, guidance_scale=3.5,
                         height=args.size, width=args.size, output_type="latent", latents=noise, guided_hint=hint,
                         use_graph=not args.no_graph).images
-    gathered = [torch.empty_like(noise) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty_like(noise) for _ in range(world)] if use_dist else None
 
     def one_pass():
         lat = inner()
-        if world > 1:
+        if use_dist:
             dist.all_gather(gathered, lat)  # one all-gather of the final packed latents (RCCL over xGMI on the GPU path)
             return gathered
         return lat if stub else FluxPipeline._unpack_latents(lat, args.size, args.size, 16)
@@ -481,19 +490,19 @@ def main(argv=None):
     for _ in range(args.warmup):
         one_pass()
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     dt_local = dt = time.perf_counter() - t0
     rank_ms = [dt_local / args.steps * 1e3]
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt_local], device=dev, dtype=torch.float64)
         allt = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
@@ -512,7 +521,7 @@ def main(argv=None):
             "value": images_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_pass, "ms_per_denoise_step": ms_pass / N, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random MLLM hidden states, seeded noise)",
-            "rccl_ranks": world if world > 1 else 0, "rank_ms_per_step": [round(x, 3) for x in rank_ms],
+            "rccl_ranks": world if use_dist else 0, "rank_ms_per_step": [round(x, 3) for x in rank_ms],
             "launcher": ("self (bench.py re-executed under torch.distributed.run)" if os.environ.get("X2I_BENCH_LAUNCHED") else
                          "external (WORLD_SIZE set by the caller)") if world > 1 else "none",
             "config": {"workload": "BASELINE configs[%d]: %s conditioning (C=%d,H=%d,S_txt=512) -> projector -> %s DiT %dx%d, %d steps"
@@ -569,7 +578,7 @@ def main(argv=None):
             if not args.no_cpu_baseline and world == 1 and args.config == 2:
                 line["cpu_baseline"] = cpu_baseline()
             print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()  # rank 0 is still timing the roofline kernels: leave the job together
         dist.destroy_process_group()
 
