@@ -266,7 +266,7 @@ def _physical_cores():
         return None, "?"
 
 
-def cpu_baseline(reps=3, budget_s=75.0):
+def cpu_baseline(reps=3, budget_s=100.0):
     """The CPU oracle (restated reference path, fp32, torch eager) on the host cores.  MEASURED: one whole denoise step at 512 x 512,
     batch 1 -- 19 double-stream + 38 single-stream FLUX blocks at full width on 512 text + 1024 image tokens (21.5 TFLOP; SURVEY.md
     section 8(d)); the 57 blocks share one double-block and one single-block weight set (same arithmetic and bytes per block; generating
