@@ -25,7 +25,10 @@ def show(t, nwg=3):
 
 if "--fp8" in sys.argv:
     # the persistent e4m3 kernel (gen_gemm256f8.py): the two roofline launches
-    for (M, N, K, kind) in ((18432, 12288, 3072, "gelu_e4m3"), (18432, 3072, 15360, "res"), (18432, 12288, 3072, "plain")):
+    shapes = ((18432, 12288, 3072, "gelu_e4m3"), (18432, 3072, 15360, "res"), (18432, 12288, 3072, "plain"))
+    if "--hot" in sys.argv:   # one round of tiles whose operands fit the caches: what the K-loop takes when nothing has to come from HBM
+        shapes = ((4096, 4096, 15360, "plain"), (4096, 4096, 3072, "plain"), (2048, 8192, 15360, "plain"))
+    for (M, N, K, kind) in shapes:
         A8, sa = ops.quantize_rows_fp8(torch.randn((M, K), device=DEV, generator=g).bfloat16())
         W8, sw = ops.quantize_rows_fp8((torch.randn((N, K), device=DEV, generator=g) * 0.02).bfloat16())
         dbg = torch.zeros((16 * 64,), device=DEV, dtype=torch.int64)
