@@ -20,10 +20,17 @@ def _line(r):
     return json.loads(lines[0])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_bench_rccl_path_with_one_rank_under_torch_distributed_run():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29631",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py")] + FLAGS
     ln = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
     assert ln["n_gpus"] == 1 and ln["rccl_ranks"] == 1 and len(ln["rank_ms_per_step"]) == 1 and ln["value"] > 0
