@@ -26,19 +26,24 @@ def show(t, nwg=3):
 if "--fp8" in sys.argv:
     # the persistent e4m3 kernel (gen_gemm256f8.py): the two roofline launches
     shapes = ((18432, 12288, 3072, "gelu_e4m3"), (18432, 3072, 15360, "res"), (18432, 12288, 3072, "plain"))
+    if "--split" in sys.argv:   # what the GELU and what the e4m3 output path add to the plain epilogue, separately
+        shapes = ((18432, 12288, 3072, "plain_e4m3"), (18432, 12288, 3072, "gelu_bf16"), (18432, 12288, 3072, "gelu_e4m3"), (18432, 12288, 3072, "plain"))
     if "--hot" in sys.argv:   # one round of tiles whose operands fit the caches: what the K-loop takes when nothing has to come from HBM
         shapes = ((4096, 4096, 15360, "plain"), (4096, 4096, 3072, "plain"), (2048, 8192, 15360, "plain"))
     for (M, N, K, kind) in shapes:
         A8, sa = ops.quantize_rows_fp8(torch.randn((M, K), device=DEV, generator=g).bfloat16())
         W8, sw = ops.quantize_rows_fp8((torch.randn((N, K), device=DEV, generator=g) * 0.02).bfloat16())
         dbg = torch.zeros((16 * 64,), device=DEV, dtype=torch.int64)
-        out = torch.empty((M, N), device=DEV, dtype=ops.FP8 if kind == "gelu_e4m3" else torch.bfloat16)
+        out = torch.empty((M, N), device=DEV, dtype=ops.FP8 if kind.endswith("e4m3") else torch.bfloat16)
         gate = torch.randn((1, N), device=DEV, generator=g)
         for mode, what in ((79, "no epilogue"), (80, "with its epilogue")):
             for it in range(4):
                 dbg.zero_()
-                if kind == "gelu_e4m3":
-                    ops.gemm_fp8(A8, W8, None, out=out, a_scale=sa, w_scale=sw, act=1, out_fp8=True, _act2=mode, _bias2=dbg.view(torch.float32))
+                if kind.endswith("e4m3"):
+                    ops.gemm_fp8(A8, W8, None, out=out, a_scale=sa, w_scale=sw, act=1 if kind == "gelu_e4m3" else 0, out_fp8=True, _act2=mode,
+                                 _bias2=dbg.view(torch.float32))
+                elif kind == "gelu_bf16":
+                    ops.gemm_fp8(A8, W8, None, out=out, a_scale=sa, w_scale=sw, act=1, _act2=mode, _bias2=dbg.view(torch.float32))
                 elif kind == "res":
                     ops.gemm_fp8(A8, W8, None, out=out, w_scale=sw, res=out, gate=gate, _act2=mode, _bias2=dbg.view(torch.float32))
                 else:

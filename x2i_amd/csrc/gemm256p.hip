@@ -129,8 +129,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4
     });
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e] * dq.sw[h * 4 + j][e & 3], dq.sr[c][e >> 2], bv[h * 4 + j][e & 3]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e], ACT);   // (a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
+    apply_act8(x, ACT);   // (GELU: eight at once, x2i_common.h; a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if constexpr (!UNIT_OUT) x[e] *= p.f_oinv;   // (out_inv_scale == 1, the model's setting: the multiply is skipped -- x * 1 is x)
@@ -293,8 +292,7 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
         x[i * 4 + r] = t;
       }
     });
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e], ACT);   // (a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
+    apply_act8(x, ACT);   // (GELU: eight at once, x2i_common.h; a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       float v[4];

@@ -128,6 +128,40 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Eight tanh-GELUs at once, for the GEMM epilogues that run with ONE wave per SIMD (nothing else to hide a latency behind): hipcc emits the
+// seven-instruction chain of gelu_tanh_f element after element through one temporary -- mul, fma, mul, v_exp_f32, add, v_rcp_f32, wait state,
+// mul, each waiting for the one before: ~62 cycles per element (profiles/r04r_fp8_unit_timeline.log).  Here the two transcendental steps are
+// two asm blocks of eight independent instructions (their latencies overlap; the closing s_nop is the wait state a VALU read of a
+// transcendental result needs, which the compiler cannot know about behind an asm block) and the polynomial / sum / product steps are packed
+// two-wide.  Same operations on the same values in the same order per element: bit-identical to gelu_tanh_f.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_tanh8(float (&x)[8]) {
+  f32x2_t v[4], t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = (f32x2_t){x[2 * k], x[2 * k + 1]};
+    t[k] = v[k] * __builtin_elementwise_fma(v[k] * v[k], (f32x2_t){-0.10294324f, -0.10294324f}, (f32x2_t){-2.3022082f, -2.3022082f});
+  }
+  float e0 = t[0][0], e1 = t[0][1], e2 = t[1][0], e3 = t[1][1], e4 = t[2][0], e5 = t[2][1], e6 = t[3][0], e7 = t[3][1];
+  asm("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\tv_exp_f32 %4, %4\n\tv_exp_f32 %5, %5\n\t"
+      "v_exp_f32 %6, %6\n\tv_exp_f32 %7, %7\n\ts_nop 0"
+      : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7));
+  t[0] = (f32x2_t){e0, e1} + 1.0f; t[1] = (f32x2_t){e2, e3} + 1.0f; t[2] = (f32x2_t){e4, e5} + 1.0f; t[3] = (f32x2_t){e6, e7} + 1.0f;
+  e0 = t[0][0]; e1 = t[0][1]; e2 = t[1][0]; e3 = t[1][1]; e4 = t[2][0]; e5 = t[2][1]; e6 = t[3][0]; e7 = t[3][1];
+  asm("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3\n\tv_rcp_f32 %4, %4\n\tv_rcp_f32 %5, %5\n\t"
+      "v_rcp_f32 %6, %6\n\tv_rcp_f32 %7, %7\n\ts_nop 0"
+      : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7));
+  t[0] = v[0] * (f32x2_t){e0, e1}; t[1] = v[1] * (f32x2_t){e2, e3}; t[2] = v[2] * (f32x2_t){e4, e5}; t[3] = v[3] * (f32x2_t){e6, e7};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x[2 * k] = t[k][0]; x[2 * k + 1] = t[k][1]; }
+}
+// the activation of a quarter chunk (eight values) of the pipelined GEMM epilogues
+__device__ __forceinline__ void apply_act8(float (&x)[8], int act) {
+  if (act == X2I_ACT_GELU_TANH) { gelu_tanh8(x); return; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = apply_act(x[e], act);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
