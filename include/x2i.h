@@ -64,6 +64,8 @@ const char* x2i_last_error(void);
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
+ * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
+ * same values up to the summation order of the row statistics),
  * "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
  * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale), "conv5_variant" (0),
  * "fp8" (0); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the

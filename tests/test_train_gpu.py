@@ -71,14 +71,21 @@ def test_ln_modulate_backward_vs_autograd(ops, B, S, D, R):
     y = F.layer_norm(xr, (D,), eps=1e-6) * (1 + scr[:, None]) + sh[:, None]
     (y * dy.float()).sum().backward()
     nw = (S + R - 1) // R
-    part = torch.empty((B, nw, 2, D), device=DEV, dtype=torch.float32)
-    dx = g(dres).clone()
-    ops.ln_mod_bwd(g(x), g(dy), g(sc), dx, dx, part, B=B, S=S, D=D, R=R, mult_bs=D)
-    assert rel_l2(dx, dres.float() + xr.grad) < 1e-2
-    out = torch.zeros((B, 2 * D), device=DEV)
-    ops.reduce_rows(part, out, np_=nw, len_=D, nz=B, in_zs=nw * 2 * D, in_ps=2 * D, out_zs=2 * D, accumulate=True)
-    ops.reduce_rows(part, out, np_=nw, len_=D, nz=B, in_zs=nw * 2 * D, in_ps=2 * D, out_zs=2 * D, accumulate=True, in_offset=D, out_offset=D)
-    assert rel_l2(out[:, :D], scr.grad) < 5e-3 and rel_l2(out[:, D:], sh.grad) < 5e-3
+    from x2i_amd import _lib
+    old = _lib.get_option("train_rows_wg")
+    try:
+        for form in (1, 0):   # a workgroup per row group with a thread per eight columns (default) / a wave per row
+            _lib.set_option("train_rows_wg", form)
+            part = torch.full((B, nw, 2, D), float("nan"), device=DEV, dtype=torch.float32)
+            dx = g(dres).clone()
+            ops.ln_mod_bwd(g(x), g(dy), g(sc), dx, dx, part, B=B, S=S, D=D, R=R, mult_bs=D)
+            assert rel_l2(dx, dres.float() + xr.grad) < 1e-2, form
+            out = torch.zeros((B, 2 * D), device=DEV)
+            ops.reduce_rows(part, out, np_=nw, len_=D, nz=B, in_zs=nw * 2 * D, in_ps=2 * D, out_zs=2 * D, accumulate=True)
+            ops.reduce_rows(part, out, np_=nw, len_=D, nz=B, in_zs=nw * 2 * D, in_ps=2 * D, out_zs=2 * D, accumulate=True, in_offset=D, out_offset=D)
+            assert rel_l2(out[:, :D], scr.grad) < 5e-3 and rel_l2(out[:, D:], sh.grad) < 5e-3, form
+    finally:
+        _lib.set_option("train_rows_wg", old)
 
 
 def test_gate_backward_and_act_backward(ops):
@@ -86,13 +93,24 @@ def test_gate_backward_and_act_backward(ops):
     dx, t, G = bf(seeded((B, S, D), 9)), bf(seeded((B, S, D), 10)), bf(seeded((B, S, D), 11))
     gate = seeded((B, D), 12)
     nw = S // R
-    part = torch.empty((B, nw, D), device=DEV, dtype=torch.float32)
-    dT = torch.empty((B, S, D), device=DEV, dtype=torch.bfloat16)
-    ops.gate_bwd(g(dx), g(t), g(gate), g(G), dT, part, B=B, S=S, D=D, R=R, gate_bs=D)
-    assert rel_l2(dT, gate[:, None] * dx.float() + G.float()) < 5e-3
-    dg = torch.zeros((B, D), device=DEV)
-    ops.reduce_rows(part, dg, np_=nw, len_=D, nz=B, in_zs=nw * D, in_ps=D, out_zs=D)
-    assert rel_l2(dg, (dx.float() * t.float()).sum(1)) < 5e-3
+    from x2i_amd import _lib
+    old = _lib.get_option("train_rows_wg")
+    try:
+        for form in (1, 0):
+            _lib.set_option("train_rows_wg", form)
+            part = torch.full((B, nw, D), float("nan"), device=DEV, dtype=torch.float32)
+            dT = torch.empty((B, S, D), device=DEV, dtype=torch.bfloat16)
+            ops.gate_bwd(g(dx), g(t), g(gate), g(G), dT, part, B=B, S=S, D=D, R=R, gate_bs=D)
+            assert rel_l2(dT, gate[:, None] * dx.float() + G.float()) < 5e-3, form
+            dg = torch.zeros((B, D), device=DEV)
+            ops.reduce_rows(part, dg, np_=nw, len_=D, nz=B, in_zs=nw * D, in_ps=D, out_zs=D)
+            assert rel_l2(dg, (dx.float() * t.float()).sum(1)) < 5e-3, form
+            # plain residual form (no gate: dT = dX + G, no partials), ragged last row group
+            dT2 = torch.empty((B, S, D), device=DEV, dtype=torch.bfloat16)
+            ops.gate_bwd(g(dx), None, None, g(G), dT2, None, B=B, S=S - 3, D=D, R=R, dx_bs=S * D, g_bs=S * D, dt_bs=S * D)
+            assert rel_l2(dT2[:, :S - 3], (dx.float() + G.float())[:, :S - 3]) < 5e-3, form
+    finally:
+        _lib.set_option("train_rows_wg", old)
     from x2i_amd.ops import ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU
     pre = bf(seeded((64, 256), 13, 2.0))
     for act, fn in ((ACT_GELU_TANH, lambda v: F.gelu(v, approximate="tanh")), (ACT_GELU_ERF, F.gelu), (ACT_SILU, F.silu)):

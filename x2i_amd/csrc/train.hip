@@ -304,31 +304,221 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same two operators with a WORKGROUP per R rows and a THREAD per eight columns (D / 8 <= 512 threads): the wave-per-row forms above
+// keep a whole row and its column accumulators in one wave's registers (320+ registers: one wave per SIMD, one row's loads in flight),
+// and at batch 1 their 576 waves leave half the SIMDs empty -- 0.9-1.4 TB/s on kernels that only stream rows
+// (profiles/r03i_train_b1_kernel_stats.csv: 90 / 62 us per call for 112 / 84 MB).  Here a thread owns its eight columns for all R rows
+// (its slice of the column sums stays in 8-16 registers), loads RB rows at a time, and the row statistics of ln_mod_bwd are
+// workgroup reductions (wave sums, one LDS exchange per round, fixed order).  Same partial layout: partial[b][w][stat][:], w = row group.
+// wave sum on the VALU's DPP path (four steps inside a row of 16 lanes, two row broadcasts): the total arrives in lane 63.  (wave_sum's six
+// __shfl_xor steps are six dependent LDS-crossbar round trips; a row kernel that needs eight sums per row step spends its time there.)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_step(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_step<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = dpp_step<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = dpp_step<0x141>(v);       // row_half_mirror
+  v = dpp_step<0x140>(v);       // row_mirror: every lane of a 16-lane row holds the row's sum
+  v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// every thread returns the workgroup's sums of x[0..NV); `red` is one of two alternating LDS buffers (one barrier per call: a buffer is
+// rewritten only two calls later, behind the barrier of the call in between)
+template <int NV>
+__device__ __forceinline__ void block_sums(float (&x)[NV], float* red, int nwaves) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) x[k] = wave_sum_lane63(x[k]);
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[wv * NV + k] = x[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += red[u * NV + k];   // (slots of waves the workgroup does not have hold zeros: cleared once by the kernel)
+    x[k] = a;
+  }
+}
+
+constexpr int LB_RB = 2;   // rows per step of ln_mod_bwd_rows_kernel (measured: 4 rows = 227 registers, two waves per SIMD, 3.4 TB/s; 2 rows = 120 registers, four
+                           // waves, 4.2-4.6 TB/s; 8 rows 1.2 TB/s: tools/train_rows_probe.py)
+constexpr int GB_RB = 4;   // ... of gate_bwd_rows_kernel (no reductions: loads in flight are all that matters)
+__global__ __launch_bounds__(512) void ln_mod_bwd_rows_kernel(const bf16_t* __restrict__ X, long long x_bs, int ldx, const bf16_t* __restrict__ dY,
+                                                               long long dy_bs, int ldy, const float* __restrict__ m, long long m_bs,
+                                                               int mult_is_scale, const bf16_t* dXin, bf16_t* __restrict__ dXout, long long dx_bs,
+                                                               int lddx, int S, int D, int R, float* __restrict__ partial, float eps,
+                                                               int ngroups_per_b) {
+  __shared__ float red[2][8 * 2 * LB_RB];
+  for (int i = threadIdx.x; i < 2 * 8 * 2 * LB_RB; i += blockDim.x) (&red[0][0])[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.x / ngroups_per_b, w = blockIdx.x % ngroups_per_b;
+  const int c = threadIdx.x, nv = D >> 3, nwaves = blockDim.x >> 6;
+  const bool act = c < nv;
+  const float invD = 1.f / (float)D;
+  float mul[8], a0[8], a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a0[j] = a1[j] = 0.f;
+    mul[j] = act ? (mult_is_scale ? 1.f + m[(long long)b * m_bs + c * 8 + j] : m[c * 8 + j]) : 0.f;
+  }
+  const int s_end = min(S, (w + 1) * R);
+  for (int s0 = w * R; s0 < s_end; s0 += LB_RB) {
+    float v[LB_RB][8], g[LB_RB][8], st[2 * LB_RB];
+    bf16x8_t dxi[LB_RB];
+#pragma unroll
+    for (int k = 0; k < LB_RB; ++k) {   // every load of the step first
+      const bool live = act && s0 + k < s_end;
+      bf16x8_t xv = {0, 0, 0, 0, 0, 0, 0, 0}, gv = {0, 0, 0, 0, 0, 0, 0, 0};
+      dxi[k] = xv;
+      if (live) {
+        xv = *(const bf16x8_t*)(X + (long long)b * x_bs + (long long)(s0 + k) * ldx + c * 8);
+        gv = *(const bf16x8_t*)(dY + (long long)b * dy_bs + (long long)(s0 + k) * ldy + c * 8);
+        if (dXin) dxi[k] = *(const bf16x8_t*)(dXin + (long long)b * dx_bs + (long long)(s0 + k) * lddx + c * 8);
+      }
+      unpack8(xv, v[k]);
+      unpack8(gv, g[k]);
+    }
+    // round 1: sum x and sum x^2 of every row (one exchange; the variance as E[x^2] - mean^2 in f32 over D <= 4096 columns)
+#pragma unroll
+    for (int k = 0; k < LB_RB; ++k) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a += v[k][j];
+        q = fmaf(v[k][j], v[k][j], q);
+      }
+      st[2 * k] = a;
+      st[2 * k + 1] = q;
+    }
+    block_sums<2 * LB_RB>(st, red[0], nwaves);
+    float mean[LB_RB], rstd[LB_RB];
+#pragma unroll
+    for (int k = 0; k < LB_RB; ++k) {
+      mean[k] = st[2 * k] * invD;
+      rstd[k] = rsqrtf(fmaxf(fmaf(-mean[k], mean[k], st[2 * k + 1] * invD), 0.f) + eps);
+      float sg = 0.f, sgx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = act ? (v[k][j] - mean[k]) * rstd[k] : 0.f;
+        a0[j] = fmaf(g[k][j], xh, a0[j]);
+        a1[j] += g[k][j];
+        const float gm = g[k][j] * mul[j];
+        v[k][j] = xh;   // keep xhat
+        g[k][j] = gm;   // keep g * mult
+        sg += gm;
+        sgx = fmaf(gm, xh, sgx);
+      }
+      st[2 * k] = sg;
+      st[2 * k + 1] = sgx;
+    }
+    block_sums<2 * LB_RB>(st, red[1], nwaves);   // round 2: sum g and sum g * xhat
+#pragma unroll
+    for (int k = 0; k < LB_RB; ++k) {
+      if (act && s0 + k < s_end) {
+        const float mg = st[2 * k] * invD, mgx = st[2 * k + 1] * invD;
+        float o[8];
+        unpack8(dxi[k], o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += rstd[k] * (g[k][j] - mg - v[k][j] * mgx);
+        *(bf16x8_t*)(dXout + (long long)b * dx_bs + (long long)(s0 + k) * lddx + c * 8) = pack8(o);
+      }
+    }
+  }
+  if (act) {
+    float* pp = partial + ((long long)b * ngroups_per_b + w) * 2 * D + c * 8;
+    *(f32x4_t*)pp = (f32x4_t){a0[0], a0[1], a0[2], a0[3]};
+    *(f32x4_t*)(pp + 4) = (f32x4_t){a0[4], a0[5], a0[6], a0[7]};
+    *(f32x4_t*)(pp + D) = (f32x4_t){a1[0], a1[1], a1[2], a1[3]};
+    *(f32x4_t*)(pp + D + 4) = (f32x4_t){a1[4], a1[5], a1[6], a1[7]};
+  }
+}
+
+__global__ __launch_bounds__(512) void gate_bwd_rows_kernel(const bf16_t* __restrict__ dX, long long dx_bs, int lddx, const bf16_t* __restrict__ T,
+                                                             long long t_bs, int ldt, const float* __restrict__ gate, long long g_bs,
+                                                             const bf16_t* __restrict__ G, long long gg_bs, int ldg, bf16_t* __restrict__ dT,
+                                                             long long dt_bs, int lddt, int S, int D, int R, float* __restrict__ partial,
+                                                             int ngroups_per_b) {
+  const int b = blockIdx.x / ngroups_per_b, w = blockIdx.x % ngroups_per_b;
+  const int c = threadIdx.x;
+  if (c >= (D >> 3)) return;
+  float gt[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] = 0.f;
+    gt[j] = gate ? gate[(long long)b * g_bs + c * 8 + j] : 1.f;
+  }
+  const int s_end = min(S, (w + 1) * R);
+  for (int s0 = w * R; s0 < s_end; s0 += GB_RB) {
+    bf16x8_t dv[GB_RB], tv[GB_RB], ov[GB_RB];
+#pragma unroll
+    for (int k = 0; k < GB_RB; ++k) {   // every load of the step first
+      const bool live = s0 + k < s_end;
+      dv[k] = tv[k] = ov[k] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      if (live) {
+        dv[k] = *(const bf16x8_t*)(dX + (long long)b * dx_bs + (long long)(s0 + k) * lddx + c * 8);
+        if (gate) tv[k] = *(const bf16x8_t*)(T + (long long)b * t_bs + (long long)(s0 + k) * ldt + c * 8);
+        if (G) ov[k] = *(const bf16x8_t*)(G + (long long)b * gg_bs + (long long)(s0 + k) * ldg + c * 8);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GB_RB; ++k) {
+      if (s0 + k < s_end) {
+        float d[8], t[8], o[8];
+        unpack8(dv[k], d);
+        unpack8(tv[k], t);
+        unpack8(ov[k], o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[j] = fmaf(d[j], t[j], acc[j]);
+          o[j] = fmaf(gt[j], d[j], o[j]);
+        }
+        *(bf16x8_t*)(dT + (long long)b * dt_bs + (long long)(s0 + k) * lddt + c * 8) = pack8(o);
+      }
+    }
+  }
+  if (gate && partial) {
+    float* pp = partial + ((long long)b * ngroups_per_b + w) * D + c * 8;
+    *(f32x4_t*)pp = (f32x4_t){acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4_t*)(pp + 4) = (f32x4_t){acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
 // out[z][i] (op)= sum_{p < np} in[z][p][i]   (second stage of every column sum); accumulate != 0: add to what is there.
 // A block owns 64 consecutive i and splits the partial rows over its 4 waves (fixed order: deterministic), four loads in flight per lane.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, long long in_zs, int np, long long in_ps, float* __restrict__ out,
-                                                          long long out_zs, int len, int accumulate, float alpha) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ in, long long in_zs, int np, long long in_ps, float* __restrict__ out,
+                                                           long long out_zs, int len, int accumulate, float alpha) {
+  // 16 waves per block, wave w takes partial rows w, w + 16, ...; eight loads in flight per lane (the first form -- four waves, four
+  // loads -- walked 576 partial rows in 36 dependent steps: 16.8 us for 7 MB, 432 calls per training step)
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   float s = 0.f;
   if (i < len) {
     const float* p = in + (long long)blockIdx.y * in_zs + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
     int k = w;
-    for (; k + 12 < np; k += 16) {
-      s0 += p[(long long)k * in_ps];
-      s1 += p[(long long)(k + 4) * in_ps];
-      s2 += p[(long long)(k + 8) * in_ps];
-      s3 += p[(long long)(k + 12) * in_ps];
+    for (; k + 7 * 16 < np; k += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += p[(long long)(k + u * 16) * in_ps];
     }
-    for (; k < np; k += 4) s0 += p[(long long)k * in_ps];
-    s = (s0 + s1) + (s2 + s3);
+    for (; k < np; k += 16) acc[0] += p[(long long)k * in_ps];
+    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
   red[w][lane] = s;
   __syncthreads();
   if (w == 0 && i < len) {
-    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += red[u][lane];
     float* o = out + (long long)blockIdx.y * out_zs + i;
     *o = accumulate ? *o + alpha * t : alpha * t;
   }
@@ -796,6 +986,12 @@ int x2i_launch_ln_mod_bwd(const void* X, long long x_bs, int ldx, const void* dY
     return x2i_set_error(X2I_ERR_ALIGN, "ln_mod_bwd: D %% 8 == 0, D <= 4096, 16-byte aligned rows");
   const int nw = (S + R - 1) / R;
   const long long waves = (long long)B * nw;
+  if (x2i_options().train_rows_wg && D / 8 <= 512 && (((uintptr_t)partial) & 15) == 0 && waves < 0x7fffffffLL) {   // a workgroup per row group (see ln_mod_bwd_rows_kernel)
+    const int nt = ((D / 8 + 63) / 64) * 64;
+    hipLaunchKernelGGL(ln_mod_bwd_rows_kernel, dim3((unsigned)waves), dim3(nt), 0, stream, (const bf16_t*)X, x_bs, ldx, (const bf16_t*)dY, dy_bs, ldy, m,
+                       m_bs, mult_is_scale, (const bf16_t*)dXin, (bf16_t*)dXout, dx_bs, lddx, S, D, R, partial, eps, nw);
+    return x2i_check_launch("ln_mod_bwd");
+  }
   hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)X, x_bs, ldx, (const bf16_t*)dY,
                      dy_bs, ldy, m, m_bs, mult_is_scale, (const bf16_t*)dXin, (bf16_t*)dXout, dx_bs, lddx, S, D, R, partial, eps, nw, B);
   return x2i_check_launch("ln_mod_bwd");
@@ -810,6 +1006,12 @@ int x2i_launch_gate_bwd(const void* dX, long long dx_bs, int lddx, const void* T
     return x2i_set_error(X2I_ERR_ALIGN, "gate_bwd: D %% 8 == 0, D <= 4096, 16-byte aligned rows");
   const int nw = (S + R - 1) / R;
   const long long waves = (long long)B * nw;
+  if (x2i_options().train_rows_wg && D / 8 <= 512 && (!partial || (((uintptr_t)partial) & 15) == 0) && waves < 0x7fffffffLL) {
+    const int nt = ((D / 8 + 63) / 64) * 64;
+    hipLaunchKernelGGL(gate_bwd_rows_kernel, dim3((unsigned)waves), dim3(nt), 0, stream, (const bf16_t*)dX, dx_bs, lddx, (const bf16_t*)T, t_bs, ldt, gate,
+                       g_bs, (const bf16_t*)G, gg_bs, ldg, (bf16_t*)dT, dt_bs, lddt, S, D, R, partial, nw);
+    return x2i_check_launch("gate_bwd");
+  }
   hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)dX, dx_bs, lddx, (const bf16_t*)T,
                      t_bs, ldt, gate, g_bs, (const bf16_t*)G, gg_bs, ldg, (bf16_t*)dT, dt_bs, lddt, S, D, R, partial, nw, B);
   return x2i_check_launch("gate_bwd");
@@ -818,7 +1020,7 @@ int x2i_launch_gate_bwd(const void* dX, long long dx_bs, int lddx, const void* T
 int x2i_launch_reduce_rows(const float* in, long long in_zs, int np, long long in_ps, float* out, long long out_zs, int nz, int len,
                            int accumulate, float alpha, hipStream_t stream) {
   if (!in || !out || np <= 0 || nz <= 0 || len <= 0) return x2i_set_error(X2I_ERR_ARG, "reduce_rows: bad argument");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((len + 63) / 64, nz), dim3(256), 0, stream, in, in_zs, np, in_ps, out, out_zs, len, accumulate, alpha);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((len + 63) / 64, nz), dim3(1024), 0, stream, in, in_zs, np, in_ps, out, out_zs, len, accumulate, alpha);
   return x2i_check_launch("reduce_rows");
 }
 
