@@ -115,6 +115,34 @@ def test_ln_modulate_fp8_matches_bf16_kernel_and_torch():
     ops.ln_modulate_fp8(Xd, None, Y8, rs, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)  # bf16 output optional
 
 
+def test_ln_modulate_fp8_rows_form_equals_per_row_form():
+    """D = 3072 with >= 4096 rows takes the four-rows-per-wave kernel (modulation vectors in registers, ln_fp8_rows_kernel): e4m3 rows,
+    row scales and the optional bf16 output against the per-row kernel (option fp8 = 2) bit for bit; the text / image boundary S0 falls
+    inside a wave's row group, and the last row group is ragged."""
+    from x2i_amd import _lib, ops
+    B, S, D, S0 = 2, 2307, 3072, 510
+    g = torch.Generator(device=DEV).manual_seed(5)
+    Xd = (torch.randn((B, S, D), device=DEV, generator=g) * 2 + 0.3).bfloat16()
+    md = torch.randn((B, 4 * D), device=DEV, generator=g) * 0.3
+    outs = []
+    old = _lib.get_option("fp8")
+    try:
+        for form in (2, 0):
+            _lib.set_option("fp8", form)
+            Y = torch.zeros_like(Xd)
+            Y8 = torch.zeros((B, S, D), device=DEV, dtype=torch.uint8)
+            rs = torch.zeros((B * S,), device=DEV, dtype=torch.float32)
+            ops.ln_modulate_fp8(Xd, Y, Y8.view(FP8), rs, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)
+            outs.append((Y, Y8, rs))
+    finally:
+        _lib.set_option("fp8", old)
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+    Yref = torch.empty_like(Xd)
+    ops.ln_modulate(Xd, Yref, B, S, D, S0, md, md[:, D:], md[:, 2 * D:], md[:, 3 * D:], 4 * D)
+    assert torch.equal(outs[1][0], Yref)
+
+
 @pytest.mark.parametrize("variant", [0, 9])
 def test_attention_e4m3_output_equals_quantised_bf16_output(variant):
     """variant 9: the hand-scheduled kernel's e4m3 epilogue (16 consecutive bytes per lane), 0: the automatic choice at this size"""

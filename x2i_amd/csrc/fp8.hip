@@ -139,6 +139,87 @@ __global__ __launch_bounds__(256) void ln_fp8_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// The same operator for D = 512 * CPL with RW consecutive rows per wave: the (1 + scale) / shift vectors of a sample (four times a row's
+// bf16 bytes) stay in registers across the rows instead of coming back from the L2 for every row -- ln_rows_kernel's form (elementwise.hip;
+// 57.8 -> the bf16 kernel's ~45 us per call is what the per-row fetch cost).  Same arithmetic as ln_fp8_kernel, element for element.
+template <int CPL, int RW>
+__global__ __launch_bounds__(256) void ln_fp8_rows_kernel(const bf16_t* __restrict__ X, long long x_bs, int ldx, bf16_t* __restrict__ Y,
+                                                          long long y_bs, int ldy, uint8_t* __restrict__ Y8, long long y8_bs, int ldy8,
+                                                          float* __restrict__ row_scale, int S, int S0, const float* shift0,
+                                                          const float* scale0, const float* shift1, const float* scale1, long long mod_bs,
+                                                          float eps, long long total_rows) {
+  constexpr int D = CPL * 512;
+  const int lane = threadIdx.x & 63;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  float sc[CPL][8], sh[CPL][8];
+  int cb = -1, cside = -1;
+#pragma unroll 1
+  for (int r = 0; r < RW; ++r) {
+    const long long row = row0 + r;
+    if (row >= total_rows) return;
+    const int b = (int)(row / S);
+    const int s = (int)(row - (long long)b * S);
+    const int side = s < S0 ? 0 : 1;
+    const bf16_t* x = X + (long long)b * x_bs + (long long)s * ldx;
+    float v[CPL][8];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) unpack8(*(const bf16x8_t*)(x + (lane + i * 64) * 8), v[i]);
+    if (b != cb || side != cside) {  // (wave-uniform) a new sample or stream: fetch its modulation vectors once
+      const float* shp = (side ? shift1 : shift0) + (long long)b * mod_bs;
+      const float* scp = (side ? scale1 : scale0) + (long long)b * mod_bs;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = (lane + i * 64) * 8;
+        const f32x4_t s0 = *(const f32x4_t*)(scp + c), s1 = *(const f32x4_t*)(scp + c + 4);
+        const f32x4_t h0 = *(const f32x4_t*)(shp + c), h1 = *(const f32x4_t*)(shp + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[i][j] = s0[j]; sc[i][j + 4] = s1[j]; sh[i][j] = h0[j]; sh[i][j + 4] = h1[j]; }
+      }
+      cb = b; cside = side;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = __fsub_rn(v[i][j], mean);
+        sq = __builtin_fmaf(d, d, sq);
+      }
+    const float rstd = rsqrtf(__fadd_rn(wave_sum(sq) / (float)D, eps));
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] = ln_mod1(v[i][j], mean, rstd, sc[i][j], sh[i][j]);
+        amax = fmaxf(amax, fabsf(v[i][j]));
+      }
+    amax = wave_max(amax);
+    const float qs = amax > 0.f ? amax * (1.f / E4M3_MAX) : 1.f;
+    const float inv = 1.f / qs;
+    if (lane == 0) row_scale[row] = qs;
+    uint8_t* y8 = Y8 + (long long)b * y8_bs + (long long)s * ldy8;
+    bf16_t* y = Y ? Y + (long long)b * y_bs + (long long)s * ldy : nullptr;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + i * 64;
+      *(uint2*)(y8 + c * 8) = pack_e4m3x8(v[i], inv);
+      if (y) {
+        union { bf16x8_t v8; uint32_t u[4]; } rr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr.u[j] = pack_bf16x2(v[i][2 * j], v[i][2 * j + 1]);
+        *(bf16x8_t*)(y + c * 8) = rr.v8;
+      }
+    }
+  }
+}
+
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -161,6 +242,11 @@ int x2i_launch_ln_modulate_fp8(const void* X, long long x_bs, int ldx, void* Y, 
   if (ldx % 8 || x_bs % 8 || mod_bs % 4 || !al16(X) || (Y && (ldy % 8 || y_bs % 8 || !al16(Y))) || ldy8 % 8 || y8_bs % 8 || (((uintptr_t)Y8) & 7))
     return x2i_set_error(X2I_ERR_ALIGN, "ln_modulate_fp8: rows must be 16-byte (bf16) / 8-byte (e4m3) aligned");
   const long long rows = (long long)B * S;
+  if (D == 3072 && rows >= 4096 && x2i_options().fp8 != 2) {  // the model's width: four rows per wave, modulation vectors in registers (option fp8 = 2: the per-row form, A/B)
+    hipLaunchKernelGGL((ln_fp8_rows_kernel<6, 4>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, (const bf16_t*)X, x_bs, ldx, (bf16_t*)Y, y_bs,
+                       ldy, (uint8_t*)Y8, y8_bs, ldy8, row_scale, S, S0, shift0 ? shift0 : shift1, scale0 ? scale0 : scale1, shift1, scale1, mod_bs, eps, rows);
+    return x2i_check_launch("ln_modulate_fp8");
+  }
   hipLaunchKernelGGL(ln_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)X, x_bs, ldx, (bf16_t*)Y, y_bs,
                      ldy, (uint8_t*)Y8, y8_bs, ldy8, row_scale, S, D, S0, shift0 ? shift0 : shift1, scale0 ? scale0 : scale1, shift1, scale1,
                      mod_bs, eps, rows);

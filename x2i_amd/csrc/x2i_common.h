@@ -42,7 +42,7 @@ struct X2IOptions {
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
   int conv5_variant;      // matrix-core projector conv: 0 = automatic form choice; 1 = plain stages, 2 = pipelined, 3 = two row blocks   X2I_CONV5_VARIANT
-  int fp8;                // reserved for the fp8 path switch                                               X2I_FP8
+  int fp8;                // 2 = x2i_ln_modulate_fp8 keeps its per-row kernel at the model's width (A/B against the four-rows-per-wave form); else unused   X2I_FP8
   int last_gemm_tile;     // read-only introspection for the parity tests: tile edge of the kernel the last GEMM / conv launch used
                           // (256, 128, 0 = generic kernel), + 1000 when a peeled 128^2 tail launch followed the 256^2 launch
   // measurement-only library (libx2i_hip_ablate.so, -DX2I_ABLATION); ignored by the product library
