@@ -247,17 +247,26 @@ class ControlNeXtModel(nn.Module):
             sc = x_in
         return ops.conv2d_nhwc(n, r.conv2.packed(), r.conv2.bias, h, w, cout, cout, 3, 3, 1, 1, res=sc)
 
+    @staticmethod
     @torch.no_grad()
-    def forward_nhwc(self, prep, timestep, add_into=None, add_offset=0, add_batch_stride=None, add_ld=None):
-        """Timestep-dependent part.  Returns NHWC [B, H/16, W/16, out_ch]; with `add_into` (the transformer's joint
-        residual buffer) the final conv's epilogue adds its result straight into the image-token rows instead
-        (hidden_states + control['out'] * 1.0, lightcontrol_flux.py:506-507)."""
-        B, h, w = prep["B"], prep["h"], prep["w"]
+    def timestep_features(prep, timestep):
+        """Timesteps(128)(timestep) for the B samples of a prepared hint: f32 [B, 128] (lightcontrol_flux.py:730-733).  The same for every
+        net that was prepared with the same hint dtype, so the 19 nets of a step share ONE evaluation (make_control_fn)."""
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([float(t)], device=prep["x0"].device)
-        t = t.reshape(-1).to(device=prep["x0"].device, dtype=torch.float32).expand(B).contiguous()
-        tp = ops.timestep_sinusoid(t, 128, round_bf16=prep["round_bf16"])  # Timesteps(128).to(sample.dtype) (:730-733)
+        t = t.reshape(-1).to(device=prep["x0"].device, dtype=torch.float32).expand(prep["B"]).contiguous()
+        return ops.timestep_sinusoid(t, 128, round_bf16=prep["round_bf16"])  # Timesteps(128).to(sample.dtype)
+
+    @torch.no_grad()
+    def forward_nhwc(self, prep, timestep, add_into=None, add_offset=0, add_batch_stride=None, add_ld=None, tp=None):
+        """Timestep-dependent part.  Returns NHWC [B, H/16, W/16, out_ch]; with `add_into` (the transformer's joint
+        residual buffer) the final conv's epilogue adds its result straight into the image-token rows instead
+        (hidden_states + control['out'] * 1.0, lightcontrol_flux.py:506-507).  `tp`: timestep_features(prep, timestep) when the caller
+        has them already."""
+        B, h, w = prep["B"], prep["h"], prep["w"]
+        if tp is None:
+            tp = self.timestep_features(prep, timestep)
         te = self.time_embedding
         e1 = ops.skinny_linear(tp, te.linear_1.weight, te.linear_1.bias, act_out=ACT_SILU)
         emb = ops.skinny_linear(e1, te.linear_2.weight, te.linear_2.bias)  # [B,256] f32
@@ -316,10 +325,14 @@ def make_control_fn(control_nets, guided_hint):
     nets = list(control_nets)
     preps = [n.prepare_hint(guided_hint) for n in nets]
 
+    shared = {"t": None, "tp": None}   # the sinusoidal timestep features are the same for all nets of a step: one evaluation per step
+
     def fn(i, t1000, X, St, S, D):
         if i >= len(nets):
             return False
-        nets[i].forward_nhwc(preps[i], t1000, add_into=X, add_offset=St * D, add_batch_stride=S * D, add_ld=D)
+        if shared["t"] is not t1000:
+            shared["t"], shared["tp"] = t1000, ControlNeXtModel.timestep_features(preps[0], t1000)
+        nets[i].forward_nhwc(preps[i], t1000, add_into=X, add_offset=St * D, add_batch_stride=S * D, add_ld=D, tp=shared["tp"])
         return True
 
     return fn
