@@ -80,6 +80,14 @@ def test_full_pipeline_graph_replay_equals_eager(full_model):
     b = pipe(**kw, use_graph=True).images
     c = pipe(**kw, use_graph=True).images
     assert a.shape == (2, 4096, 64) and torch.equal(a, b) and torch.equal(b, c)
+    # the AdaLN tables of two steps per pass in front of the loop (default at batch 2) against one table per step: the same samples
+    # through the same skinny kernel in other batches -- bit-identical final latents (FluxTransformer2DModel.prepare_modulation)
+    assert full_model.MOD_GROUP // 2 == 2
+    pipe.hoist_modulation = False
+    assert torch.equal(pipe(**kw).images, a)
+    pipe.hoist_modulation = True
+    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == 2 else v) for k, v in kw.items()}   # batch 1: four steps per pass
+    assert torch.equal(pipe(**one).images, a[:1])
     u = FluxPipeline._unpack_latents(a, 1024, 1024, 16)
     assert u.shape == (2, 16, 128, 128)
     assert torch.equal(FluxPipeline._pack_latents(u, 2, 16, 128, 128), a)  # pack o unpack = id at full size

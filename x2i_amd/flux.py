@@ -345,10 +345,40 @@ class FluxTransformer2DModel(nn.Module):
         return dict(B=B, St=St, Si=Si, ctx=ctx, cos=cos, sin=sin, cond=cond, ws=ws,
                     round_bf16=pooled_projections.dtype == torch.bfloat16)
 
+    MOD_GROUP = 4   # (t, sample) pairs per pass of the modulation table: x2i_skinny_linear stages its activations in LDS, and beyond four
+                    # samples of K = 3072 only one workgroup fits a CU -- measured: eight pairs per pass run no faster than two passes of four
+
     @torch.no_grad()
-    def denoise(self, state, hidden_states, timestep, control=None):
+    def prepare_modulation(self, state, timesteps, dtype=torch.bfloat16):
+        """The AdaLN modulation tables of SEVERAL denoise calls: temb = timestep_embedder(Timesteps(t * 1000)) + cond and
+        `mod = Linear(SiLU(temb))` for every t of `timesteps` (a list of [B] tensors, each what `denoise` would be given; `dtype` = the
+        dtype of its hidden_states).  The table is a pass over 27 % of the model's weights (6.4 GB, 1.34 ms at any batch: 2 % of a
+        batch-1 step) that depends on (t, pooled text, guidance) only: a sampler that knows its schedule evaluates MOD_GROUP // B steps
+        per pass.  Returns one [B, mod_rows] f32 table per entry of `timesteps` for `denoise(mod=...)`, or None where a pass would hold
+        a single step anyway (B > MOD_GROUP / 2: `denoise` then computes its own, into the workspace).  Per-sample results are those of
+        the per-step evaluation (x2i_skinny_linear treats every sample alike; tests/test_fullsize_gpu.py)."""
+        f = self._fused
+        B, n = state["B"], len(timesteps)
+        g = self.MOD_GROUP // B
+        if g < 2:
+            return [None] * n
+        out = []
+        for i0 in range(0, n, g):
+            ts = timesteps[i0:i0 + g]
+            t1000 = torch.cat([(t.to(device=self.device, dtype=dtype) * 1000).float().reshape(-1).expand(B) for t in ts]).contiguous()
+            tp = ops.timestep_sinusoid(t1000, 256, round_bf16=state["round_bf16"])
+            h1 = ops.skinny_linear(tp, f["tte.timestep_embedder.1.w"], f["tte.timestep_embedder.1.b"], act_out=ACT_SILU)
+            temb = state["cond"].repeat(len(ts), 1)
+            ops.skinny_linear(h1, f["tte.timestep_embedder.2.w"], f["tte.timestep_embedder.2.b"], out=temb, accumulate=True)
+            table = ops.skinny_linear(temb, f["mod.w"], f["mod.b"], act_in=ACT_SILU)
+            out += [table[k * B:(k + 1) * B] for k in range(len(ts))]
+        return out
+
+    @torch.no_grad()
+    def denoise(self, state, hidden_states, timestep, control=None, mod=None):
         """One transformer evaluation given prepared conditioning.  `control`: optional callable
-        (i, timestep_x1000, X, St, S, D) that adds control net i's output into the image rows of X after double block i."""
+        (i, timestep_x1000, X, St, S, D) that adds control net i's output into the image rows of X after double block i.
+        `mod`: this call's modulation table from prepare_modulation (None: computed here)."""
         cfg = self.config
         f = self._fused
         ws = state["ws"]
@@ -365,14 +395,19 @@ class FluxTransformer2DModel(nn.Module):
         # ---- temb = timestep_embedder(Timesteps(t*1000)) + cond   (lightcontrol_flux.py:447,452-456)
         # `timestep.to(hidden_states.dtype) * 1000` -- in the reference's bf16 run this multiply rounds to bf16
         # (750 -> 752); we follow the dtype the caller hands us, exactly as the reference module does.
-        t1000 = (timestep.to(device=self.device, dtype=hidden_states.dtype) * 1000).float().contiguous()
-        tp = ops.timestep_sinusoid(t1000, 256, round_bf16=state["round_bf16"])
-        h1 = ops.skinny_linear(tp, f["tte.timestep_embedder.1.w"], f["tte.timestep_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
-        temb = ws["TEMB"]
-        temb.copy_(state["cond"])
-        ops.skinny_linear(h1, f["tte.timestep_embedder.2.w"], f["tte.timestep_embedder.2.b"], out=temb, accumulate=True)
-        # ---- every AdaLN modulation vector of this step in one HBM-bound pass over 27% of the weights
-        ops.skinny_linear(temb, f["mod.w"], f["mod.b"], out=MOD, act_in=ACT_SILU)
+        t1000 = None
+        if mod is None or control is not None:
+            t1000 = (timestep.to(device=self.device, dtype=hidden_states.dtype) * 1000).float().contiguous()
+        if mod is not None:
+            MOD = mod   # (prepare_modulation: the same values, computed with the other steps' tables)
+        else:
+            tp = ops.timestep_sinusoid(t1000, 256, round_bf16=state["round_bf16"])
+            h1 = ops.skinny_linear(tp, f["tte.timestep_embedder.1.w"], f["tte.timestep_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
+            temb = ws["TEMB"]
+            temb.copy_(state["cond"])
+            ops.skinny_linear(h1, f["tte.timestep_embedder.2.w"], f["tte.timestep_embedder.2.b"], out=temb, accumulate=True)
+            # ---- every AdaLN modulation vector of this step in one HBM-bound pass over 27% of the weights
+            ops.skinny_linear(temb, f["mod.w"], f["mod.b"], out=MOD, act_in=ACT_SILU)
         cos, sin = state["cos"], state["sin"]
         scale = 1.0 / math.sqrt(128.0)
 

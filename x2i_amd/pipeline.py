@@ -14,6 +14,8 @@ Batch > 1 and batch sharding over ranks (x2i_amd.dist) are this build's extensio
 import math
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -100,6 +102,8 @@ class FluxPipeline:
         self.vae_scale_factor = 16  # diffusers 0.31: 2 ** len(vae.config.block_out_channels) == 16 for FLUX
         self.default_sample_size = 64
         self.control_nets = control_nets
+        # all steps' AdaLN tables in front of the loop (False / X2I_HOIST_MOD=0: one table per step, A/B; identical results)
+        self.hoist_modulation = os.environ.get("X2I_HOIST_MOD", "1") != "0"
         self._graphs = {}
 
     @classmethod
@@ -240,8 +244,10 @@ class FluxPipeline:
             """prepare + N x (transformer, Euler) -- every launch goes to the current stream (graph-capturable)."""
             state = tr.prepare_conditioning(pe, pooled, aux["txt_ids"], aux["img_ids"], aux["guidance"])
             control = self._control_fn(hnt)
+            # the schedule is known: several steps' AdaLN tables per pass over the modulation weights at batch 1 / 2 (prepare_modulation)
+            mods = tr.prepare_modulation(state, tvals, lat.dtype) if self.hoist_modulation else [None] * len(tvals)
             for i in range(len(tvals)):
-                noise = tr.denoise(state, lat, tvals[i], control=control)
+                noise = tr.denoise(state, lat, tvals[i], control=control, mod=mods[i])
                 ops.euler_step_(lat, noise, dts[i:i + 1])
 
         if not use_graph:
