@@ -139,10 +139,18 @@ __global__ __launch_bounds__(256) void gn_finish_kernel(float* __restrict__ part
   float a = 0.f, q = 0.f;
   if (g < G) {
     const float* pp = partial + (long long)gridDim.x * G * 2 + ((long long)b * GN_SLABS * G + g) * 2;
-    for (int s = part; s < GN_SLABS; s += 8) {
-      a += pp[(long long)s * G * 2];
-      q += pp[(long long)s * G * 2 + 1];
+    // eight slabs' loads in flight (as one dependent chain of 32 the kernel took 9.7 us, 80 calls per LightControl step)
+    float a4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < GN_SLABS; s0 += 32) {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const float2*)(pp + (long long)(s0 + part + 8 * u) * G * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a4[u] += v[u].x; q4[u] += v[u].y; }
     }
+    a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
   }
   red[part][g][0] = a;
   red[part][g][1] = q;
