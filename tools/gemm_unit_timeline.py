@@ -4,7 +4,7 @@ M = 18432, N = 12288, K = 3072 without epilogue: how long a K-loop statement run
 import os
 import sys
 import torch
-os.environ["X2I_LIB_VARIANT"] = "ablate"
+os.environ["X2I_LIB_VARIANT"] = os.environ.get("X2I_TIMELINE_LIB", "ablate")   # (another measurement build: X2I_TIMELINE_LIB=<name>)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from x2i_amd import ops  # noqa: E402
 

@@ -126,9 +126,23 @@ def check(s, kind):
         assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0", "XD") or e == ("CNT", 0)), "SCC must survive to the branch"
 
 
+ABL = os.environ.get("X2I_F8_ABL", "")   # measurement builds only (WRONG results): the loop without its pieces (nodma), barriers (nobar),
+                                         # fragment reads (nolds) or M0 writes (nom0) -- profiles/r04am_fp8_kloop_ablation.log
+
+
 def emit(ev, st):
     kind = ev[0]
     mode = st["mode"]
+    if (ABL == "nobar" and kind == "BAR") or (ABL == "nom0" and kind == "M0"):
+        return []
+    if ABL == "nolds" and kind in ("RA", "RW"):
+        st["ds"] += [(kind, ev[1], 0), (kind, ev[1], 1)]
+        return []
+    if ABL == "nodma" and kind == "D":
+        st["vm"] += 1
+        return []
+    if ABL == "nodma" and kind == "VM":
+        return []
     if kind in ("RA", "RW"):
         n = ev[1]
         reg, addr = (A, "%[la]") if kind == "RA" else (W, "%[lw]")
