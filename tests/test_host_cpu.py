@@ -258,6 +258,9 @@ def test_generated_gemm_loop_is_current():
     # the M0 / piece pairing are asserted by the generator, lgkmcnt counts derived from the simulated LDS queue)
     gen8 = os.path.join(here, "x2i_amd", "csrc", "gen_gemm256f8.py")
     assert subprocess.run([sys.executable, gen8, "--check"]).returncode == 0
+    # ... and the K-loop of the "two residents" A/B kernel (csrc/gemm_r2_loop.inc <- gen_gemm_r2.py: wait counts from the simulated queues)
+    gen_r2 = os.path.join(here, "x2i_amd", "csrc", "gen_gemm_r2.py")
+    assert subprocess.run([sys.executable, gen_r2, "--check"]).returncode == 0
 
 
 def test_generated_attention_statement_is_current():

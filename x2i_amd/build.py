@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libx2i_hip.so")
 # measurement-only library for tools/ (ablation kernels that are "wrong results by design", the k-half-unit GEMM form):
 # same sources, the files below recompiled with -DX2I_ABLATION.  Never loaded by the product package.
 LIB_ABLATE = os.path.join(HERE, "libx2i_hip_ablate.so")
-ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm256w.hip", "gemm256p.hip", "attention.hip", "c_api.hip")
+ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm_r2.hip", "gemm256w.hip", "gemm256p.hip", "attention.hip", "c_api.hip")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=fast"]
 

@@ -281,6 +281,25 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     }
     if (frc) return frc;
   }
+  // A/B (option gemm_r2): the "two residents" form -- 256 x 128 tiles, two workgroups per CU, epilogues hidden behind the other
+  // workgroup's K-loop; whole K-tiles in groups of four
+  if (opt.gemm_r2 && !conv && !qd && fast && !f32 && a->K % (4 * BK) == 0 && a->M >= 256 && a->N >= 128 && !a->w_batch_stride) {
+#ifdef X2I_ABLATION
+    const int var = opt.gemm_ablate;
+#else
+    const int var = 0;
+#endif
+    if (kern_t kr = pick_gemm_r2(p.act, res, f32, c2, var)) {
+      const int rc = x2i_ensure_dynamic_smem((const void*)kr, SMEM_R2_BYTES);
+      if (rc) return rc;
+      GemmP pm = p;
+      pm.tilesM = (a->M + 255) / 256; pm.tilesN = (a->N + 127) / 128;
+      pm.gm = opt.gemm_gm > 0 ? opt.gemm_gm : 4;
+      hipLaunchKernelGGL(kr, dim3(pm.tilesM * pm.tilesN, a->batch), dim3(256), SMEM_R2_BYTES, stream, pm);
+      opt.last_gemm_tile = 4256;
+      return x2i_check_launch("gemm (r2)");
+    }
+  }
   if (force == 128) use256 = false;
   if (force == 256 && !conv) use256 = true;
   if (conv && !conv256) use256 = false;

@@ -37,6 +37,8 @@ struct X2IOptions {
                           // bit-identical results; default); 0 = whole tiles only (+ the peeled 128^2 tail launch)          X2I_GEMM_STREAMK
   int gemm_fx;            // 1 = launches with fewer 256^2 tiles per batch item than CUs and a deep K are cut along K over all CUs (parallel split with
                           // fix-up, gemm256p.hip FX; default); 0 = whole tiles (A/B; results differ in the association of the K sum)   X2I_GEMM_FX
+  int gemm_r2;            // A/B: 1 = plain bf16 launches take the "two residents" kernel (gemm_r2.hip: 256 x 128 tiles, two workgroups per CU) when
+                          // their shape allows (K % 256 == 0); bit-identical results; default 0                              X2I_GEMM_R2
   int gemm_fp8_persist;   // 1 = x2i_gemm_fp8 / x2i_gemm_qkv_fp8 take the persistent four-wave form when they can (default); 0 = the one-tile 8-wave kernel (A/B)
   int gemm_persist;       // 1 = batch-1 launches with whole-line epilogues take the persistent form (gemm256p.hip, default)   X2I_GEMM_PERSIST
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
