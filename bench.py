@@ -18,6 +18,7 @@ events on the launch stream) and "cpu_baseline" (the CPU oracle timed on the hos
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -153,7 +154,7 @@ def _in_step_gemm_rate(B):
         return None
     rate = gemm_fl * steps / (t_ns * 1e-9)
     return dict(achieved=rate / 1e12, frac=rate / PEAK_BF16, unit="TFLOP/s", gemm_ms_per_denoise_step=t_ns * 1e-6 / steps, gemm_launches=calls,
-                source=os.path.relpath(path, ROOT), note="all MFMA GEMM launches of %d denoise steps (2*M*N*K of every nn.Linear of the DiT, SURVEY.md "
+                measured="committed profile (builder's box, not this run)", source=os.path.relpath(path, ROOT), note="all MFMA GEMM launches of %d denoise steps (2*M*N*K of every nn.Linear of the DiT, SURVEY.md "
                 "Appendix C) / their summed rocprofv3 kernel time" % steps)
 
 
@@ -201,10 +202,86 @@ def gemm_roofline(B, rounds=6, per_round=8):
                 frac_best=flt / t_min / PEAK_BF16, frac_worst=flt / t_max / PEAK_BF16,
                 probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", statistic="median round (frac), fastest (frac_best)",
                            us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times], clock_power=power),
+                measured="live (HIP events on the launch stream, this run)",
                 in_step=_in_step_gemm_rate(B),
-                traffic=traffic, traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_kernel (bf16 instantiations)",
+                traffic=traffic, traffic_measured="committed PMC profile (builder's box, not this run)" if traffic is not None else None,
+                traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_kernel (bf16 instantiations)",
                 shapes="M=%d: N=12288,K=3072 (+GELU) + N=3072,K=15360 (single-block proj_mlp / proj_out shapes, 1.39 + 1.74 TFLOP; one persistent "
                        "256^2 launch each, last round cut along K)" % (B * S))
+
+
+def attention_roofline(B, rounds=6, per_round=8):
+    """Second kernel of the step (21 % of its time): `attn_w4_kernel` at the single-block geometry (24 heads, S = 4608, output into the
+    [S, 5D] concatenation buffer, exp2-domain scale as flux.py passes it).  Two live estimators, both HIP events on the launch stream:
+    `alone` = back-to-back launches (what tools/attn_bench.py reports), and `in_sequence` = every attention launch timed on its own
+    between the two roofline GEMM launches, i.e. in the power / clock state the step leaves it in.  frac = the in-sequence median."""
+    from x2i_amd import ops
+    H, S, D = 24, 4608, 3072
+    B = min(B, 8)
+    Spad = ops.pad128(S)
+    Q = (torch.randn(B, H, Spad, 128, device="cuda") * (math.log2(math.e) / math.sqrt(128))).bfloat16()
+    K_, VT = torch.randn(B, H, Spad, 128, device="cuda").bfloat16(), torch.randn(B, H, 128, Spad, device="cuda").bfloat16()
+    CAT = torch.empty((B, S, 5 * D), device="cuda", dtype=torch.bfloat16)
+    A0 = torch.randn(B * S, D, device="cuda").bfloat16()
+    W0 = (torch.randn(4 * D, D, device="cuda") * 0.02).bfloat16()
+    W1 = (torch.randn(D, 5 * D, device="cuda") * 0.02).bfloat16()
+    X = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
+
+    def attn():
+        ops.attention(Q, K_, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, math.log(2.0))
+
+    def g0():
+        ops.gemm(A0, W0, None, out=CAT, act=1, ldc=5 * D, c_offset=D)     # proj_mlp + GELU into the concatenation buffer, as the block does
+
+    def g1():
+        ops.gemm(CAT, W1, None, out=X)                                   # proj_out over [attention | MLP]
+    fl = 4.0 * B * H * S * S * 128
+    times, power = _interleaved_probe([attn], rounds, per_round)
+    alone = sorted(times[0])
+    for _ in range(2):
+        g0(); attn(); g1()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds * per_round)]
+    with ClockPowerSampler(torch.cuda.current_device()) as smp:
+        for e0, e1 in ev:
+            g0()
+            e0.record()
+            attn()
+            e1.record()
+            g1()
+        torch.cuda.synchronize()
+    seq = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev)
+    t_seq, t_alone = seq[len(seq) // 2], alone[len(alone) // 2]
+    return dict(bound="mfma", kernel="attn_w4_kernel", achieved=fl / t_seq / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / t_seq / PEAK_BF16,
+                frac_alone=fl / t_alone / PEAK_BF16, us_in_sequence=t_seq * 1e6, us_alone=t_alone * 1e6, us_in_sequence_min_max=[seq[0] * 1e6, seq[-1] * 1e6],
+                measured="live (HIP events on the launch stream, this run)", flop_per_launch=fl,
+                clock_power_alone=power, clock_power_in_sequence=smp.summary(),
+                note="in_sequence: each launch between the two roofline GEMM launches (the step's order); alone: back-to-back attention launches. "
+                     "The difference is the clock the power-capped part runs the kernel at behind a GEMM (DESIGN.md section 4, round 5)",
+                shapes="B=%d, 24 heads, S=4608 (512 text + 4096 image tokens), head dim 128; 4*B*H*S^2*128 FLOP" % B)
+
+
+def vae_decode_line(B, images_s_denoise, passes=3):
+    """The step right after the sampling path (row N1), BESIDE the headline and never inside it: ms per 1024^2 image of the HIP VAE decoder
+    (random-init FLUX VAE), its algorithmic FLOPs and fraction of the bf16 peak, and the images/s the job would have with the decode
+    included.  HIP-event timed."""
+    from x2i_amd.vae import AutoencoderKL, decode_flops
+    vae = AutoencoderKL(device="cuda").init_random_(0)
+    z = torch.randn(B, 16, 128, 128, device="cuda").bfloat16()
+    for _ in range(2):
+        vae.decode(z, return_dict=False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(passes):
+        vae.decode(z, return_dict=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_img = e0.elapsed_time(e1) / passes / B
+    fl = decode_flops(vae.config, 128, 128)
+    del vae
+    return dict(ms_per_image=ms_img, flop_per_image=fl, achieved=fl / (ms_img * 1e-3) / 1e12, unit="TFLOP/s", frac=fl / (ms_img * 1e-3) / PEAK_BF16,
+                images_s_incl_decode=1.0 / (1.0 / images_s_denoise + ms_img * 1e-3), measured="live (HIP events, this run)", batch=B,
+                note="FLUX VAE decoder at 1024^2, random-init weights; outside the timed region of `value` (BASELINE metric = projector + denoise loop)")
 
 
 def gemm_roofline_fp8(B, rounds=6, per_round=8):
@@ -241,7 +318,7 @@ def gemm_roofline_fp8(B, rounds=6, per_round=8):
     t_med, t_min = pair[len(pair) // 2], pair[0]
     alg_bytes = (B * S * D + 4 * D * D + B * S * 4 * D) + (B * S * 5 * D + 5 * D * D + 2 * 2 * B * S * D)
     return dict(bound="mfma", achieved=fl / t_med / 1e12, peak=PEAK_FP8 / 1e12, unit="TFLOP/s", frac=fl / t_med / PEAK_FP8,
-                frac_best=fl / t_min / PEAK_FP8, traffic=None, algorithmic_bytes=float(alg_bytes), kernel=kernel,
+                frac_best=fl / t_min / PEAK_FP8, measured="live (HIP events on the launch stream, this run)", traffic=None, algorithmic_bytes=float(alg_bytes), kernel=kernel,
                 probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", clock_power=power,
                            us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times]),
                 shapes="M=%d: N=12288,K=3072 (+GELU, e4m3 out) + N=3072,K=15360 (gated residual), e4m3 operands" % (B * S))
@@ -487,7 +564,9 @@ def main(argv=None):
             return gathered
         return lat if stub else FluxPipeline._unpack_latents(lat, args.size, args.size, 16)
 
-    for _ in range(args.warmup):
+    # graph policy of FluxPipeline: a shape's first pass runs eagerly, its second is captured; both happen here, in front of the W warm-ups
+    setup_passes = 0 if (args.no_graph or stub) else 2
+    for _ in range(setup_passes + args.warmup):
         one_pass()
     sync()
     if use_dist:
@@ -517,8 +596,8 @@ def main(argv=None):
         Si = (args.size // 16) ** 2
         fl = flops_per_denoise_step(B, St, Si)
         line = {
-            "metric": "images/sec, FLUX-schnell 1024x1024 4-step (projector + denoise loop), whole job",
-            "value": images_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "images/sec, FLUX-schnell %dx%d %d-step (projector + denoise loop), whole job" % (args.size, args.size, N),
+            "value": images_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_passes": setup_passes,
             "ms_per_step": ms_pass, "ms_per_denoise_step": ms_pass / N, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random MLLM hidden states, seeded noise)",
             "rccl_ranks": world if use_dist else 0, "rank_ms_per_step": [round(x, 3) for x in rank_ms],
@@ -542,7 +621,7 @@ def main(argv=None):
             print(json.dumps(line), flush=True)
         else:
             if args.config == 5:
-                line["metric"] = "images/sec, LightControl FLUX.1-dev 1024x1024 %d-step (projector + denoise loop), whole job" % N
+                line["metric"] = "images/sec, LightControl FLUX.1-dev %dx%d %d-step (projector + denoise loop), whole job" % (args.size, args.size, N)
                 line["model_tflops_per_gpu"] = (fl + 8.30e12 * B) * N / (ms_pass * 1e-3) / 1e12  # + 19 x 436.8 GFLOP per image-step
                 line["model_frac_of_bf16_peak"] = line["model_tflops_per_gpu"] * 1e12 / PEAK_BF16
             if args.dtype == "fp8":
@@ -556,12 +635,17 @@ def main(argv=None):
                 line["roofline"] = None if args.no_roofline else gemm_roofline_fp8(B)
             else:
                 line["roofline"] = None if args.no_roofline else gemm_roofline(B)
+                if not args.no_roofline and args.size == 1024:
+                    line["roofline_attention"] = attention_roofline(B)
+                    if args.config == 2 and world == 1:
+                        line["vae"] = vae_decode_line(B, images_s)
             if args.dtype == "bf16" and world == 1 and args.config == 2 and not args.no_fp8_lines:
                 # the opt-in e4m3 configurations in the same driver-timed record (the headline above stays bf16 = the reference's arithmetic):
                 # 1 warm-up + 3 timed passes each; stated tolerances in tests/test_fp8_gpu.py / test_fullscale_parity_gpu.py
                 for mode in ("mlp", "all"):
                     model.enable_fp8(mode)
-                    one_pass()
+                    for _ in range(max(1, setup_passes)):   # (eager pass, then the capture: see setup_passes)
+                        one_pass()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     for _ in range(3):

@@ -20,8 +20,10 @@
  *     mutex-protected: the option table below, a per-kernel "dynamic LDS size already raised" cache, and ONE HIP object set per
  *     device that holds no memory -- a side stream with two events, created on the first x2i_attention_bwd_bf16 call that runs
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
- *   - ABI version 2 (x2i_abi_version): x2i_gemm_args grew `workspace` / `workspace_bytes` and x2i_qkv_desc `q_scale` since
- *     version 1; a caller built against another version must not load this library (x2i_amd/_lib.py checks).
+ *   - ABI version 3 (x2i_abi_version).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
+ *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
+ *     zero-initialised descriptor means what it meant in version 1).  A caller built against another version must not load this
+ *     library (x2i_amd/_lib.py checks).
  */
 #ifndef X2I_H
 #define X2I_H
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define X2I_ABI_VERSION 2
+#define X2I_ABI_VERSION 3
 
 #define X2I_OK 0
 #define X2I_ERR_ARG (-1)
@@ -56,7 +58,7 @@ const char* x2i_last_error(void);
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
  * "gemm_w4" (1: 4-wave hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output
  * tiles), "gemm_fp8_persist" (1: x2i_gemm_fp8 / x2i_gemm_qkv_fp8 take the persistent four-wave form too; 0: the one-tile e4m3 kernel, bit-identical),
- * "gemm_fx" (1: a gated-residual launch whose batch ITEM has fewer 256^2 output tiles than the chip has CUs, with K >= 6144, is cut along K
+ * "gemm_fx" (DEFAULT 0, opt-in; 1: a gated-residual launch whose batch ITEM has fewer 256^2 output tiles than the chip has CUs, with K >= 6144, is cut along K
  * over all CUs -- every part summed from zero in parallel, the parts of a tile added in a fixed order by the workgroup that holds the last
  * one; needs the workspace.  Decided and cut by the item's shape alone, so a sample's result does not depend on its batch; deterministic;
  * NOT bit-identical to the whole-tile kernels (another association of the K sum, same tolerance).  0: whole tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
@@ -64,6 +66,8 @@ const char* x2i_last_error(void);
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
+ * "gemm_r2" (DEFAULT 0; 1: A/B -- plain bf16 launches with K % 256 == 0 take the "two residents" kernel, 256 x 128 tiles and two
+ * workgroups per CU, bit-identical and measured slower: DESIGN.md section 4 round 5),
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
  * same values up to the summation order of the row statistics),
  * "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
@@ -169,7 +173,8 @@ int x2i_ln_modulate_fp8(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64
 typedef struct x2i_conv_desc {
   int32_t H, W, Cin, KH, KW, stride, pad;
   int32_t up; /* 1: F.interpolate(scale_factor=2, mode="nearest") fused in front of the conv (diffusers Upsample2D) */
-  int32_t pad_w; /* padding along W; negative: the same as `pad` (which then pads both dimensions, nn.Conv2d(padding=int)) */
+  int32_t pad_w_p1; /* 0 (a zero-initialised descriptor): `pad` pads both dimensions, nn.Conv2d(padding=int); otherwise the padding
+                     * along W is pad_w_p1 - 1 and `pad` is the padding along H (nn.Conv2d(padding=(pad, pad_w_p1 - 1))) */
 } x2i_conv_desc;
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
 

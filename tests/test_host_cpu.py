@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
                                     "x2i_streamk_workspace_bytes", "x2i_groupnorm_moments_scratch_floats"}
     assert declared == bound, (declared ^ bound)
     ver = int(re.search(r"#define X2I_ABI_VERSION (\d+)", hdr).group(1))
-    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 2   # header, library and binding move together
+    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 3   # header, library and binding move together
     assert lib.x2i_streamk_workspace_bytes() == 4096 + 256 * 256 * 1024   # the caller-owned stream-K workspace: flags + 256 slabs of 256 KiB
 
 
@@ -210,6 +210,13 @@ def test_c_abi_argument_validation_returns_codes_without_a_gpu():
     a = _lib.GemmArgs()
     a.A, a.W, a.C, a.M, a.N, a.K, a.batch = 0x1000, 0x1000, 0x1000, 64, 64, 9 * 48, 1
     assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"multiple of 64" in lib.x2i_last_error()
+    # ABI 3: a descriptor whose ninth field was never set (0) pads W like H -- nn.Conv2d(padding=pad); pad_w_p1 = 1 means NO padding along W
+    cd = _lib.ConvDesc(H=8, W=8, Cin=64, KH=3, KW=3, stride=1, pad=1, up=0)
+    a.M, a.K = 48, 9 * 64
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"OH*OW=64" in lib.x2i_last_error()
+    cd.pad_w_p1 = 1
+    a.M = 64
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"OH*OW=48" in lib.x2i_last_error()
 
     assert lib.x2i_attention_bf16(fake, fake, fake, fake, 1, 1, 100, 100, 128, 12800, 0.1, None) < 0  # Spad % 128
     assert lib.x2i_qkv_split_bf16(None, fake, 384, 384, 1, 64, 0, 1, None, None, fake, fake, fake, fake, fake, fake, fake, 100, 1e-6, None) < 0

@@ -260,3 +260,50 @@ def test_attention_taps_for_distillation_match_oracle():
     assert abs(float(loss0)) < 1e-6 and float(loss1) > 1e-4 and torch.isfinite(loss1)
     ref_loss = distill.kd_attention_loss([torch.stack(x, 1).float().cpu() for x in tl], [torch.stack(x, 1).float().cpu() for x in sl])
     assert abs(float(loss1) - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)))
+
+
+def test_graph_policy_first_seen_shape_runs_once_and_graphs_form_an_lru():
+    """FluxPipeline.__call__(use_graph=True): a key seen for the first time runs the eager launch sequence ONCE and returns its latents
+    (no discarded warm-up pass, no capture); the graph is captured when the key comes back; graphs of several text lengths stay cached
+    (LRU bounded by count and bytes) -- the ragged prompt lengths of infer/inference_minicpm.py:160-177 and the growing ones of
+    infer/inference_multi_turn.py:132-156 at the reference's batch 1 (infer/inference_qwenvl.py:188-207)."""
+    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+    t, meta = golden("flux_tiny_schnell")
+    cfg = meta["cfg"]
+    m = make_model(cfg, OF.random_flux_state_dict(cfg, seed=meta["weight_seed"], std=meta["weight_std"]))
+    pipe = FluxPipeline(m, FlowMatchEulerDiscreteScheduler(**OS.SCHEDULER_SCHNELL))
+    eager = FluxPipeline(m, FlowMatchEulerDiscreteScheduler(**OS.SCHEDULER_SCHNELL))
+    noise = OS.pack_latents(torch.randn((1, 16, 16, 24), generator=torch.Generator().manual_seed(0))).bfloat16().to(DEV)
+
+    def inputs(st, seed):
+        return dict(prompt_embeds=seeded((1, st, 128), seed).bfloat16().to(DEV), pooled_prompt_embeds=seeded((1, 64), seed + 1).bfloat16().to(DEV),
+                    num_inference_steps=4, guidance_scale=3.5, height=128, width=192, output_type="latent", latents=noise)
+
+    ref = {st: eager(**inputs(st, 7 + st)).images for st in (40, 24, 56)}
+    # a new text length: one eager pass, its result is the answer; nothing captured yet
+    a = pipe(**inputs(40, 47), use_graph=True).images
+    assert torch.equal(a, ref[40]) and pipe.graph_stats == dict(eager=1, captures=0, replays=0, evictions=0)
+    # the length comes back: captured now, replayed; no further eager pass
+    b = pipe(**inputs(40, 47), use_graph=True).images
+    assert torch.equal(b, ref[40]) and pipe.graph_stats == dict(eager=1, captures=1, replays=1, evictions=0)
+    c = pipe(**inputs(40, 47), use_graph=True).images
+    assert torch.equal(c, ref[40]) and pipe.graph_stats == dict(eager=1, captures=1, replays=2, evictions=0)
+    # alternating two lengths three times: two captures in total (the old one-entry cache captured on every switch)
+    pipe2 = FluxPipeline(m, FlowMatchEulerDiscreteScheduler(**OS.SCHEDULER_SCHNELL))
+    for _ in range(3):
+        for st in (40, 24):
+            assert torch.equal(pipe2(**inputs(st, 7 + st), use_graph=True).images, ref[st])
+    assert pipe2.graph_stats == dict(eager=2, captures=2, replays=4, evictions=0)
+    # the LRU evicts the least recently used graph once the bound is hit, and an evicted length is captured again when it returns
+    pipe2.graph_cache_entries = 2
+    for _ in range(2):
+        assert torch.equal(pipe2(**inputs(56, 63), use_graph=True).images, ref[56])
+    assert pipe2.graph_stats["captures"] == 3 and pipe2.graph_stats["evictions"] == 1 and len(pipe2._graphs) == 2
+    assert torch.equal(pipe2(**inputs(24, 31), use_graph=True).images, ref[24])      # 24 was used after 40: still cached
+    assert pipe2.graph_stats["captures"] == 3
+    assert torch.equal(pipe2(**inputs(40, 47), use_graph=True).images, ref[40])      # 40 was evicted: captured again (its warm-up pass exists)
+    assert pipe2.graph_stats["captures"] == 4 and pipe2.graph_stats["eager"] == 3
+    # bytes bound: a budget smaller than one graph keeps exactly the newest one
+    pipe2.graph_cache_bytes = 1
+    pipe2._evict()
+    assert len(pipe2._graphs) == 1

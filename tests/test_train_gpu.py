@@ -88,6 +88,32 @@ def test_ln_modulate_backward_vs_autograd(ops, B, S, D, R):
         _lib.set_option("train_rows_wg", old)
 
 
+def test_ln_modulate_backward_rows_with_a_large_mean(ops):
+    """massive-activation rows (mean 200 x the spread): the workgroup-per-row-group form takes the variance as mean((x - mean)^2) like the
+    forward and the wave-per-row form do; E[x^2] - mean^2 in f32 would lose it."""
+    B, S, D, R = 1, 16, 3072, 8
+    x = seeded((B, S, D), 15, 1.0)
+    x[:, ::2] += 200.0
+    x, dy, sc = bf(x), bf(seeded((B, S, D), 16)), seeded((B, D), 17, 0.3)
+    xr = x.float().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), eps=1e-6) * (1 + sc[:, None])
+    (y * dy.float()).sum().backward()
+    from x2i_amd import _lib
+    old = _lib.get_option("train_rows_wg")
+    got = {}
+    try:
+        for form in (1, 0):
+            _lib.set_option("train_rows_wg", form)
+            part = torch.empty((B, S // R, 2, D), device=DEV, dtype=torch.float32)
+            dx = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+            ops.ln_mod_bwd(g(x), g(dy), g(sc), None, dx, part, B=B, S=S, D=D, R=R, mult_bs=D)
+            got[form] = dx.float().cpu()
+            assert rel_l2(dx, xr.grad) < 1e-2, form
+    finally:
+        _lib.set_option("train_rows_wg", old)
+    assert rel_l2(got[1], got[0]) < 4e-3
+
+
 def test_gate_backward_and_act_backward(ops):
     B, S, D, R = 2, 32, 256, 8
     dx, t, G = bf(seeded((B, S, D), 9)), bf(seeded((B, S, D), 10)), bf(seeded((B, S, D), 11))

@@ -14,7 +14,7 @@ _VARIANT = os.environ.get("X2I_LIB_VARIANT", "")
 LIB_PATH = os.path.join(_HERE, "libx2i_hip_%s.so" % _VARIANT if _VARIANT else "libx2i_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
-ABI_VERSION = 2  # include/x2i.h: X2I_ABI_VERSION
+ABI_VERSION = 3  # include/x2i.h: X2I_ABI_VERSION
 
 
 class X2IError(RuntimeError):
@@ -40,7 +40,7 @@ class GemmArgs(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
-                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32), ("pad_w", C.c_int32)]
+                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32), ("pad_w_p1", C.c_int32)]
 
 
 class QkvDesc(C.Structure):

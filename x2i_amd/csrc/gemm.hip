@@ -216,7 +216,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
     const int up = cd->up ? 1 : 0;
-    const int pad_w = cd->pad_w < 0 ? cd->pad : cd->pad_w;
+    const int pad_w = cd->pad_w_p1 <= 0 ? cd->pad : cd->pad_w_p1 - 1;
     if (cd->KH * cd->KW > 32) return x2i_set_error(X2I_ERR_SHAPE, "conv: at most 32 filter taps (KH=%d KW=%d)", cd->KH, cd->KW);
     const int OH = ((cd->H << up) + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = ((cd->W << up) + 2 * pad_w - cd->KW) / cd->stride + 1;
     if (a->M != OH * OW || a->K != cd->KH * cd->KW * cd->Cin)

@@ -266,9 +266,14 @@ DOC = """// operands of the e4m3 persistent loop (all named; fragments are NOT o
 
 
 def main():
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm256f8_loop.inc")
+    # an ablation stream (X2I_F8_ABL: a loop without its DMA / barriers / LDS reads, WRONG results) never lands in the product file: it goes
+    # to gemm256f8_loop_abl_<what>.inc and carries an #error for builds without -DX2I_ABLATION
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"gemm256f8_loop_abl_{ABL}.inc" if ABL else "gemm256f8_loop.inc")
     P, MC, D = generate()
     txt = ["// GENERATED by gen_gemm256f8.py -- do not edit; the schedule table lives in the generator.", DOC]
+    if ABL:
+        txt += [f"// ABLATION STREAM ({ABL}): wrong results by design, measurement builds only", "#ifndef X2I_ABLATION",
+                f'#error "gemm256f8_loop_abl_{ABL}.inc is an ablation stream: measurement builds (-DX2I_ABLATION) only"', "#endif"]
     for name, L in (("X2I_GEMM256F8_PRO", P), ("X2I_GEMM256F8_MAIN", MC), ("X2I_GEMM256F8_DRAIN", D)):
         txt.append(f"// {name}: {len(L)} lines")
         txt.append(f"#define {name} \\")

@@ -326,7 +326,7 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
   return v;
 }
-// every thread returns the workgroup's sums of x[0..NV); `red` is one of two alternating LDS buffers (one barrier per call: a buffer is
+// every thread returns the workgroup's sums of x[0..NV); `red` is one of the cyclically used LDS buffers (one barrier per call: a buffer is
 // rewritten only two calls later, behind the barrier of the call in between)
 template <int NV>
 __device__ __forceinline__ void block_sums(float (&x)[NV], float* red, int nwaves) {
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_rows_kernel(const bf16_t* __re
                                                                int mult_is_scale, const bf16_t* dXin, bf16_t* __restrict__ dXout, long long dx_bs,
                                                                int lddx, int S, int D, int R, float* __restrict__ partial, float eps,
                                                                int ngroups_per_b) {
-  __shared__ float red[2][8 * 2 * LB_RB];
-  for (int i = threadIdx.x; i < 2 * 8 * 2 * LB_RB; i += blockDim.x) (&red[0][0])[i] = 0.f;
+  __shared__ float red[3][8 * 2 * LB_RB];   // one exchange buffer per reduction round of a step (0: sum x, 1: sum (x - mean)^2, 2: sum g, sum g xhat)
+  for (int i = threadIdx.x; i < 3 * 8 * 2 * LB_RB; i += blockDim.x) (&red[0][0])[i] = 0.f;
   __syncthreads();
   const int b = blockIdx.x / ngroups_per_b, w = blockIdx.x % ngroups_per_b;
   const int c = threadIdx.x, nv = D >> 3, nwaves = blockDim.x >> 6;
@@ -385,24 +385,32 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_rows_kernel(const bf16_t* __re
       unpack8(xv, v[k]);
       unpack8(gv, g[k]);
     }
-    // round 1: sum x and sum x^2 of every row (one exchange; the variance as E[x^2] - mean^2 in f32 over D <= 4096 columns)
+    // rounds 1a / 1b: the row mean, then the variance as mean((x - mean)^2) -- the two-pass form of the forward kernel and of the
+    // wave-per-row backward (E[x^2] - mean^2 loses the variance of a row whose mean is large against its spread: massive-activation rows)
+    float mean[LB_RB], rstd[LB_RB], s1[LB_RB];
 #pragma unroll
     for (int k = 0; k < LB_RB; ++k) {
-      float a = 0.f, q = 0.f;
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += v[k][j];
+      s1[k] = a;
+    }
+    block_sums<LB_RB>(s1, red[0], nwaves);
+#pragma unroll
+    for (int k = 0; k < LB_RB; ++k) {
+      mean[k] = s1[k] * invD;
+      float q = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        a += v[k][j];
-        q = fmaf(v[k][j], v[k][j], q);
+        const float d = act ? v[k][j] - mean[k] : 0.f;
+        q = fmaf(d, d, q);
       }
-      st[2 * k] = a;
-      st[2 * k + 1] = q;
+      s1[k] = q;
     }
-    block_sums<2 * LB_RB>(st, red[0], nwaves);
-    float mean[LB_RB], rstd[LB_RB];
+    block_sums<LB_RB>(s1, red[1], nwaves);
 #pragma unroll
     for (int k = 0; k < LB_RB; ++k) {
-      mean[k] = st[2 * k] * invD;
-      rstd[k] = rsqrtf(fmaxf(fmaf(-mean[k], mean[k], st[2 * k + 1] * invD), 0.f) + eps);
+      rstd[k] = rsqrtf(s1[k] * invD + eps);
       float sg = 0.f, sgx = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_rows_kernel(const bf16_t* __re
       st[2 * k] = sg;
       st[2 * k + 1] = sgx;
     }
-    block_sums<2 * LB_RB>(st, red[1], nwaves);   // round 2: sum g and sum g * xhat
+    block_sums<2 * LB_RB>(st, red[2], nwaves);   // round 2: sum g and sum g * xhat
 #pragma unroll
     for (int k = 0; k < LB_RB; ++k) {
       if (act && s0 + k < s_end) {

@@ -438,7 +438,7 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     a.act = act
     a.out_f32 = 0
     a.w_batch_stride = 0
-    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, 1 if up else 0, -1 if pad_w is None else pad_w)
+    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, 1 if up else 0, 0 if pad_w is None else pad_w + 1)
     check(lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(d), _stream()), "conv2d_nhwc")
     return out
 

@@ -7,7 +7,8 @@
     latents = FluxPipeline._unpack_latents(latents, height, width, vae_scale_factor)
 
 The loop body (transformer + Euler update) runs entirely in libx2i_hip.so; with `use_graph=True` the whole N-step
-loop is captured once into a hipGraph (per shape) and replayed -- timesteps and sigma deltas are device-side inputs.
+loop of a shape that comes back is captured into a hipGraph and replayed (an LRU of graphs; a shape seen for the first time runs
+eagerly and its pass is the answer) -- timesteps and sigma deltas are device-side inputs.
 Batch > 1 and batch sharding over ranks (x2i_amd.dist) are this build's extension along the axis the API already has
 (`prompt_embeds.shape[0]`).
 """
@@ -104,7 +105,15 @@ class FluxPipeline:
         self.control_nets = control_nets
         # all steps' AdaLN tables in front of the loop (False / X2I_HOIST_MOD=0: one table per step, A/B; identical results)
         self.hoist_modulation = os.environ.get("X2I_HOIST_MOD", "1") != "0"
-        self._graphs = {}
+        # hipGraph cache: a key (batch, text length, size, steps, guidance, hint, fp8 mode) is run EAGERLY the first time it is seen and
+        # that pass's latents are returned; it is captured when it comes back, and the captured graphs form an LRU bounded by count and
+        # bytes (ragged prompt lengths -- infer/inference_minicpm.py:160-177, inference_multi_turn.py:132-156 -- neither pay two passes
+        # per new length nor evict each other's graphs)
+        self._graphs = {}           # key -> [graph, static inputs, aux tensors, bytes]; insertion order = recency
+        self._seen = {}             # keys run eagerly once (a warm-up pass exists), not yet captured
+        self.graph_cache_entries = int(os.environ.get("X2I_GRAPH_CACHE_ENTRIES", "8"))
+        self.graph_cache_bytes = int(float(os.environ.get("X2I_GRAPH_CACHE_GB", "32")) * 2 ** 30)
+        self.graph_stats = dict(eager=0, captures=0, replays=0, evictions=0)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, text_encoder=None, text_encoder_2=None, tokenizer=None,
@@ -147,7 +156,7 @@ class FluxPipeline:
                 n.to(device)
             if self.vae is not None and hasattr(self.vae, "to"):
                 self.vae.to(device)
-            self._graphs = {}
+            self._graphs, self._seen = {}, {}
         return self
 
     @property
@@ -250,30 +259,38 @@ class FluxPipeline:
                 noise = tr.denoise(state, lat, tvals[i], control=control, mod=mods[i])
                 ops.euler_step_(lat, noise, dts[i:i + 1])
 
-        if not use_graph:
+        key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None,
+               getattr(self.transformer, "_fp8_mode", None),  # a graph captured on the bf16 path must not serve the e4m3 path
+               self.hoist_modulation)
+        entry = self._graphs.get(key) if use_graph else None
+        if entry is None and not (use_graph and key in self._seen):
+            # eager launch sequence: the caller's choice, or a key seen for the FIRST time -- its pass IS the answer (and the warm-up of
+            # every lazy allocation / kernel attribute of this shape); a graph is captured only when the key comes back
             latents = latents.clone()
             body(prompt_embeds, pooled_prompt_embeds, latents, hint)
             ops.streamk_poll()
+            self.graph_stats["eager"] += 1
+            self._seen[key] = True
+            while len(self._seen) > 256:
+                self._seen.pop(next(iter(self._seen)))
             return FluxPipelineOutput(latents) if return_dict else (latents,)
-
-        key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None,
-               getattr(self.transformer, "_fp8_mode", None))  # a graph captured on the bf16 path must not serve the e4m3 path
-        entry = self._graphs.get(key)
         if entry is None:
             static = dict(pe=prompt_embeds.clone(), pooled=pooled_prompt_embeds.clone(), lat=latents.clone(),
                           hint=None if hint is None else hint.clone())
             # the graph owns its stream-K workspace (ops.streamk_scope): two graphs replayed on two streams never share one
+            torch.cuda.synchronize(device)
+            before = torch.cuda.memory_allocated(device)
             aux["sk_ws"] = ops.StreamKWorkspace(device)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), ops.streamk_scope(aux["sk_ws"]):  # warm-up: lazy allocations, kernel attributes
-                body(static["pe"], static["pooled"], static["lat"], static["hint"])
-            torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), ops.streamk_scope(aux["sk_ws"]):
                 body(static["pe"], static["pooled"], static["lat"], static["hint"])
-            entry = (graph, static, aux)  # ids / guidance / schedule tensors must outlive the call: the graph reads them
-            self._graphs = {key: entry}
+            nbytes = max(0, torch.cuda.memory_allocated(device) - before)   # static inputs + workspace + the capture's private pool
+            entry = [graph, static, aux, nbytes]  # ids / guidance / schedule tensors must outlive the call: the graph reads them
+            self._graphs[key] = entry
+            self.graph_stats["captures"] += 1
+            self._evict(keep=key)
+        else:
+            self._graphs[key] = self._graphs.pop(key)   # most recently used last
         graph, static = entry[0], entry[1]
         static["pe"].copy_(prompt_embeds)
         static["pooled"].copy_(pooled_prompt_embeds)
@@ -282,8 +299,19 @@ class FluxPipeline:
             static["hint"].copy_(hint)
         graph.replay()
         entry[2]["sk_ws"].poll()
+        self.graph_stats["replays"] += 1
         out = static["lat"].clone()
         return FluxPipelineOutput(out) if return_dict else (out,)
+
+    def _evict(self, keep=None):
+        """LRU over the captured graphs, bounded by entries AND by the device bytes they pin (static inputs, stream-K workspace, the
+        activations in the capture's private pool: ~2.5 GB per 1024^2 batch-4 graph)."""
+        def total():
+            return sum(e[3] for e in self._graphs.values())
+        while len(self._graphs) > 1 and (len(self._graphs) > self.graph_cache_entries or total() > self.graph_cache_bytes):
+            victim = next(k for k in self._graphs if k != keep)
+            del self._graphs[victim]
+            self.graph_stats["evictions"] += 1
 
     def _control_fn(self, hint):
         if hint is None:

@@ -609,6 +609,7 @@ class GraphedDistillStep:
             self.warm_shapes = None
         if self.calls == 1 or getattr(self, "warm_shapes", None) != shapes:
             loss = self._body(text_embeddings, latents, timestep, teacher)   # eager warm-up step (a real step)
+            ops.streamk_poll()
             self.warm_shapes = shapes
         else:
             if self.graph is None:
@@ -631,6 +632,7 @@ class GraphedDistillStep:
                 for d, t in zip(s["teacher"], teacher):
                     d.copy_(t)
             self.graph.replay()
+            self.sk_ws.poll()   # asynchronous read of the graph's stream-K give-up marker; checked per optimizer step (train_distill.run)
             loss = self.loss
             # the table packed inside the graph belongs to the graph's pool and is rewritten by every replay; an eager forward must
             # not pick it up from the cache

@@ -18,6 +18,7 @@ import os
 import torch
 
 from . import dist as xdist
+from . import ops
 from .flux import FluxTransformer2DModel
 from .pipeline import FluxPipeline
 from .proj import Proj7Exp, create_proj3_qwen3b, create_proj3_qwen7b
@@ -182,12 +183,17 @@ def run(args):
             loss = distill_step(trainer, chain, batch["text_embeddings"], batch["latents"], batch["timestep"] / 1000, teacher, txt_ids, img_ids,
                                 guidance=guidance[: batch["latents"].shape[0]], temperature=args.temperature, optimizer_step=sync)
         step += 1
+        if not args.use_graph:
+            ops.streamk_poll()
         if sync:
             global_step += 1
-            losses.append(float(loss))
+            losses.append(float(loss))   # (synchronises: the marker reads enqueued above have completed)
+            # a chained stream-K segment that gave up leaves undefined gradients: stop before another update or a checkpoint is built on them
+            ops.streamk_check(sync=False)
             if rank == 0 or (groups is not None and rank == groups.train_ranks[0]):
                 print(f"step {global_step}: step_loss {losses[-1]:.4f} lr {trainer.lr:.3e} grad_norm {float(trainer.last_norm[1]):.4e}", flush=True)
                 if global_step % args.checkpointing_steps == 0:
+                    ops.streamk_check(sync=True)
                     print("saving model to", save_checkpoint(proj, args.output_dir, global_step), flush=True)
     run.last = dict(trainer=trainer, resume_step=resume_step, global_step=global_step)   # (introspection for tests)
     if groups is not None:

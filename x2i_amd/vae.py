@@ -163,6 +163,26 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
+def decode_flops(cfg, H, W):
+    """Algorithmic FLOPs of one `decode` of an [*, latent_channels, H, W] latent (2 * Cin * Cout * k^2 per output pixel of every
+    convolution, 2 M N K of the mid-block attention's linears and its two T x T products), un-padded channel counts."""
+    rev = list(reversed(cfg.block_out_channels))
+    conv = lambda ci, co, k, h, w: 2.0 * ci * co * k * k * h * w   # noqa: E731
+    res = lambda ci, co, h, w: conv(ci, co, 3, h, w) + conv(co, co, 3, h, w) + (conv(ci, co, 1, h, w) if ci != co else 0.0)   # noqa: E731
+    fl = conv(cfg.latent_channels, rev[0], 3, H, W)
+    c, T = rev[0], H * W
+    fl += 2 * res(c, c, H, W) + 4 * 2.0 * T * c * c + 2 * 2.0 * T * T * c
+    prev = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            fl += res(prev if j == 0 else co, co, H, W)
+        if i != len(rev) - 1:
+            H, W = 2 * H, 2 * W
+            fl += conv(co, co, 3, H, W)
+        prev = co
+    return fl + conv(rev[-1], cfg.out_channels, 3, H, W)
+
+
 class AutoencoderKL(nn.Module):
     """Decoder half of diffusers' AutoencoderKL with the FLUX configuration as defaults."""
 
