@@ -21,6 +21,9 @@ def main():
               (18432, 3072, 15360, "res"), (18432, 3072, 12288, "res"), (4608, 12288, 3072, "gelu"), (4608, 3072, 15360, "res")]
     if quick:
         shapes = shapes[:3]
+    if "--small" in sys.argv:   # the launches of a 512^2 batch-1 step (S = 1536 = 512 text + 1024 image rows) and of a 1024^2 batch-1 step
+        shapes = [(1536, 3072, 15360, "res"), (1536, 12288, 3072, "gelu"), (1536, 9216, 3072, "bias"), (1024, 3072, 12288, "res"), (512, 3072, 12288, "res"),
+                  (1536, 3072, 3072, "res"), (1024, 12288, 3072, "gelu"), (4608, 3072, 15360, "res"), (4608, 3072, 3072, "res"), (4608, 12288, 3072, "gelu")]
     for M, N, K, kind in shapes:
         A = torch.randn((M, K), device=DEV, generator=g).bfloat16()
         W = (torch.randn((N, K), device=DEV, generator=g) * 0.02).bfloat16()

@@ -44,7 +44,7 @@ X2IOptions make_options() {
   o.gemm_w4 = env_int("X2I_GEMM_W4", 1);
   o.gemm_persist = env_int("X2I_GEMM_PERSIST", 1);
   o.gemm_fp8_persist = env_int("X2I_GEMM_FP8_PERSIST", 1);
-  o.gemm_fx = env_int("X2I_GEMM_FX", 0);
+  o.gemm_fx = env_int("X2I_GEMM_FX", 2);
   o.gemm_r2 = env_int("X2I_GEMM_R2", 0);
   o.gemm_streamk = env_int("X2I_GEMM_STREAMK", 1);
   o.gemm_pair = env_int("X2I_GEMM_PAIR", 1);

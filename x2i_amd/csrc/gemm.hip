@@ -134,6 +134,9 @@ static bool fx_for(const x2i_gemm_args* a0, const x2i_gemm_args* a1, int cus, in
   const long long T1 = a1 ? (long long)((a1->M + BM2 - 1) / BM2) * ((a1->N + BN2 - 1) / BN2) : 0;
   const long long Ts = T0 + T1;
   if (Ts >= cus || Ts * 5 < cus) return false;                 // whole tiles fill the chip / too few tiles: more than five parts per tile
+  // gemm_fx = 2 (default): only items with at most HALF a round of tiles (a 512^2 sample: 72; measured x1.34-1.51 at batch 1, x0.81-0.96 at batch
+  // 2 / 4, profiles/r05g_*); a 1024^2 sample (216 tiles) keeps whole tiles, where the split measures x0.92-1.03.  Still by the item's shape alone.
+  if (opt.gemm_fx == 2 && Ts * 2 > cus) return false;
   // the split is per XCD (an XCD's cus / 8 workgroups share the K-tile space of the item tiles the tile order gives that XCD)
   if ((cus & 7) || (T0 & 7) || (T1 & 7)) return false;
   const int gx = cus >> 3;

@@ -350,6 +350,107 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
   });
 }
 
+// FX with every part parked ("A": a tile cut into P equal K ranges, one workgroup each, all at work at the same time): instead of ONE
+// finisher reading P - 1 slabs and running the whole epilogue while the others idle (measured on the single-block proj_out of a 512^2
+// batch-1 step: K-loops done at 84 us, launch done at 181 us -- tools/fx_timeline.py, profiles/r05f_*), EVERY part finishes the chunks
+// q = j, j + P, ... of each wave's 128 x 128 quadrant: it adds the P parked ranges of those chunks in slab order (p_0 + p_1 + ... : the
+// association the one-finisher form uses, bit-identical to it) and runs the gated-residual epilogue of epilogue_chunked_pipe on them
+// (same arithmetic, same staging image, same whole-line stores).  Chunk indices are run-time values here -- nothing is read from
+// the accumulator registers.
+__device__ __forceinline__ void epilogue_fx_slice(const GemmP& p, int z, int m_wave, int n_wave, int lane, char* stage, int slab0, int P, int j,
+                                                  int tid) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const int mlane = lane & 15, ng = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
+#ifdef X2I_ABLATION
+  if (p.act2 >= 80) b2 = nullptr;
+#endif
+  const float* gz = p.gate ? p.gate + (long long)z * p.gate_bs : nullptr;
+  __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)z * p.r_bs), 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
+  const uint32_t c_bytes = (uint32_t)(((long long)(p.M - 1) * p.ldc + p.N) * 2);
+  __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.C + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
+  const float* sbase = p.sk_slabs + (long long)slab0 * (SK_SLAB_BYTES / 4) + tid * 4;
+  for (int q = j; q < 8; q += P) {
+    const int h = q >> 2, c = q & 3;
+    // bias / gate of this lane's 4 columns per 16-column block of the chunk's column half
+    float bv[4][4], gv[4][4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int n = n_wave + h * 64 + jj * 16 + ng * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[jj][r] = 0.f, gv[jj][r] = 1.f;
+      if (n + 3 < p.N) {
+        if (p.bias) {
+          const uint2 bb = *(const uint2*)(p.bias + n);
+          bv[jj][0] = __uint_as_float(bb.x << 16); bv[jj][1] = __uint_as_float(bb.x & 0xffff0000u);
+          bv[jj][2] = __uint_as_float(bb.y << 16); bv[jj][3] = __uint_as_float(bb.y & 0xffff0000u);
+        }
+        if (gz) {
+          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
+          gv[jj][0] = g4[0]; gv[jj][1] = g4[1]; gv[jj][2] = g4[2]; gv[jj][3] = g4[3];
+        }
+        if (b2) {
+          const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
+          bv[jj][0] += t4[0]; bv[jj][1] += t4[1]; bv[jj][2] += t4[2]; bv[jj][3] += t4[3];
+        }
+      }
+    }
+    u32x2 rres[2][4];
+    const uint32_t rsoff = (uint32_t)(((long long)c * 32 * p.ldr + h * 64) * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        rres[i][jj] = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, (uint32_t)(((long long)(m_wave + i * 16 + mlane) * p.ldr + n_wave + ng * 4) * 2) + jj * 32, rsoff, 0);
+    // the P parked ranges of the chunk's eight accumulator tiles, summed in slab order (two slabs in flight)
+    f32x4_t sum[2][4];
+    for (int u = 0; u < P; ++u) {
+      const float* su = sbase + (long long)u * 8 * (SK_SLAB_BYTES / 4);
+      f32x4_t v[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v[i][jj] = *(const f32x4_t*)(su + ((2 * c + i) * 8 + 4 * h + jj) * 1024);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) sum[i][jj] = u ? sum[i][jj] + v[i][jj] : v[i][jj];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 16 + mlane;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sum[i][jj][r] + bv[jj][r];
+        const u32x2 r2 = rres[i][jj];
+        v[0] = fmaf(gv[jj][0], v[0], __uint_as_float(r2[0] << 16));
+        v[1] = fmaf(gv[jj][1], v[1], __uint_as_float(r2[0] & 0xffff0000u));
+        v[2] = fmaf(gv[jj][2], v[2], __uint_as_float(r2[1] << 16));
+        v[3] = fmaf(gv[jj][3], v[3], __uint_as_float(r2[1] & 0xffff0000u));
+        char* slot = stage + row * 128 + ((((jj << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
+        *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    u32x4 d[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) d[it] = *(const u32x4*)(stage + it * 1024 + lane * 16);
+    const uint32_t soff = (uint32_t)((long long)c * 32 * p.ldc * 2);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + srow;
+      const int n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
+      const uint32_t vo = (n + 7 < p.N) ? (uint32_t)(((long long)(m_wave + row) * p.ldc + n) * 2) : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(d[it], c_rsrc, vo, soff, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging buffer is rewritten by the next chunk)
+  }
+}
+
 // Fused QKV epilogue of one wave (x2i_gemm_qkv_bf16: q / k RMSNorm + RoPE + head split, V transposed) on the persistent kernel's
 // 8 KiB of private staging.  A wave's 128 x 128 outputs are 128 tokens of exactly ONE head of the q, k or v section (tile columns
 // never straddle a section; checked by the launcher).  Same arithmetic and rounding points as qkv_park / qkv_finish (gemm_device.h):
@@ -658,7 +759,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
   };
   // ---- FX: what this workgroup does for ONE batch item (the same for every item): fx_cnt units, unit u = K-tiles [fx_k0, fx_k0 + fx_len) of
   // the XCD's tile fx_t0 + u * fx_tstep of problem fx_sel; fx_kind 1 = park the sums (P), 2 = finish the tile (F: add fx_npre parked parts)
-  int fx_sel = 0, fx_Tp = 0, fx_nbz = 0, fx_kind = 0, fx_cnt = 0, fx_t0 = 0, fx_tstep = 1, fx_k0 = 0, fx_len = 0, fx_npre = 0, fx_modeB = 0, fx_slab_base = 0;
+  int fx_sel = 0, fx_Tp = 0, fx_nbz = 0, fx_kind = 0, fx_cnt = 0, fx_t0 = 0, fx_tstep = 1, fx_k0 = 0, fx_len = 0, fx_npre = 0, fx_modeB = 0, fx_slab_base = 0, fx_part = 0;
   const int fx_x = w & 7;
   if constexpr (FX) {
     // Per XCD: workgroup w runs on XCD w & 7 (round-robin dispatch) and the tile order gives that XCD the tiles bid = 8 t + (w & 7) of an
@@ -698,8 +799,9 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
       const int j = li < cutw ? li - t * (base + 1) : (li - cutw) - (t - extra) * base;
       const int k_lo = (int)((long long)nk * j / P), k_hi = (int)((long long)nk * (j + 1) / P);
       fx_cnt = 1; fx_t0 = t; fx_k0 = k_lo; fx_len = k_hi - k_lo;
-      fx_kind = j == P - 1 ? 2 : 1;
+      fx_kind = P > 1 ? 3 : 2;      // 3: every part parks its range and finishes the chunks j, j + P, ... (epilogue_fx_slice); one part: a whole tile
       fx_npre = P - 1;
+      fx_part = j;
     }
   }
   // ---- this workgroup's unit list: S whole tiles (vb = w + s*G) and, with stream-K, up to two segments of the last round's tiles
@@ -745,7 +847,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
       u.len = fx_len;
       // P: the slab this range is parked in -- "B": the tile's (a tail workgroup parks several per item), "A": the workgroup's;
       // F: the first of the fx_npre slabs to add (they are 8 apart in "A": the XCD's workgroups)
-      u.slab = fx_modeB ? fx_slab_base + tile : (fx_kind == 1 ? w : w - 8 * fx_npre);
+      u.slab = fx_modeB ? fx_slab_base + tile : (fx_kind == 1 ? w : (fx_kind == 3 ? w - 8 * fx_part : w - 8 * fx_npre));   // (kind 3: the tile's FIRST slab; this part's own is w)
       u.kind = fx_kind;
       u.tag = zi + 1;
       return Unit{uni(u.vb), uni(u.k0), uni(u.len), uni(u.slab), uni(u.kind), uni(u.tag)};
@@ -887,7 +989,47 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
       }
     };
     if constexpr (FX) {
-      if (cur.kind == 1) {
+      if (cur.kind == 3) {
+        // every part of the tile: park this range (own slab = w: free, see the last step), publish, wait for the other parts, finish
+        // the own chunks, tell every slab's owner, and take the own slab back once all P parts have read it
+        const int P = fx_npre + 1;
+        __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(w);
+        asm volatile(X2I_GEMM256P_STORE_PARTIAL
+                     : [so] "=&s"(s_so)
+                     : X2I_GEMM256P_OPS_ACC_IN(acc), [vo] "v"(slab_vo), [rs] "s"(s_rsrc)
+                     : "memory", "scc");
+        __syncthreads();
+        if (tid == 0) {
+          __hip_atomic_store(p.sk_flags + w, (unsigned)cur.tag << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int q = 0; q < P; ++q) {   // (bounded, like every wait here: a lost partner leaves a marker instead of a hung GPU)
+            int spins = 0;
+            while ((__hip_atomic_load(p.sk_flags + cur.slab + 8 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) != (unsigned)cur.tag) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > (1 << 22)) {
+                __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        epilogue_fx_slice(prob(pp, sel), z, m0 + wm * 128, n0 + wn * 128, lane, stage, cur.slab, P, fx_part, tid);
+        __syncthreads();   // every wave has read the slabs
+        if (tid == 0) {
+          for (int q = 0; q < P; ++q) __hip_atomic_fetch_add(p.sk_flags + cur.slab + 8 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((__hip_atomic_load(p.sk_flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) != (unsigned)P) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) {
+              __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          __hip_atomic_store(p.sk_flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the slab is this workgroup's again
+        }
+        __syncthreads();
+      } else if (cur.kind == 1) {
         // park this range's sums; the slab is free once the finisher of the previous item's tile has reset its flag
         if (tid == 0) spin_until(p.sk_flags + cur.slab, 0u);
         __syncthreads();
