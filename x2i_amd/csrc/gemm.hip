@@ -346,7 +346,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       if (rc) return rc;
     }
     int tm_main = tm_all;
-    // (re-measured in round 2, tools/tail_probe.py: peeling pays up to a 3/8-full last round at any depth, and for a half-full one
+    // (re-measured in round 2 with a sweep of last-round fill levels: peeling pays up to a 3/8-full last round at any depth, and for a half-full one
     // only behind >= 8 full rounds; a fuller last round is faster left in the one launch.  Either way the results are bit-identical.)
     if (!sk && force == 0 && !conv && full_rounds >= 1 && rem > 0 && (rem <= 96 || (rem <= 128 && full_rounds >= 8)) && opt.gemm_split_tail) {
       const long long tm_fit = (full_rounds * 256) / per_row;
