@@ -2,9 +2,11 @@
 """Interactive multi-turn Qwen2.5-VL -> image loop on the HIP path.  Counterpart of infer/inference_multi_turn.py: the
 chat history grows each turn, the model answers with max_new_tokens=64, and the conditioning is the prompt-pass hidden
 states concatenated along S with the generated-token hidden states (:132-141); 4 steps, 1024x1024, manual_seed(0)."""
+import time
+
 import torch
 
-from .harness import Harness, build_parser, stack_hidden_states
+from .harness import Harness, SyntheticConditioner, build_parser, stack_hidden_states
 
 
 class MultiTurnConditioner:
@@ -37,11 +39,34 @@ class MultiTurnConditioner:
         return prompt_hs, answer
 
 
+def synthetic_turns(args, kind, device):
+    """--synthetic: no checkpoints; the conversation is a list of text lengths (--turn_lengths, default: a history that grows by 37 tokens
+    per turn, then the first two lengths again) and every turn prints its sampling latency -- a NEW length runs the eager launch sequence
+    once (FluxPipeline's graph policy: no discarded warm-up pass), a length that comes back is captured and from then on replayed."""
+    lengths = [int(x) for x in args.turn_lengths.split(",")] if args.turn_lengths else [96 + 37 * t for t in range(4)] + [96, 133, 96, 133]
+    cond = SyntheticConditioner(kind, device)
+    h = Harness(args, kind, cond, device)
+    for turn, S in enumerate(lengths):
+        cond.seq_len = S
+        pooled, embeds = h.embeds(text_prompt="turn %d" % turn)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h.generate(pooled, embeds, "multi_turn", "turn_%d" % turn, seed=0)
+        torch.cuda.synchronize()
+        st = h.pipeline.graph_stats
+        print("turn %d: S_txt %4d  sampling %8.1f ms   (pipeline so far: %d eager, %d captures, %d replays)"
+              % (turn, S, (time.perf_counter() - t0) * 1e3, st["eager"], st["captures"], st["replays"]), flush=True)
+
+
 def main(argv=None):
-    args = build_parser("qwenvl").parse_args(argv)
+    ap = build_parser("qwenvl")
+    ap.add_argument("--turn_lengths", type=str, default=None, help="with --synthetic: comma-separated text lengths of the turns")
+    args = ap.parse_args(argv)
     kind = "qwen" + args.qwen_size
     device = "cuda:0"
     torch.cuda.set_device(device)
+    if args.synthetic:
+        return synthetic_turns(args, kind, device)
     cond = MultiTurnConditioner(args.qwen_path, device)
     h = Harness(args, kind, lambda **kw: cond(**kw)[0], device)
     turn = 0
