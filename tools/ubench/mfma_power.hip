@@ -33,10 +33,10 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ data, float* 
   if (out && threadIdx.x == 9999) out[0] = 1.f;
 }
 template <int VAR>
-void run(const char* name, const uint4* d, int iters) {
+void run(const char* name, const uint4* d, int iters, int reps = 3) {
   hipEvent_t s, e;
   hipEventCreate(&s); hipEventCreate(&e);
-  for (int rep = 0; rep < 3; ++rep) {
+  for (int rep = 0; rep < reps; ++rep) {
     hipEventRecord(s);
     hipLaunchKernelGGL(k<VAR>, dim3(256), dim3(256), 0, 0, d, nullptr, iters);
     hipEventRecord(e);
@@ -62,8 +62,9 @@ int main(int argc, char** argv) {
   hipMalloc(&d, n * 2);
   hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice);
   const int iters = 400000;  // ~ 0.3 s per launch at 2 PF
-  run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters);
-  run<1>(zero ? "16x16x32 zeros" : "16x16x32 random", d, iters);
-  run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters);
+  const int reps = argc > 2 ? atoi(argv[2]) : 3;   // (round 5: e.g. 20 launches = ~6 s per shape, long enough for the power management to settle)
+  run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters, reps);
+  run<1>(zero ? "16x16x32 zeros" : "16x16x32 random", d, iters, reps);
+  run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters, reps);
   return 0;
 }
