@@ -203,6 +203,10 @@ def gemm_roofline(B, rounds=6, per_round=8):
                 probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", statistic="median round (frac), fastest (frac_best)",
                            us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times], clock_power=power),
                 measured="live (HIP events on the launch stream, this run)",
+                matrix_pipe_alone=dict(achieved=1941.0, frac_of_peak=0.776, unit="TFLOP/s", measured="committed profile (builder's box, not this run)",
+                                       source="profiles/r05o_mfma_power_sustained_fixed_ubench.log",
+                                       note="v_mfma_f32_16x16x32_bf16 on random operands held in registers, no memory traffic, sustained: what the power "
+                                            "management lets the matrix pipe do on this part (2.05 GHz at 1.25 kW); zeros run at the full 2.4 GHz"),
                 in_step=_in_step_gemm_rate(B),
                 traffic=traffic, traffic_measured="committed PMC profile (builder's box, not this run)" if traffic is not None else None,
                 traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_kernel (bf16 instantiations)",
