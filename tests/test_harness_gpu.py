@@ -61,3 +61,23 @@ def test_real_prompt_batches_match_one_prompt_at_a_time(tmp_path):
                              width=256, output_type="latent", latents=noise[i:i + 1]).images
             got = torch.load(os.path.join(str(tmp_path), "text2image", "%s_0_latents.pt" % k))
             assert torch.equal(got, one.cpu()), k
+
+
+def test_multi_turn_synthetic_lengths_and_graph_policy(tmp_path, capsys):
+    """infer/inference_multi_turn.py:132-156: the text length grows with the conversation.  --synthetic walks a list of lengths; a new length
+    costs ONE eager pass, a returning one is captured once and replayed afterwards (the pipeline's graph statistics are printed per turn),
+    and a repeated turn (same length, same seed-0 noise, same synthetic conditioning call index aside) writes finite latents."""
+    from x2i_amd.infer import inference_multi_turn
+    inference_multi_turn.main(["--synthetic", "--qwen_size", "3b", "--height", "256", "--width", "256", "--num_steps", "2",
+                               "--turn_lengths", "48,80,48,48,80", "--outputs", str(tmp_path)])
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("turn ")]
+    assert len(out) == 5
+    assert "2 eager, 0 captures, 0 replays" in out[1]      # two new lengths: two eager passes
+    assert "2 eager, 1 captures, 1 replays" in out[2]      # 48 comes back: captured, replayed
+    assert "2 eager, 1 captures, 2 replays" in out[3]      # ... replay only
+    assert "2 eager, 2 captures, 3 replays" in out[4]      # 80 comes back
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "multi_turn", "turn_*_latents.pt")))
+    assert len(files) == 5
+    for f in files:
+        lat = torch.load(f)
+        assert lat.shape == (1, 256, 64) and torch.isfinite(lat.float()).all()
