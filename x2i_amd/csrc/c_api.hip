@@ -99,7 +99,7 @@ int x2i_num_cus() {
 bool x2i_streamk_workspace(const x2i_gemm_args* a, float** slabs, unsigned** flags, int* rc) {
   *rc = X2I_OK;
   if (!a->workspace) return false;
-  const long long need = 4096 + (long long)x2i_gemm_sk_max_tiles() * x2i_gemm_sk_slab_bytes();
+  const long long need = 4096 + (long long)x2i_gemm_sk_slabs() * x2i_gemm_sk_slab_bytes();
   if (a->workspace_bytes < need || (((uintptr_t)a->workspace) & 255)) {
     *rc = x2i_set_error(X2I_ERR_ARG, "gemm: stream-K workspace must be 256-byte aligned and >= x2i_streamk_workspace_bytes() = %lld bytes (got %lld)",
                         need, (long long)a->workspace_bytes);
@@ -179,7 +179,7 @@ int x2i_get_option(const char* name, int64_t* value) {
   return X2I_OK;
 }
 
-int64_t x2i_streamk_workspace_bytes(void) { return 4096 + (int64_t)x2i_gemm_sk_max_tiles() * x2i_gemm_sk_slab_bytes(); }
+int64_t x2i_streamk_workspace_bytes(void) { return 4096 + (int64_t)x2i_gemm_sk_slabs() * x2i_gemm_sk_slab_bytes(); }
 
 int x2i_streamk_workspace_status(const void* workspace, int64_t workspace_bytes) {
   if (!workspace || workspace_bytes < x2i_streamk_workspace_bytes()) return x2i_set_error(X2I_ERR_ARG, "streamk_workspace_status: no / too small workspace");

@@ -46,6 +46,7 @@ constexpr double NAIVE_MAX_FLOP = 5.0e10;
 }  // namespace
 
 int x2i_gemm_sk_max_tiles() { return SK_MAX_TILES; }
+int x2i_gemm_sk_slabs() { return SK_SLABS; }
 long long x2i_gemm_sk_slab_bytes() { return SK_SLAB_BYTES; }
 
 static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream);

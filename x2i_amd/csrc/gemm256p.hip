@@ -891,6 +891,38 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(27);
   }
 #endif
+  // ---- FX, every part parks (kind 3): flags and the deferred slice (see the unit loop)
+  auto fx_flag = [&](int buf, int slab) { return p.sk_flags + buf * 512 + slab; };
+  auto fx_spin = [&](unsigned* f, unsigned want, unsigned shift, unsigned mask) {   // (thread 0) bounded: a lost partner leaves a marker, not a hung GPU
+    int spins = 0;
+    while (((__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> shift) & mask) != want) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 22)) {
+        __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  };
+  auto fx_reclaim = [&](int buf) {   // this workgroup's slab of buffer `buf` is free once all P parts have read it
+    if (tid == 0) {
+      fx_spin(fx_flag(buf, w), (unsigned)(fx_npre + 1), 0u, 0xffu);
+      __hip_atomic_store(fx_flag(buf, w), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  };
+  auto fx_slice_of = [&](int usel, int uz, int um0, int un0, int uslab0, int utag, int buf) {
+    const int P = fx_npre + 1;
+    if (tid == 0) {
+      for (int q = 0; q < P; ++q) fx_spin(fx_flag(buf, uslab0 + 8 * q), (unsigned)utag, 8u, 0xffffffu);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    epilogue_fx_slice(prob(pp, usel), uz, um0 + wm * 128, un0 + wn * 128, lane, stage, uslab0 + 256 * buf, P, fx_part, tid);
+    __syncthreads();   // every wave has read the slabs
+    if (tid == 0)
+      for (int q = 0; q < P; ++q) __hip_atomic_fetch_add(fx_flag(buf, uslab0 + 8 * q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  int pend_valid = 0, pend_sel = 0, pend_z = 0, pend_m0 = 0, pend_n0 = 0, pend_slab0 = 0, pend_tag = 0;
   Unit cur = unit(0);
   int sel, z, m0, n0;
   tile_of(cur.vb, sel, z, m0, n0);
@@ -990,45 +1022,21 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
     };
     if constexpr (FX) {
       if (cur.kind == 3) {
-        // every part of the tile: park this range (own slab = w: free, see the last step), publish, wait for the other parts, finish
-        // the own chunks, tell every slab's owner, and take the own slab back once all P parts have read it
-        const int P = fx_npre + 1;
-        __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(w);
+        // every part of the tile parks its range and finishes a slice (epilogue_fx_slice).  The slabs are DOUBLE-BUFFERED by the unit's parity
+        // (slab w + 256 b, flags 512 b + slab), so a workgroup parks item u, goes straight into item u + 1's K-loop (already prefetched by
+        // the seamless loop) and finishes its slice of item u behind it, when every other part has long been parked: only the last item of
+        // a launch pays the park -> wait -> slice tail (round 5: batches of 2 / 4 512^2 samples lost 3-20 % per launch to that tail)
+        const int buf = ui & 1;
+        if (ui >= 2) fx_reclaim(buf);          // the slab's last use was unit ui - 2: all P parts have read it by now
+        __amdgpu_buffer_rsrc_t s_rsrc = slab_rsrc(w + 256 * buf);
         asm volatile(X2I_GEMM256P_STORE_PARTIAL
                      : [so] "=&s"(s_so)
                      : X2I_GEMM256P_OPS_ACC_IN(acc), [vo] "v"(slab_vo), [rs] "s"(s_rsrc)
                      : "memory", "scc");
         __syncthreads();
-        if (tid == 0) {
-          __hip_atomic_store(p.sk_flags + w, (unsigned)cur.tag << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int q = 0; q < P; ++q) {   // (bounded, like every wait here: a lost partner leaves a marker instead of a hung GPU)
-            int spins = 0;
-            while ((__hip_atomic_load(p.sk_flags + cur.slab + 8 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 8) != (unsigned)cur.tag) {
-              __builtin_amdgcn_s_sleep(8);
-              if (++spins > (1 << 22)) {
-                __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        epilogue_fx_slice(prob(pp, sel), z, m0 + wm * 128, n0 + wn * 128, lane, stage, cur.slab, P, fx_part, tid);
-        __syncthreads();   // every wave has read the slabs
-        if (tid == 0) {
-          for (int q = 0; q < P; ++q) __hip_atomic_fetch_add(p.sk_flags + cur.slab + 8 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int spins = 0;
-          while ((__hip_atomic_load(p.sk_flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffu) != (unsigned)P) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 22)) {
-              __hip_atomic_store(p.sk_flags + SK_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
-          }
-          __hip_atomic_store(p.sk_flags + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the slab is this workgroup's again
-        }
-        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fx_flag(buf, w), (unsigned)cur.tag << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pend_valid) fx_slice_of(pend_sel, pend_z, pend_m0, pend_n0, pend_slab0, pend_tag, buf ^ 1);
+        pend_valid = 1; pend_sel = sel; pend_z = z; pend_m0 = m0; pend_n0 = n0; pend_slab0 = cur.slab; pend_tag = cur.tag;
       } else if (cur.kind == 1) {
         // park this range's sums; the slab is free once the finisher of the previous item's tile has reset its flag
         if (tid == 0) spin_until(p.sk_flags + cur.slab, 0u);
@@ -1087,6 +1095,14 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
 
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) va[jj] = na[jj], vw[jj] = nw[jj];
+  }
+  if constexpr (FX) {
+    if (pend_valid) {   // the last item's slice, then both buffers' slabs back (flags return to zero: the workspace invariant between launches)
+      const int last = (n_units - 1) & 1;
+      fx_slice_of(pend_sel, pend_z, pend_m0, pend_n0, pend_slab0, pend_tag, last);
+      if (n_units >= 2) fx_reclaim(last ^ 1);
+      fx_reclaim(last);
+    }
   }
   asm volatile(X2I_GEMM256P_DRAIN ::: "memory");   // (the e4m3 loop's drain is the same two instructions)
 }

@@ -52,6 +52,7 @@ struct GemmP2 { GemmP p[2]; };                  // grouped launch of the persist
 constexpr int SK_MAX_TILES = 256;               // split tiles per launch (< number of CUs)
 constexpr int SK_ERR_SLOT = SK_MAX_TILES;       // sk_flags[SK_ERR_SLOT] != 0: a segment gave up waiting for its predecessor
 constexpr long long SK_SLAB_BYTES = 256LL * 256 * 4;
+constexpr int SK_SLABS = 2 * SK_MAX_TILES;      // slabs in a workspace: the parallel split (FX) double-buffers its parked partial sums (flags of buffer b at 512 b)
 
 // Row m of a QKV GEMM -> (sample b, position st in the joint sequence) without a division per row: the division happens ONCE for a
 // uniform base row; rows behind it wrap by subtraction (at most once when a sample has at least as many rows as the span, 256).  (The per-row `mg / rows_per_sample` of the first form was most of the fused epilogue's instruction count.)

@@ -52,7 +52,7 @@ _SK_EAGER_MAX = 8
 
 
 class StreamKWorkspace:
-    """64 MB + 4 KiB of device memory, zero flags; `poll()` enqueues an asynchronous read of the give-up marker, `check()` raises
+    """128 MB + 4 KiB of device memory (x2i_streamk_workspace_bytes), zero flags; `poll()` enqueues an asynchronous read of the give-up marker, `check()` raises
     X2IError when a completed read (or, with sync=True, a synchronising one) shows it set."""
 
     def __init__(self, device=None):
