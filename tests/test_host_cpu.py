@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     ver = int(re.search(r"#define X2I_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 3   # header, library and binding move together
-    assert lib.x2i_streamk_workspace_bytes() == 4096 + 256 * 256 * 1024   # the caller-owned stream-K workspace: flags + 256 slabs of 256 KiB
+    assert lib.x2i_streamk_workspace_bytes() == 4096 + 512 * 256 * 1024   # the caller-owned workspace: flags + 512 slabs of 256 KiB (round 5: the K split double-buffers)
 
 
 def test_options_are_resolved_once_and_product_library_has_no_ablation_kernels():
