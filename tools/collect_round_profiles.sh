@@ -41,6 +41,10 @@ python tools/fp8_bench.py > "$OUT/${TAG}_fp8_bench.log" 2>&1
 python tools/conv_bench.py 4 > "$OUT/${TAG}_conv_bench.log" 2>&1
 python tools/attn_bench.py 4 > "$OUT/${TAG}_attn_bench.log" 2>&1
 timeout 600 python tools/train_bench.py 1 2 > "$OUT/${TAG}_train_bench.log" 2>&1
+python tools/fx_bench.py > "$OUT/${TAG}_fx_bench.log" 2>&1
+python tools/gemm_r2_probe.py --quick > "$OUT/${TAG}_gemm_r2_probe.log" 2>&1
+bash tools/attn_clock_pmc.sh "$OUT/attn_clock" > /dev/null 2>&1; cp "$OUT/attn_clock/attn_clock.json" "$OUT/${TAG}_attn_clock_alone_vs_in_sequence.json" 2>/dev/null; rm -rf "$OUT/attn_clock/alone" "$OUT/attn_clock/seq"
+[ -x tools/ubench/bin/mfma_power ] && bash tools/clock_watch.sh "$OUT/${TAG}_mfma_power_clock.log" -- tools/ubench/bin/mfma_power 1 8 > "$OUT/${TAG}_mfma_power.log" 2>&1
 cd /tmp
 run_stats bench_b4_1024_fp8 python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dtype fp8 --no-roofline
 run_stats bench_config5 python "$R/bench.py" --config 5 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
