@@ -33,6 +33,14 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ data, float* 
 #define M(i) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"i"(16 * i), "i"(16 * i + 15), "i"(32 + 4 * i), "i"(35 + 4 * i), "i"(64 + 4 * i), "i"(67 + 4 * i));
       REP8(M) REP8(M) REP8(M) REP8(M)
 #undef M
+    } else if (VAR == 3 || VAR == 4) {
+      // 16x16x32 with ONE operand held for eight consecutive MFMAs (the GEMM K-loop's pattern: an A fragment against eight W fragments):
+      // 3 = the first source operand held, the second rotating; 4 = the other way round.  Same FLOPs per iteration as VAR 1.
+#define M(i) \
+      if (VAR == 3) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], v[32:35], v[%c2:%c3], a[%c0:%c1]\n v_mfma_f32_16x16x32_bf16 a[%c4:%c5], v[32:35], v[%c6:%c7], a[%c4:%c5]" ::"i"(8 * i), "i"(8 * i + 3), "i"(64 + 4 * i), "i"(67 + 4 * i), "i"(8 * i + 4), "i"(8 * i + 7), "i"(64 + 4 * ((i + 4) & 7)), "i"(67 + 4 * ((i + 4) & 7))); \
+      else asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], v[%c2:%c3], v[32:35], a[%c0:%c1]\n v_mfma_f32_16x16x32_bf16 a[%c4:%c5], v[%c6:%c7], v[32:35], a[%c4:%c5]" ::"i"(8 * i), "i"(8 * i + 3), "i"(64 + 4 * i), "i"(67 + 4 * i), "i"(8 * i + 4), "i"(8 * i + 7), "i"(64 + 4 * ((i + 4) & 7)), "i"(67 + 4 * ((i + 4) & 7)));
+      REP8(M) REP8(M) REP8(M) REP8(M)
+#undef M
     } else if (VAR == 2) {  // e4m3, 16x16x128 (8 registers per operand: fragment pairs i and i ^ 1 together), 4 x the FLOPs of a bf16 16x16x32
 #define M(i) asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]\n v_mfma_f32_16x16x128_f8f6f4 a[%c6:%c7], v[%c4:%c5], v[%c2:%c3], a[%c6:%c7]" ::"i"(8 * i), "i"(8 * i + 3), "i"(32 + 8 * (i >> 1)), "i"(39 + 8 * (i >> 1)), "i"(64 + 8 * (i >> 1)), "i"(71 + 8 * (i >> 1)), "i"(8 * i + 4), "i"(8 * i + 7));
       REP8(M) REP8(M) REP8(M) REP8(M)
@@ -80,6 +88,8 @@ int main(int argc, char** argv) {
   run<2>(zero ? "e4m3 16x16x128 zeros" : "e4m3 16x16x128 random", d, iters / 2, reps, 4.0);
   run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters, reps);
   run<1>(zero ? "16x16x32 zeros" : "16x16x32 random", d, iters, reps);
+  run<3>("16x16x32, first operand held x8", d, iters, reps);
+  run<4>("16x16x32, second operand held x8", d, iters, reps);
   run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters, reps);
   return 0;
 }
