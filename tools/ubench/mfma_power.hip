@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ data, float* 
   // (round 5) the hard-coded registers must be part of the kernel's register allocation: without this clobber list the kernel descriptor asked
   // for a handful of VGPRs and no accumulator registers, the MFMAs addressed registers the wave did not own (reads of zero, writes dropped), and
   // the run drew 370 W at "2.46 PFLOP/s" whatever the data -- the round-3 figure quoted from this file was that artefact
-  asm volatile("" ::: "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+  asm volatile("" ::: "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
   const uint4* p = data + (size_t)(blockIdx.x * 256 + threadIdx.x) * 16;
 #define LD(i) asm volatile("global_load_dwordx4 v[%c0:%c1], %2, off offset:%c3" ::"i"(32 + 4 * i), "i"(35 + 4 * i), "v"(p), "i"(16 * i) : "memory");
   REP8(LD)
@@ -29,7 +29,19 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ data, float* 
   REP8(Z)
 #undef Z
   for (int it = 0; it < iters; ++it) {
-    if (VAR == 0) {  // 32x32x16: 8 accumulators of 16 registers, operands rotate over the 8 fragment pairs
+    if (VAR == 6) {  // attention-like mix on 32x32x16: per MFMA (one operand held) one v_exp_f32, one v_add_f32, one v_cvt_pk / v_max3, one v_mov
+#define M(i) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[32:35], v[%c2:%c3], a[%c0:%c1]\n v_exp_f32 v%c4, v%c5\n v_add_f32 v%c6, v%c5, v%c6\n v_max3_f32 v%c7, v%c5, v%c4, v%c7\n v_cvt_pk_bf16_f32 v%c8, v%c4, v%c5" ::"i"(16 * i), "i"(16 * i + 15), "i"(64 + 4 * i), "i"(67 + 4 * i), "i"(96 + i), "i"(104 + i), "i"(112 + i), "i"(120 + i), "i"(124 + (i & 3)));
+      REP8(M) REP8(M) REP8(M) REP8(M)
+#undef M
+    } else if (VAR == 7) {  // the same vector work per FLOP on 16x16x32: two MFMAs carry what one 32x32x16 carried (2 VALU instructions each)
+#define M(i) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], v[32:35], v[%c2:%c3], a[%c0:%c1]\n v_exp_f32 v%c4, v%c5\n v_add_f32 v%c6, v%c5, v%c6\n v_mfma_f32_16x16x32_bf16 a[%c9:%c10], v[32:35], v[%c11:%c12], a[%c9:%c10]\n v_max3_f32 v%c7, v%c5, v%c4, v%c7\n v_cvt_pk_bf16_f32 v%c8, v%c4, v%c5" ::"i"(8 * i), "i"(8 * i + 3), "i"(64 + 4 * i), "i"(67 + 4 * i), "i"(96 + i), "i"(104 + i), "i"(112 + i), "i"(120 + i), "i"(124 + (i & 3)), "i"(8 * i + 4), "i"(8 * i + 7), "i"(64 + 4 * ((i + 4) & 7)), "i"(67 + 4 * ((i + 4) & 7)));
+      REP8(M) REP8(M) REP8(M) REP8(M)
+#undef M
+    } else if (VAR == 5) {  // 32x32x16 with the first source operand held for eight MFMAs (attention's S^T = K Q^T: the Q fragment stays)
+#define M(i) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[32:35], v[%c2:%c3], a[%c0:%c1]" ::"i"(16 * i), "i"(16 * i + 15), "i"(64 + 4 * i), "i"(67 + 4 * i));
+      REP8(M) REP8(M) REP8(M) REP8(M)
+#undef M
+    } else if (VAR == 0) {  // 32x32x16: 8 accumulators of 16 registers, operands rotate over the 8 fragment pairs
 #define M(i) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"i"(16 * i), "i"(16 * i + 15), "i"(32 + 4 * i), "i"(35 + 4 * i), "i"(64 + 4 * i), "i"(67 + 4 * i));
       REP8(M) REP8(M) REP8(M) REP8(M)
 #undef M
@@ -88,6 +100,9 @@ int main(int argc, char** argv) {
   run<2>(zero ? "e4m3 16x16x128 zeros" : "e4m3 16x16x128 random", d, iters / 2, reps, 4.0);
   run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters, reps);
   run<1>(zero ? "16x16x32 zeros" : "16x16x32 random", d, iters, reps);
+  run<5>("32x32x16, first operand held x8", d, iters, reps);
+  run<6>("32x32x16 held + 4 VALU / MFMA", d, iters, reps);
+  run<7>("16x16x32 held + 2 VALU / MFMA", d, iters, reps);
   run<3>("16x16x32, first operand held x8", d, iters, reps);
   run<4>("16x16x32, second operand held x8", d, iters, reps);
   run<0>(zero ? "32x32x16 zeros" : "32x32x16 random", d, iters, reps);
