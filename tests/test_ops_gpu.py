@@ -184,11 +184,12 @@ def test_attention_forced_rescale_branch(ops):
     assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("B,H,S,S0", [(1, 1, 64, 0), (2, 2, 136, 40), (1, 2, 1152, 128), (1, 3, 700, 100), (2, 1, 2000, 0)])
 def test_attention_kernel_forms(ops, opt, variant, B, H, S, S0):
     """attn_variant 4 = the 4-wave kernel, 5 / 6 = the 8-wave ping-pong kernel (attention_pp.hip) with / without defer-max, 9 = the
-    hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip: 1, 2, 3, 11, 18 and 32 key tiles, ragged last tiles), on
+    hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip: 1, 2, 3, 11, 18 and 32 key tiles, ragged last tiles), 10 = the A/B kernel on
+    16 x 16 x 32 MFMAs (attention16.hip), on
     ragged sequence lengths (S % 64 != 0, S % 256 != 0, fewer rows than one 256-row workgroup) and with the forced-rescale spike."""
     opt("attn_variant", variant)
     assert _attention_case(ops, B, H, S, S0, 200 + S) < 1e-2

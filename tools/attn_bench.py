@@ -29,10 +29,22 @@ def main():
     Q, K_, VT = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16)
     names = {4: "4-wave", 5: "ping-pong", 7: "ping-pong, DMA in vector phase", 8: "ping-pong, 4-deep rings + fragment prefetch",
-             9: "hand-scheduled, one wave per SIMD (attention_w4.hip)"}
-    for var in (9, 8, 4, 9, 8, 9):
+             9: "hand-scheduled, one wave per SIMD (attention_w4.hip)", 10: "4-wave organisation on 16x16x32 MFMAs (attention16.hip, A/B)"}
+    ref = None
+    perm = torch.tensor([16 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3) for kk in range(32)], device="cuda")
+    VTP = VT.view(B, H, 128, Spad // 32, 32)[..., perm].reshape(B, H, 128, Spad).contiguous()   # variant 11: keys permuted within 32-key spans
+    names[11] = "... with V^T pre-permuted (one 16-byte fragment read)"
+    for var in (4, 10, 11):   # the 16x16x32 A/B kernel against its 32x32x16 partner: same values up to rounding?
         _lib.set_option("attn_variant", var)
-        t = timeit(lambda: ops.attention(Q, K_, VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
+        ops.attention(Q, K_, VTP if var == 11 else VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128))
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = O.float().clone()
+        else:
+            print(f"variant {var} vs variant 4: rel-L2 {float((O.float() - ref).norm() / ref.norm()):.3e}")
+    for var in (9, 8, 4, 10, 11, 9, 8, 4, 10, 11, 9):
+        _lib.set_option("attn_variant", var)
+        t = timeit(lambda: ops.attention(Q, K_, VTP if var == 11 else VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention[{names[var]}] B={B}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
     _lib.set_option("attn_variant", 0)
 
