@@ -71,7 +71,8 @@ const char* x2i_last_error(void);
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
  * same values up to the summation order of the row statistics),
  * "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
- * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale, 10 = A/B kernel on 16x16x32 MFMAs), "conv5_variant" (0),
+ * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale, 10 / 11 = A/B kernels on 16x16x32 MFMAs (compiler-scheduled), 12 = the hand-scheduled kernel on 16x16x32 MFMAs (11 / 12: V^T with the
+ * 32-key-span permutation of attention16.hip -- tools and tests only)), "conv5_variant" (0),
  * "fp8" (0; 2 = x2i_ln_modulate_fp8 keeps its per-row kernel at D = 3072, bit-identical A/B); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
  * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
  * return X2I_ERR_ARG.  Every setting selects between

@@ -281,3 +281,6 @@ def test_generated_attention_statement_is_current():
     gen = os.path.join(here, "x2i_amd", "csrc", "gen_attn_w4.py")
     env = {k: v for k, v in os.environ.items() if not k.startswith("X2I_ATTN_")}
     assert subprocess.run([sys.executable, gen, "--check"], env=env).returncode == 0
+    # ... and the same program on the 16 x 16 x 32 MFMA shape (csrc/attn_w16_loop.inc <- gen_attn_w16.py; A/B kernel, attn_variant = 12)
+    gen16 = os.path.join(here, "x2i_amd", "csrc", "gen_attn_w16.py")
+    assert subprocess.run([sys.executable, gen16, "--check"], env=env).returncode == 0

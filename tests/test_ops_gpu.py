@@ -459,3 +459,37 @@ def test_rope_table_matches_float64_reference(ops):
     rc, rs = P.flux_pos_embed(ids, (16, 56, 56))
     assert cos.shape == (300, 128) and torch.allclose(cos.cpu(), rc, atol=1e-6) and torch.allclose(sin.cpu(), rs, atol=1e-6)
     assert torch.equal(cos[:40].cpu(), torch.ones(40, 128)) and torch.equal(sin[:40].cpu(), torch.zeros(40, 128))
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 136), (1, 2, 1152), (1, 3, 700), (2, 1, 2000), (1, 24, 4608)])
+def test_attention_hand_scheduled_16x16x32_kernel(ops, opt, B, H, S):
+    """attention_w16.hip (attn_variant = 12, A/B): attention_w4.hip's program on v_mfma_f32_16x16x32_bf16 -- P^T from the lane's own registers
+    through a key permutation within 32-key spans (V^T arrives permuted: the caller's job until the QKV epilogue writes that order), row sums
+    on the matrix pipe.  Against fp32 softmax(Q K^T / sqrt(128)) V on the bf16 inputs (ragged lengths: 1 .. 72 key tiles, masked last tiles),
+    its log2-sum-exp rows against torch.logsumexp, and twice in a row bit for bit."""
+    import math
+    Spad = ops.pad128(S)
+    D = H * 128
+    gen = torch.Generator(device=DEV).manual_seed(1000 + S)
+    Q = (torch.randn((B, H, Spad, 128), device=DEV, generator=gen) * 1.5).bfloat16()
+    K = (torch.randn((B, H, Spad, 128), device=DEV, generator=gen) * 1.5).bfloat16()
+    VT = torch.randn((B, H, 128, Spad), device=DEV, generator=gen).bfloat16()
+    perm = torch.tensor([16 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3) for kk in range(32)], device=DEV)
+    VTP = VT.view(B, H, 128, Spad // 32, 32)[..., perm].reshape(B, H, 128, Spad).contiguous()
+    scale = 1 / math.sqrt(128)
+    opt("attn_variant", 12)
+    outs = []
+    for _ in range(2):
+        O = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros((B, H, Spad), device=DEV)
+        ops.attention_lse(Q, K, VTP, O, lse, B, H, S, Spad, D, S * D, scale)
+        outs.append((O, lse))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    O, lse = outs[0]
+    for (b, h) in {(0, 0), (B - 1, H - 1)}:
+        sc = scale * Q[b, h, :S].float() @ K[b, h, :S].float().t()
+        ref = torch.softmax(sc, -1) @ VT[b, h, :, :S].float().t()
+        assert rel_l2(O[b, :, h * 128:(h + 1) * 128], ref) < 8e-3, (b, h)
+        ref_lse = torch.logsumexp(sc, -1) * 1.4426950408889634
+        assert float((lse[b, h, :S] - ref_lse).abs().max()) < 2e-2
+        assert bool((lse[b, h, S:] > 1e29).all())

@@ -34,17 +34,18 @@ def main():
     perm = torch.tensor([16 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3) for kk in range(32)], device="cuda")
     VTP = VT.view(B, H, 128, Spad // 32, 32)[..., perm].reshape(B, H, 128, Spad).contiguous()   # variant 11: keys permuted within 32-key spans
     names[11] = "... with V^T pre-permuted (one 16-byte fragment read)"
-    for var in (4, 10, 11):   # the 16x16x32 A/B kernel against its 32x32x16 partner: same values up to rounding?
+    names[12] = "hand-scheduled, one wave per SIMD, 16x16x32 MFMAs (attention_w16.hip, V^T pre-permuted)"
+    for var in (4, 10, 11, 12):   # the 16x16x32 A/B kernel against its 32x32x16 partner: same values up to rounding?
         _lib.set_option("attn_variant", var)
-        ops.attention(Q, K_, VTP if var == 11 else VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128))
+        ops.attention(Q, K_, VTP if var >= 11 else VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128))
         torch.cuda.synchronize()
         if ref is None:
             ref = O.float().clone()
         else:
             print(f"variant {var} vs variant 4: rel-L2 {float((O.float() - ref).norm() / ref.norm()):.3e}")
-    for var in (9, 8, 4, 10, 11, 9, 8, 4, 10, 11, 9):
+    for var in (9, 12, 8, 4, 10, 11, 9, 12, 8, 4, 9, 12):
         _lib.set_option("attn_variant", var)
-        t = timeit(lambda: ops.attention(Q, K_, VTP if var == 11 else VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
+        t = timeit(lambda: ops.attention(Q, K_, VTP if var >= 11 else VT, O, B, H, S, Spad, D, S * D, 1 / math.sqrt(128)))
         print(f"attention[{names[var]}] B={B}: {t*1e3:8.3f} ms  {4*B*H*S*S*128/t/1e12:8.1f} TFLOP/s")
     _lib.set_option("attn_variant", 0)
 

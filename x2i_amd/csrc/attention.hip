@@ -333,6 +333,10 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     const int rc = x2i_launch_attention_w4(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse, out8, oinv);
     if (rc != X2I_ERR_STATE) return rc;
   }
+  if (var == 12 && !out8) {   // A/B: the hand-scheduled kernel on 16 x 16 x 32 MFMAs (attention_w16.hip); V^T pre-permuted by the caller -- tools / tests only
+    const int rc = x2i_launch_attention_w16(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse);
+    if (rc != X2I_ERR_STATE) return rc;
+  }
   if ((var == 10 || var == 11) && !out8) {   // (11: V^T arrives with the 32-key-span permutation of attention16.hip -- tools only)   // A/B: the 16 x 16 x 32 MFMA shape (attention16.hip; compare with variant 4, the same organisation on 32 x 32 x 16)
     const int rc = x2i_launch_attention_16(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, lse, var == 11);
     if (rc != X2I_ERR_STATE) return rc;

@@ -25,6 +25,8 @@ int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long H
                                       const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                          long long o_bs, float scale, hipStream_t stream, int out8 = 0, float oinv = 1.f, float* lse = nullptr);
+int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
+                             float scale_log2, int prescale, hipStream_t stream, float* lse);   // A/B: hand-scheduled, 16x16x32 (attention_w16.hip, attn_variant = 12)
 int x2i_launch_attention_16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
                             float scale_log2, hipStream_t stream, float* lse, int vperm);   // A/B: 16x16x32 MFMA shape (attention16.hip, attn_variant = 10 / 11)
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
