@@ -215,8 +215,10 @@ def gemm_roofline(B, rounds=6, per_round=8):
 
 
 def attention_roofline(B, rounds=6, per_round=8):
-    """Second kernel of the step (21 % of its time): `attn_w4_kernel` at the single-block geometry (24 heads, S = 4608, output into the
-    [S, 5D] concatenation buffer, exp2-domain scale as flux.py passes it).  Two live estimators, both HIP events on the launch stream:
+    """Second kernel of the step (21 % of its time): the attention kernel the step uses -- `attn_w16_kernel` on a span-permuted V^T where
+    x2i_attention_prefers_vt_perm says so (flux.py asks the same question), else `attn_w4_kernel` -- at the single-block geometry (24 heads,
+    S = 4608, output into the [S, 5D] concatenation buffer, exp2-domain scale as flux.py passes it), with the other kernel's numbers
+    beside it (`other`).  Two live estimators, both HIP events on the launch stream:
     `alone` = back-to-back launches (what tools/attn_bench.py reports), and `in_sequence` = every attention launch timed on its own
     between the two roofline GEMM launches, i.e. in the power / clock state the step leaves it in.  frac = the in-sequence median."""
     from x2i_amd import ops
@@ -231,8 +233,13 @@ def attention_roofline(B, rounds=6, per_round=8):
     W1 = (torch.randn(D, 5 * D, device="cuda") * 0.02).bfloat16()
     X = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
 
+    vp = ops.attention_prefers_vt_perm(H, S, math.log(2.0))   # (random V^T: the key order does not change the work)
+
     def attn():
-        ops.attention(Q, K_, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, math.log(2.0))
+        ops.attention(Q, K_, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, math.log(2.0), vt_perm=vp)
+
+    def attn_other():
+        ops.attention(Q, K_, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, math.log(2.0), vt_perm=not vp)
 
     def g0():
         ops.gemm(A0, W0, None, out=CAT, act=1, ldc=5 * D, c_offset=D)     # proj_mlp + GELU into the concatenation buffer, as the block does
@@ -240,23 +247,32 @@ def attention_roofline(B, rounds=6, per_round=8):
     def g1():
         ops.gemm(CAT, W1, None, out=X)                                   # proj_out over [attention | MLP]
     fl = 4.0 * B * H * S * S * 128
+    names = {True: "attn_w16_kernel", False: "attn_w4_kernel"}
+
+    def in_sequence(fn):
+        for _ in range(2):
+            g0(); fn(); g1()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds * per_round)]
+        with ClockPowerSampler(torch.cuda.current_device()) as smp:
+            for e0, e1 in ev:
+                g0()
+                e0.record()
+                fn()
+                e1.record()
+                g1()
+            torch.cuda.synchronize()
+        return sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev), smp
     times, power = _interleaved_probe([attn], rounds, per_round)
     alone = sorted(times[0])
-    for _ in range(2):
-        g0(); attn(); g1()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds * per_round)]
-    with ClockPowerSampler(torch.cuda.current_device()) as smp:
-        for e0, e1 in ev:
-            g0()
-            e0.record()
-            attn()
-            e1.record()
-            g1()
-        torch.cuda.synchronize()
-    seq = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev)
+    seq, smp = in_sequence(attn)
     t_seq, t_alone = seq[len(seq) // 2], alone[len(alone) // 2]
-    return dict(bound="mfma", kernel="attn_w4_kernel", achieved=fl / t_seq / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / t_seq / PEAK_BF16,
+    to, po = _interleaved_probe([attn_other], rounds, per_round)   # the A/B partner, same box, same minute
+    so, smo = in_sequence(attn_other)
+    to = sorted(to[0])
+    other = dict(kernel=names[not vp], us_alone=to[len(to) // 2] * 1e6, us_in_sequence=so[len(so) // 2] * 1e6, clock_power_alone=po,
+                 clock_power_in_sequence=smo.summary())
+    return dict(bound="mfma", kernel=names[vp], other=other, achieved=fl / t_seq / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=fl / t_seq / PEAK_BF16,
                 frac_alone=fl / t_alone / PEAK_BF16, us_in_sequence=t_seq * 1e6, us_alone=t_alone * 1e6, us_in_sequence_min_max=[seq[0] * 1e6, seq[-1] * 1e6],
                 measured="live (HIP events on the launch stream, this run)", flop_per_launch=fl,
                 clock_power_alone=power, clock_power_in_sequence=smp.summary(),

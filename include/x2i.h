@@ -22,7 +22,7 @@
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
  *   - ABI version 3 (x2i_abi_version).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
- *     zero-initialised descriptor means what it meant in version 1).  A caller built against another version must not load this
+ *     zero-initialised descriptor means what it meant in version 1) and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
  *     library (x2i_amd/_lib.py checks).
  */
 #ifndef X2I_H
@@ -64,6 +64,7 @@ const char* x2i_last_error(void);
  * NOT bit-identical to the whole-tile kernels (another association of the K sum, same tolerance).  0: whole tiles), "gemm_streamk" (1: the persistent kernel cuts the tiles of the last, partly filled round along K and chains the segments
  * through the CALLER's workspace, x2i_gemm_args.workspace -- bit-identical to the one-tile kernel; 0, or no workspace: the peeled
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
+ * "attn_w16" (1: x2i_attention_prefers_vt_perm may answer 1 -- the sampling path then uses the 16 x 16 x 32 attention kernel; 0: never; 2: at any size -- tests),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
  * "gemm_r2" (DEFAULT 0; 1: A/B -- plain bf16 launches with K % 256 == 0 take the "two residents" kernel, 256 x 128 tiles and two
@@ -216,6 +217,15 @@ int x2i_groupnorm_nhwc_from_moments_bf16(const void* x, void* y, int32_t B, int6
  * take the hand-scheduled kernel whose softmax has no multiply (csrc/attention_w4.hip); same result within the stated tolerance. */
 int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
                        int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
+/* The same attention for a V^T written "span-permuted" (x2i_qkv_desc.vt_perm = 1): the hand-scheduled kernel on the 16 x 16 x 32 MFMA shape
+ * (csrc/attention_w16.hip), which the matrix pipe sustains at a ~11 % higher clock at this part's power cap than the 32 x 32 x 16 shape of the
+ * other kernels.  x2i_attention_prefers_vt_perm(H, S, scale) says (1 / 0) whether a caller should ask its QKV producers for that layout:
+ * scale == ln 2 (Q carries the scale), sequences long enough that one sample's 256-row workgroups fill half the chip -- by H and S, never by
+ * the batch -- and option "attn_w16" (default 1).  A call the kernel does not serve is an error (X2I_ERR_SHAPE), never a silent fallback:
+ * no other kernel reads that layout. */
+int x2i_attention_vp_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
+                          int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
+int x2i_attention_prefers_vt_perm(int32_t H, int32_t S, float scale);
 
 /* The same attention with an e4m3 output O8[b][s][h*128 + d] = sat(o * out_inv_scale) (ldo / o_batch_stride in bytes, multiples
  * of 8): the A operand of an fp8 projection (single blocks' proj_out in the fp8 configuration), no bf16 round trip. */
@@ -254,6 +264,9 @@ typedef struct x2i_qkv_desc {
                         * rounding: a caller that passes softmax_scale * log2(e) here and scale = ln 2 to x2i_attention_* gets the same
                         * attention with the score multiply gone from the kernels' inner loops (and none of the double rounding a
                         * separate rescale of the bf16 Q would cost) */
+  int32_t vt_perm;     /* 0: V^T rows hold the tokens in sequence order.  1: "span-permuted" -- within every 32-token span position kk holds token
+                        * 16 ((kk >> 2) & 1) + 4 (kk >> 3) + (kk & 3): the order x2i_attention_vp_bf16 (the 16 x 16 x 32 MFMA attention kernel)
+                        * reads.  Every producer of one attention call's V^T must use the same value (x2i_attention_prefers_vt_perm) */
 } x2i_qkv_desc;
 int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_stream_t stream);
 /* Two GEMMs of the same kind -- the image-stream and the text-stream linear of a double-stream block (lightcontrol_flux.py:173-200:

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import rel_l2, seeded
+from tests.util import rel_l2, seeded, span_permute
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -214,6 +214,13 @@ def test_gemm_qkv_fp8_equals_gemm_fp8_then_qkv_split(B, H, St, Si):
     assert torch.equal(V1[..., sl], V0[..., sl]) and torch.equal(Q1[:, :, sl], Q0[:, :, sl]) and torch.equal(K1[:, :, sl], K0[:, :, sl])
     assert float(Q1[:, :, :St].float().abs().max() if St else 0.0) == 0.0  # rows outside the launch are untouched
     assert float(Q1[:, :, sl].float().abs().mean()) > 0.1
+    # x2i_qkv_desc.vt_perm on the e4m3 form: the same V^T, span-permuted (the position map moves tokens within their own 32-token span,
+    # so the permuted buffer holds the launched rows' values at their mapped places and zeros elsewhere)
+    Q2, K2, V2 = bufs()
+    kw = dict(M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd, a_scale=sxi,
+              a_scale_batch_stride=Si, w_scale=sw) if St > 0 else dict(M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=sx, w_scale=sw)
+    ops.gemm_qkv_fp8(X8, W8, bias, Q2, K2, V2, nq, nk, cos, sin, vt_perm=True, **kw)
+    assert torch.equal(V2, span_permute(V1)) and torch.equal(Q2, Q1) and torch.equal(K2, K1)
 
 
 def _tiny(fp8, mode="mlp"):

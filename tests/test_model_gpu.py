@@ -27,8 +27,19 @@ def make_model(cfg, sd):
     return m
 
 
+@pytest.fixture
+def attn_w16(request):
+    """attn_w16 = 2: the 16 x 16 x 32 attention kernel and the span-permuted V^T of the fused QKV epilogues at ANY size (1 = where the product
+    uses them: long sequences; 0 = never)."""
+    from x2i_amd import _lib
+    old = _lib.set_option("attn_w16", request.param)
+    yield request.param
+    _lib.set_option("attn_w16", old)
+
+
+@pytest.mark.parametrize("attn_w16", [1, 2, 0], indirect=True)
 @pytest.mark.parametrize("name", ["flux_tiny_schnell", "flux_tiny_dev_control"])
-def test_transformer_forward_vs_reference_golden(name):
+def test_transformer_forward_vs_reference_golden(name, attn_w16):
     t, meta = golden(name)
     cfg = meta["cfg"]
     sd = OF.random_flux_state_dict(cfg, seed=meta["weight_seed"], std=meta["weight_std"])
@@ -48,7 +59,8 @@ def test_transformer_forward_vs_reference_golden(name):
         assert rel_l2(out, t["out"]) < 3e-2
 
 
-def test_full_width_one_plus_one_blocks_vs_oracle():
+@pytest.mark.parametrize("attn_w16", [1, 2], indirect=True)
+def test_full_width_one_plus_one_blocks_vs_oracle(attn_w16):
     """D = 3072, 24 heads (the real FLUX width), 1 double + 1 single block, ragged short sequence."""
     cfg = dict(OF.DEFAULT_CFG)
     cfg.update(num_layers=1, num_single_layers=1)

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import primitives as P
-from tests.util import rel_l2, seeded
+from tests.util import rel_l2, seeded, span_permute
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -447,6 +447,22 @@ def test_gemm_qkv_fused_equals_gemm_then_qkv_split(ops, opt, B, H, St, Si, tile)
     assert torch.equal(V1[..., :S], V0[..., :S])          # a pure move of the same bf16 values
     assert float(V1[..., S:].float().abs().max()) == 0.0 if Spad > S else True
     assert torch.equal(Q1, Q0) and torch.equal(K1, K0)    # same arithmetic, same order
+    # x2i_qkv_desc.vt_perm: the same V^T with the keys of every 32-key span permuted (what attention_w16.hip reads), Q and K untouched --
+    # both tile kernels, aligned runs (two 8-byte pieces) and the element-wise path, the grouped pair launch
+    Q2, K2, V2 = bufs()
+    if St > 0:
+        g_img = dict(A=X, W=W, bias=bias, Q=Q2, K=K2, VT=V2, norm_q=nq, norm_k=nk, cos=cos, sin=sin, M=Si, H=H, Spad=Spad, tok_off=St,
+                     rows_per_sample=Si, batch=B, a_batch_stride=S * Kd, lda=Kd, a_offset=St * Kd, vt_perm=True)
+        g_txt = dict(A=X, W=Wc, bias=biasc, Q=Q2, K=K2, VT=V2, norm_q=nqa, norm_k=nka, cos=cos, sin=sin, M=St, H=H, Spad=Spad, tok_off=0,
+                     rows_per_sample=St, batch=B, a_batch_stride=S * Kd, lda=Kd, vt_perm=True)
+        ops.gemm_qkv_pair(g_img, g_txt)
+        Q3, K3, V3 = bufs()
+        ops.gemm_qkv(**dict(g_img, Q=Q3, K=K3, VT=V3))
+        ops.gemm_qkv(**dict(g_txt, Q=Q3, K=K3, VT=V3))
+        assert torch.equal(V3, V2)
+    else:
+        ops.gemm_qkv(X, W, bias, Q2, K2, V2, nq, nk, cos, sin, M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S, vt_perm=True)
+    assert torch.equal(V2, span_permute(V1)) and torch.equal(Q2, Q1) and torch.equal(K2, K1)
 
 
 def test_rope_table_matches_float64_reference(ops):
@@ -493,3 +509,23 @@ def test_attention_hand_scheduled_16x16x32_kernel(ops, opt, B, H, S):
         ref_lse = torch.logsumexp(sc, -1) * 1.4426950408889634
         assert float((lse[b, h, :S] - ref_lse).abs().max()) < 2e-2
         assert bool((lse[b, h, S:] > 1e29).all())
+    # the product entry point of that kernel (x2i_attention_vp_bf16: no LSE rows, the softmax scale already in Q as the sampling path has it)
+    opt("attn_variant", 0)
+    Qs = (Q.float() * (scale * 1.4426950408889634)).bfloat16()
+    O2 = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+    ops.attention(Qs, K, VTP, O2, B, H, S, Spad, D, S * D, math.log(2.0), vt_perm=True)
+    opt("attn_variant", 12)
+    O3 = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+    ops.attention(Qs, K, VTP, O3, B, H, S, Spad, D, S * D, math.log(2.0))
+    assert torch.equal(O2, O3)
+    opt("attn_variant", 0)
+    O4 = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+    ops.attention(Qs, K, VT, O4, B, H, S, Spad, D, S * D, math.log(2.0))     # the 32 x 32 x 16 kernels on the natural layout
+    assert rel_l2(O2, O4) < 6e-3
+    opt("attn_w16", 0)
+    assert not ops.attention_prefers_vt_perm(24, 4608, math.log(2.0))
+    opt("attn_w16", 1)
+    assert ops.attention_prefers_vt_perm(24, 4608, math.log(2.0)) and not ops.attention_prefers_vt_perm(24, 4608, scale)
+    assert not ops.attention_prefers_vt_perm(2, 136, math.log(2.0))
+    opt("attn_w16", 2)
+    assert ops.attention_prefers_vt_perm(2, 136, math.log(2.0))

@@ -25,3 +25,10 @@ def rel_l2(a, b):
 
 def max_abs(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+def span_permute(VT):
+    """V^T [..., Spad] in the "span-permuted" key order of x2i_qkv_desc.vt_perm (include/x2i.h): within every 32-key span, position kk holds
+    key 16 ((kk >> 2) & 1) + 4 (kk >> 3) + (kk & 3)."""
+    perm = torch.tensor([16 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3) for kk in range(32)], device=VT.device)
+    return VT.reshape(*VT.shape[:-1], VT.shape[-1] // 32, 32)[..., perm].reshape(VT.shape).contiguous()

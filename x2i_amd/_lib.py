@@ -47,7 +47,7 @@ class QkvDesc(C.Structure):
     _fields_ = [("norm_q", C.c_void_p), ("norm_k", C.c_void_p), ("cos", C.c_void_p), ("sin", C.c_void_p),
                 ("Q", C.c_void_p), ("K", C.c_void_p), ("VT", C.c_void_p),
                 ("H", C.c_int32), ("Spad", C.c_int32), ("tok_off", C.c_int32), ("rows_per_sample", C.c_int32),
-                ("eps", C.c_float), ("q_scale", C.c_float)]
+                ("eps", C.c_float), ("q_scale", C.c_float), ("vt_perm", C.c_int32)]
 
 
 class Fp8Desc(C.Structure):
@@ -74,6 +74,8 @@ SIGNATURES = {
     "x2i_groupnorm_moments_f32": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "x2i_groupnorm_nhwc_from_moments_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
+    "x2i_attention_vp_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
+    "x2i_attention_prefers_vt_perm": [_i32, _i32, _f32],
     "x2i_attention_e4m3out": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _f32, _vp],
     "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
     "x2i_ln_modulate_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp],

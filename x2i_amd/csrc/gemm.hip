@@ -74,14 +74,14 @@ static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
   p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = 0;
   p.gm = 4;
-  p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f; p.q_qs = 1.f;
+  p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   p.f_sa = p.f_sw = nullptr; p.f_sa_bs = 0; p.f_alpha = p.f_oinv = 1.f; p.f_out8 = 0;
   p.nbatch = 1; p.sk_on = 0; p.sk_slabs = nullptr; p.sk_flags = nullptr; p.fx_v0 = 0;
   if (qd) {
     p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps; p.q_qs = qd->q_scale == 0.f ? 1.f : qd->q_scale;
     p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
-    p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT;
+    p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT; p.q_vperm = qd->vt_perm ? 1 : 0;
     p.ldc = a->N; p.c_bs = 0;  // C is never written
   }
 }
@@ -471,12 +471,12 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = 0;
   p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = 0;
-  p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = 0; p.q_eps = 0.f; p.q_qs = 1.f;
+  p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   if (qd) {
     p.q_on = 1; p.q_H = qd->H; p.q_Spad = qd->Spad; p.q_tok_off = qd->tok_off; p.q_rpb = qd->rows_per_sample; p.q_eps = qd->eps; p.q_qs = qd->q_scale == 0.f ? 1.f : qd->q_scale;
     p.q_nq = (const bf16_t*)qd->norm_q; p.q_nk = (const bf16_t*)qd->norm_k; p.q_cos = qd->cos; p.q_sin = qd->sin;
-    p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT;
+    p.q_Q = (bf16_t*)qd->Q; p.q_K = (bf16_t*)qd->K; p.q_VT = (bf16_t*)qd->VT; p.q_vperm = qd->vt_perm ? 1 : 0;
     p.ldc = a->N; p.c_bs = 0;  // C is never written
   }
   p.f_sa = f->a_scale; p.f_sa_bs = f->a_scale_batch_stride; p.f_sw = f->w_scale; p.f_alpha = f->alpha; p.f_oinv = f->out_inv_scale;

@@ -627,21 +627,27 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
           token(m, b, st);
           bf16_t* row0 = p.q_VT + (((long long)b * p.q_H + head) * 128 + d) * p.q_Spad;
           if (aligned) {
-            union { bf16x8_t v8; uint32_t uu[4]; } lo, hi;
+            union { bf16x8_t v8; uint32_t uu[4]; uint2 h2[2]; } lo, hi;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               lo.uu[k] = (v[2 * k] & 0xffffu) | (v[2 * k + 1] << 16);
               hi.uu[k] = (v[2 * k] >> 16) | (v[2 * k + 1] & 0xffff0000u);
             }
-            *(bf16x8_t*)(row0 + st) = lo.v8;
-            *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+            if (p.q_vperm) {   // span-permuted V^T (x2i_vt_pos): the run of eight tokens is two runs of four, eight positions apart
+              const int ps = x2i_vt_pos(st, 1);
+              *(uint2*)(row0 + ps) = lo.h2[0]; *(uint2*)(row0 + ps + 8) = lo.h2[1];
+              *(uint2*)(row0 + p.q_Spad + ps) = hi.h2[0]; *(uint2*)(row0 + p.q_Spad + ps + 8) = hi.h2[1];
+            } else {
+              *(bf16x8_t*)(row0 + st) = lo.v8;
+              *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+            }
           } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               if (m + k < p.M) {
                 int bk, sk;
                 token(m + k, bk, sk);
-                bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + head) * 128 + d) * p.q_Spad + sk;
+                bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + head) * 128 + d) * p.q_Spad + x2i_vt_pos(sk, p.q_vperm);
                 rk[0] = (bf16_t)(v[k] & 0xffffu);
                 rk[p.q_Spad] = (bf16_t)(v[k] >> 16);
               }
@@ -679,7 +685,7 @@ __device__ __forceinline__ GemmP prob(const GemmP2& a, int sel) {
   X2I_F(A) X2I_F(a_bs) X2I_F(lda) X2I_F(W) X2I_F(ldw) X2I_F(w_bs) X2I_F(bias) X2I_F(C) X2I_F(c_bs) X2I_F(ldc) X2I_F(C2) X2I_F(act2)
   X2I_F(gate) X2I_F(gate_bs) X2I_F(res) X2I_F(r_bs) X2I_F(ldr) X2I_F(bias2) X2I_F(bias2_bs) X2I_F(M) X2I_F(N) X2I_F(K) X2I_F(act)
   X2I_F(out_f32) X2I_F(tilesM) X2I_F(tilesN) X2I_F(cH) X2I_F(cW) X2I_F(cCin) X2I_F(cOW) X2I_F(cKW) X2I_F(cStride) X2I_F(cPad) X2I_F(cUp) X2I_F(cPadW)
-  X2I_F(q_on) X2I_F(q_H) X2I_F(q_Spad) X2I_F(q_tok_off) X2I_F(q_rpb) X2I_F(q_row0) X2I_F(gm) X2I_F(q_eps) X2I_F(q_qs) X2I_F(q_nq) X2I_F(q_nk)
+  X2I_F(q_on) X2I_F(q_H) X2I_F(q_Spad) X2I_F(q_tok_off) X2I_F(q_rpb) X2I_F(q_row0) X2I_F(q_vperm) X2I_F(gm) X2I_F(q_eps) X2I_F(q_qs) X2I_F(q_nq) X2I_F(q_nk)
   X2I_F(q_cos) X2I_F(q_sin) X2I_F(q_Q) X2I_F(q_K) X2I_F(q_VT) X2I_F(f_sa) X2I_F(f_sa_bs) X2I_F(f_sw) X2I_F(f_alpha) X2I_F(f_oinv) X2I_F(f_out8)
   X2I_F(nbatch) X2I_F(sk_on) X2I_F(sk_slabs) X2I_F(sk_flags) X2I_F(fx_v0)
 #undef X2I_F

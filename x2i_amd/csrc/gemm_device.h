@@ -26,7 +26,7 @@ struct GemmP {
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
   int cPadW;                                       // padding along W (cPad: along H)
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
-  int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0;
+  int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0, q_vperm;   // q_vperm: V^T span-permuted (x2i_vt_pos)
   int gm;
   float q_eps, q_qs;
   const bf16_t *q_nq, *q_nk;
@@ -446,21 +446,27 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
       tok_of(tmap, m - m0, b, st);
       bf16_t* row0 = p.q_VT + (((long long)b * p.q_H + h) * 128 + d) * p.q_Spad;
       if (aligned) {
-        union { bf16x8_t v8; uint32_t uu[4]; } lo, hi;
+        union { bf16x8_t v8; uint32_t uu[4]; uint2 h2[2]; } lo, hi;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           lo.uu[k] = (v[2 * k] & 0xffffu) | (v[2 * k + 1] << 16);
           hi.uu[k] = (v[2 * k] >> 16) | (v[2 * k + 1] & 0xffff0000u);
         }
-        *(bf16x8_t*)(row0 + st) = lo.v8;
-        *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+        if (p.q_vperm) {   // span-permuted V^T: the run of eight tokens is two runs of four, eight positions apart
+          const int ps = x2i_vt_pos(st, 1);
+          *(uint2*)(row0 + ps) = lo.h2[0]; *(uint2*)(row0 + ps + 8) = lo.h2[1];
+          *(uint2*)(row0 + p.q_Spad + ps) = hi.h2[0]; *(uint2*)(row0 + p.q_Spad + ps + 8) = hi.h2[1];
+        } else {
+          *(bf16x8_t*)(row0 + st) = lo.v8;
+          *(bf16x8_t*)(row0 + p.q_Spad + st) = hi.v8;
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           if (m + k < p.M) {
             int bk, sk;
             tok_of(tmap, m + k - m0, bk, sk);
-            bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + h) * 128 + d) * p.q_Spad + sk;
+            bf16_t* rk = p.q_VT + (((long long)bk * p.q_H + h) * 128 + d) * p.q_Spad + x2i_vt_pos(sk, p.q_vperm);
             rk[0] = (bf16_t)(v[k] & 0xffffu);
             rk[p.q_Spad] = (bf16_t)(v[k] >> 16);
           }

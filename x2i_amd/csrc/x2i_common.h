@@ -45,6 +45,7 @@ struct X2IOptions {
   int gemm_persist;       // 1 = batch-1 launches with whole-line epilogues take the persistent form (gemm256p.hip, default)   X2I_GEMM_PERSIST
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
+  int attn_w16;           // 1 = x2i_attention_prefers_vt_perm may say yes (sampling path on attention_w16.hip; default); 0 = never; 2 = at any size   X2I_ATTN_W16
   int conv5_variant;      // matrix-core projector conv: 0 = automatic form choice; 1 = plain stages, 2 = pipelined, 3 = two row blocks   X2I_CONV5_VARIANT
   int fp8;                // 2 = x2i_ln_modulate_fp8 keeps its per-row kernel at the model's width (A/B against the four-rows-per-wave form); else unused   X2I_FP8
   int last_gemm_tile;     // read-only introspection for the parity tests: tile edge of the kernel the last GEMM / conv launch used
@@ -66,6 +67,13 @@ int x2i_gemm_sk_slabs();                          // slabs per workspace (2 x ma
 int x2i_gemm_sk_max_tiles();                      // (gemm.hip: the constants of gemm_device.h)
 long long x2i_gemm_sk_slab_bytes();
 
+// Position of token / key t along the Spad axis of a V^T row when V^T is written "span-permuted" (x2i_qkv_desc.vt_perm, x2i_attention_vp_bf16):
+// within every 32-key span position kk holds key 16 ((kk >> 2) & 1) + 4 (kk >> 3) + (kk & 3), i.e. key t sits at 8 ((t >> 2) & 3) + 4 ((t >> 4) & 1) + (t & 3)
+// -- the order in which a lane of the 16 x 16 x 32 attention kernel finds a PV MFMA's eight k-positions in its own score registers
+// (attention_w16.hip).  Four consecutive tokens stay consecutive; an aligned run of eight becomes two 8-byte pieces 8 positions apart.
+__device__ __forceinline__ int x2i_vt_pos(int t, int perm) {
+  return perm ? ((t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3)) : t;
+}
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // float -> bf16, round-to-nearest-even (== torch .to(bfloat16)); hipcc lowers these casts to v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

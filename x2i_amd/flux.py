@@ -421,6 +421,10 @@ class FluxTransformer2DModel(nn.Module):
         # x2i_qkv_desc.q_scale) and the attention kernels get scale = ln 2: their inner loops lose the score multiply
         qs = scale * 1.4426950408889634 if (fuse_qkv or fp8_all) else 1.0
         scale = scale / qs if qs != 1.0 else scale
+        # the 16 x 16 x 32 attention kernel reads V^T with the keys of every 32-key span permuted (x2i_qkv_desc.vt_perm): the fused QKV
+        # epilogues write it that way where that kernel serves the call (decided by H, S and the scale only -- never by the batch)
+        vp_d = fuse_qkv and not fp8_all and ops.attention_prefers_vt_perm(H, S, scale)   # double blocks: bf16 attention unless fp8 "all"
+        vp_s = fuse_qkv and fp8 is None and ops.attention_prefers_vt_perm(H, S, scale)   # single blocks: bf16 attention without fp8
         # forward hooks on block.attn (attention-distillation capture): materialise the attention outputs of every block
         taps = any(len(b.attn._forward_hooks) for b in self.transformer_blocks) or \
             any(len(b.attn._forward_hooks) for b in self.single_transformer_blocks)
@@ -454,10 +458,10 @@ class FluxTransformer2DModel(nn.Module):
                 # (image rows and text rows: two problems, ONE grouped launch -- the text tiles ride in the image launch's rounds)
                 g_img = dict(A=NRM, W=f[p + ".qkv.w"], bias=f[p + ".qkv.b"], Q=Q, K=K, VT=VT, norm_q=f[p + ".norm_q"], norm_k=f[p + ".norm_k"],
                              cos=cos, sin=sin, M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
-                             a_offset=St * D, q_scale=qs)
+                             a_offset=St * D, q_scale=qs, vt_perm=vp_d)
                 g_txt = dict(A=NRM, W=f[p + ".cqkv.w"], bias=f[p + ".cqkv.b"], Q=Q, K=K, VT=VT, norm_q=f[p + ".norm_added_q"],
                              norm_k=f[p + ".norm_added_k"], cos=cos, sin=sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B,
-                             a_batch_stride=S * D, lda=D, q_scale=qs)
+                             a_batch_stride=S * D, lda=D, q_scale=qs, vt_perm=vp_d)
                 if St > 0:
                     ops.gemm_qkv_pair(g_img, g_txt)
                 else:
@@ -479,7 +483,7 @@ class FluxTransformer2DModel(nn.Module):
                              c_batch_stride=S * D, ldc=D, res=X, res_batch_stride=S * D, ldr=D, gate=mod(oc + 2 * D),
                              gate_batch_stride=Ntot)
             else:
-                ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale)
+                ops.attention(Q, K, VT, ATT, B, H, S, Spad, D, S * D, scale, vt_perm=vp_d)
             # hidden += gate_msa * to_out(attn_img) ; enc += c_gate_msa * to_add_out(attn_txt)
             if fp8_all:
                 pass
@@ -564,7 +568,7 @@ class FluxTransformer2DModel(nn.Module):
                                  Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=ws["RS"], w_scale=sq, q_scale=qs)
             elif fuse_qkv:
                 ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
-                             Spad=Spad, tok_off=0, rows_per_sample=S, q_scale=qs)
+                             Spad=Spad, tok_off=0, rows_per_sample=S, q_scale=qs, vt_perm=vp_s)
             else:
                 ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)
             if fp8 is None:
@@ -577,7 +581,7 @@ class FluxTransformer2DModel(nn.Module):
                 ops.qkv_split(None, QKV, 3 * D, 3 * D, B, S, 0, H, None, None, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin,
                               Q, K, VT, Spad)
             if fp8 is None:
-                ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale)
+                ops.attention(Q, K, VT, CAT, B, H, S, Spad, 5 * D, S * 5 * D, scale, vt_perm=vp_s)
                 if taps:  # single blocks' Attention (pre_only) returns the un-projected joint sequence [B, S, D]
                     self.single_transformer_blocks[i].attn(CAT.view(B, S, 5 * D)[:, :, :D].clone())
                 ops.gemm(CAT, f[p + ".proj_out.w"], f[p + ".proj_out.b"], out=X, M=S, batch=B, a_batch_stride=S * 5 * D,

@@ -225,7 +225,7 @@ def gemm_qkv(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, **kw):
 
 
 def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1, a_batch_stride=0,
-             lda=None, a_offset=0, eps=1e-6, q_scale=1.0, _act2=0, _bias2=None):
+             lda=None, a_offset=0, eps=1e-6, q_scale=1.0, vt_perm=False, _act2=0, _bias2=None):
     _req(A, torch.bfloat16, "A")
     _req(W, torch.bfloat16, "W")
     a = GemmArgs()
@@ -246,11 +246,22 @@ def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
     q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
+    q.vt_perm = 1 if vt_perm else 0
     return a, q
 
 
-def attention(Q, K, VT, out, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0):
+def attention_prefers_vt_perm(H, S, scale):
+    """True when the sampling path should ask its fused QKV projections for the span-permuted V^T (vt_perm=True) and call
+    attention(..., vt_perm=True): the 16 x 16 x 32 MFMA attention kernel (include/x2i.h: x2i_attention_prefers_vt_perm)."""
+    return bool(_lib.load().x2i_attention_prefers_vt_perm(int(H), int(S), float(scale)))
+
+
+def attention(Q, K, VT, out, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0, vt_perm=False):
     lib = _lib.load()
+    if vt_perm:
+        check(lib.x2i_attention_vp_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), B, H, S, Spad, ldo,
+                                        o_batch_stride, scale, _stream()), "attention_vp")
+        return out
     check(lib.x2i_attention_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), B, H, S, Spad, ldo,
                                  o_batch_stride, scale, _stream()), "attention")
     return out
@@ -579,7 +590,8 @@ def gemm_fp8(A8, W8, bias=None, out=None, *, M=None, N=None, K=None, batch=1, a_
 
 
 def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad, tok_off, rows_per_sample, batch=1,
-                 a_batch_stride=0, lda=None, a_offset=0, a_scale=None, a_scale_batch_stride=0, w_scale=None, alpha=1.0, eps=1e-6, q_scale=1.0):
+                 a_batch_stride=0, lda=None, a_offset=0, a_scale=None, a_scale_batch_stride=0, w_scale=None, alpha=1.0, eps=1e-6, q_scale=1.0,
+                 vt_perm=False):
     """gemm_qkv on e4m3 operands (include/x2i.h: x2i_gemm_qkv_fp8): dequantised accumulators, then the same fused epilogue."""
     lib = _lib.load()
     _req(A8, FP8, "A8")
@@ -606,6 +618,7 @@ def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
     q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
+    q.vt_perm = 1 if vt_perm else 0
     check(lib.x2i_gemm_qkv_fp8(C.byref(a), C.byref(f), C.byref(q), _stream()), "gemm_qkv_fp8")
 
 
