@@ -22,7 +22,7 @@
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
  *   - ABI version 3 (x2i_abi_version).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
- *     zero-initialised descriptor means what it meant in version 1) and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
+ *     zero-initialised descriptor means what it meant in version 1), appends `out_w` (0 = computed) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
  *     library (x2i_amd/_lib.py checks).
  */
 #ifndef X2I_H
@@ -174,9 +174,14 @@ int x2i_ln_modulate_fp8(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64
  * descriptor's out-of-range rule.  The 3-channel stem conv has its own entry point below. */
 typedef struct x2i_conv_desc {
   int32_t H, W, Cin, KH, KW, stride, pad;
-  int32_t up; /* 1: F.interpolate(scale_factor=2, mode="nearest") fused in front of the conv (diffusers Upsample2D) */
+  int32_t up; /* 1: F.interpolate(scale_factor=2, mode="nearest") fused in front of the conv (diffusers Upsample2D); 2: the same along H
+               * only (rows doubled, columns as they are) -- for the column-phase form of an upsampling convolution: output columns 2x + px
+               * of Upsample2D's 3 x 3 conv see source columns {x - 1, x} (px = 0) or {x, x + 1} (px = 1) only, so each phase is a 3 x 2 conv
+               * with the coinciding taps' weights added, 6/9 of the multiply-adds (x2i_amd/vae.py) */
   int32_t pad_w_p1; /* 0 (a zero-initialised descriptor): `pad` pads both dimensions, nn.Conv2d(padding=int); otherwise the padding
                      * along W is pad_w_p1 - 1 and `pad` is the padding along H (nn.Conv2d(padding=(pad, pad_w_p1 - 1))) */
+  int32_t out_w;    /* 0: the output has (W' + 2 pad_w - KW) / stride + 1 columns (W' = W, or 2 W with up = 1).  Otherwise: exactly out_w columns --
+                     * left padding pad_w, right padding whatever out_w implies (zero fill): asymmetric padding, M = OH * out_w */
 } x2i_conv_desc;
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
 

@@ -32,6 +32,45 @@ def test_upsample_fused_conv():
     assert out.shape == (B, 2 * H, 2 * W, Co) and rel_l2(out.permute(0, 3, 1, 2), ref) < 1e-2
 
 
+@pytest.mark.parametrize("C,Co,H,W", [(64, 128, 10, 14), (128, 256, 16, 24), (256, 512, 8, 40)])
+def test_upsample_conv_column_phase_form(C, Co, H, W):
+    """x2i_conv_desc.up = 2 (rows doubled in the gather, columns not) with out_w (asymmetric padding) and ldc = 2 Cout: Upsample2D's conv as
+    two 3 x 2 column-phase convolutions (vae._Conv.packed_up_phases) -- (1) the gather alone, arbitrary 3 x 2 weights, against F.conv2d on the
+    row-doubled input with the phase's one-sided padding; (2) the composed pair against the fp32 conv on the doubled image and against the
+    fused 3 x 3 form (x2i_conv_desc.up = 1), on both tile kernels (Cout = 128 / >= 256)."""
+    from x2i_amd import ops
+    from x2i_amd.vae import _Conv
+    B = 2
+    x = bf(seeded((B, C, H, W), 11))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    rows2 = x.float().repeat_interleave(2, 2)                                   # [B, C, 2H, W]
+    for px in (0, 1):
+        w = bf(seeded((Co, C, 3, 2), 12 + px) / 20)
+        b = bf(seeded((Co,), 14))
+        y = torch.zeros((B, 2 * H, 2 * W, Co), device=DEV, dtype=torch.bfloat16)
+        ops.conv2d_nhwc(xn, w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(DEV), b.to(DEV), H, W, C, Co, 3, 2, 1, 1, up=2,
+                        pad_w=1 - px, out_w=W, out=y, ldc=2 * Co, c_offset=px * Co, c_batch_stride=4 * H * W * Co)
+        ref = F.conv2d(F.pad(rows2, (1 - px, px, 1, 1)), w.float(), b.float())    # left / right / top / bottom
+        assert ref.shape == (B, Co, 2 * H, W)
+        assert rel_l2(y[:, :, px::2].permute(0, 3, 1, 2), ref) < 1e-2
+        assert float(y[:, :, 1 - px::2].float().abs().max()) == 0.0             # the other phase's columns are not touched
+    conv = _Conv(C, Co, 3, DEV)
+    with torch.no_grad():
+        conv.weight.copy_(bf(seeded((Co, C, 3, 3), 15) / 24))
+        conv.bias.copy_(bf(seeded((Co,), 16)))
+    w0, w1, bb = conv.packed_up_phases()
+    y = torch.empty((B, 2 * H, 2 * W, Co), device=DEV, dtype=torch.bfloat16)
+    for px, wp in ((0, w0), (1, w1)):
+        ops.conv2d_nhwc(xn, wp, bb, H, W, C, Co, 3, 2, 1, 1, up=2, pad_w=1 - px, out_w=W, out=y, ldc=2 * Co, c_offset=px * Co,
+                        c_batch_stride=4 * H * W * Co)
+    wf, bf_ = conv.packed()
+    fused = ops.conv2d_nhwc(xn, wf, bf_, H, W, C, Co, 3, 3, 1, 1, up=True)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), conv.weight.float().cpu(), conv.bias.float().cpu(), padding=1)
+    e_phase, e_fused = rel_l2(y.permute(0, 3, 1, 2), ref), rel_l2(fused.permute(0, 3, 1, 2), ref)
+    assert e_phase < 1e-2 and e_phase < 2.0 * e_fused + 1e-3, (e_phase, e_fused)
+    assert rel_l2(y, fused) < 1e-2
+
+
 def test_groupnorm_four_channels_per_group():
     from x2i_amd import ops
     x, w, b = bf(seeded((2, 128, 9, 11), 4, 2.0) + 0.2), bf(1 + 0.1 * seeded((128,), 5)), bf(0.1 * seeded((128,), 6))
@@ -65,6 +104,9 @@ def test_vae_decode_vs_oracle_reduced_width():
     ref = OV.vae_decode({k: rb(v) for k, v in sd.items()}, rb(z), cfg)
     assert img.shape == ref.shape == (2, 3, 64, 96)
     assert rel_l2(img, ref) < 3e-2
+    vae.up_phases = False     # Upsample2D's conv as one fused-gather 3 x 3 conv (A/B form): same image within the same bound
+    img1 = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert rel_l2(img1, ref) < 3e-2 and rel_l2(img, img1) < 2e-2
 
 
 def test_vae_decode_flux_config_small_latent():

@@ -29,7 +29,10 @@ def run(var):
 
 for rnd in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     for var, name in ((9, "w4  (32x32x16)"), (12, "w16 (16x16x32)")):
+        if "w16only" in sys.argv and var != 12:
+            continue
         times, clk = bench._interleaved_probe([run(var)], 6, 300)
         t = sorted(times[0])[len(times[0]) // 2]
         sc, pw = clk.get("sclk_mhz") or {}, clk.get("socket_power_w") or {}
-        print(f"{name}: {t * 1e6:7.1f} us  {fl / t / 1e12:7.1f} TFLOP/s   sclk {sc.get('median')} MHz   power {pw.get('median')} W", flush=True)
+        cyc = t * (sc.get("median") or 0) * 1e6 / 7 / 72    # 1728 workgroups = 7 rounds on 256 CUs, 72 key tiles each
+        print(f"{name}: {t * 1e6:7.1f} us  {fl / t / 1e12:7.1f} TFLOP/s   sclk {sc.get('median')} MHz   power {pw.get('median')} W   ~{cyc:.0f} cycles per key tile", flush=True)

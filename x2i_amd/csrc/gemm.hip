@@ -219,10 +219,16 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   if (conv) {
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
-    const int up = cd->up ? 1 : 0;
+    if (cd->up < 0 || cd->up > 2) return x2i_set_error(X2I_ERR_ARG, "conv: up must be 0, 1 (x2 along H and W) or 2 (x2 along H only), got %d", cd->up);
+    const int up_h = cd->up ? 1 : 0, up_w = cd->up == 1 ? 1 : 0, up = up_h | (up_w << 1);
     const int pad_w = cd->pad_w_p1 <= 0 ? cd->pad : cd->pad_w_p1 - 1;
     if (cd->KH * cd->KW > 32) return x2i_set_error(X2I_ERR_SHAPE, "conv: at most 32 filter taps (KH=%d KW=%d)", cd->KH, cd->KW);
-    const int OH = ((cd->H << up) + 2 * cd->pad - cd->KH) / cd->stride + 1, OW = ((cd->W << up) + 2 * pad_w - cd->KW) / cd->stride + 1;
+    const int OH = ((cd->H << up_h) + 2 * cd->pad - cd->KH) / cd->stride + 1;
+    int OW = ((cd->W << up_w) + 2 * pad_w - cd->KW) / cd->stride + 1;
+    if (cd->out_w) {   // fewer output columns than the symmetric padding gives: the caller's right-hand padding is smaller than pad_w (or larger: zero fill)
+      if (cd->out_w < 0 || (cd->out_w - 1) * cd->stride - pad_w >= (cd->W << up_w)) return x2i_set_error(X2I_ERR_SHAPE, "conv: out_w=%d lies outside the input (W=%d pad_w=%d)", cd->out_w, cd->W, pad_w);
+      OW = cd->out_w;
+    }
     if (a->M != OH * OW || a->K != cd->KH * cd->KW * cd->Cin)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: M=%d K=%d do not match OH*OW=%d, KH*KW*Cin=%d", a->M, a->K, OH * OW, cd->KH * cd->KW * cd->Cin);
     if ((long long)cd->H * cd->W * cd->Cin * 2 >= 0x7f000000LL) return x2i_set_error(X2I_ERR_SHAPE, "conv: image too large");

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         for (int ky = 0; ky < KH; ++ky)
           for (int kx = 0; kx < p.cKW; ++kx) {
             const int iy = c_oy[j] + ky, ix = c_ox[j] + kx;
-            if (iy >= 0 && iy < (p.cH << p.cUp) && ix >= 0 && ix < (p.cW << p.cUp)) mask |= 1u << (ky * p.cKW + kx);
+            if (iy >= 0 && iy < (p.cH << (p.cUp & 1)) && ix >= 0 && ix < (p.cW << (p.cUp >> 1))) mask |= 1u << (ky * p.cKW + kx);
           }
       }
       c_mask[j] = mask;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int iy = c_oy[j] + s_ky, ix = c_ox[j] + s_kx;
-        a_voff[j] = ((c_mask[j] >> tap) & 1) ? (uint32_t)((((iy >> 1) * p.cW + (ix >> 1)) * p.cCin + s_c0 + c_cl[j]) * 2) : 0x80000000u;
+        a_voff[j] = ((c_mask[j] >> tap) & 1) ? (uint32_t)((((iy >> (p.cUp & 1)) * p.cW + (ix >> (p.cUp >> 1))) * p.cCin + s_c0 + c_cl[j]) * 2) : 0x80000000u;
       }
     } else {
       const int toff = ((s_ky * p.cW + s_kx) * p.cCin + s_c0) * 2;

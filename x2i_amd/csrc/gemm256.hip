@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
         for (int ky = 0; ky < KH; ++ky)
           for (int kx = 0; kx < p.cKW; ++kx) {
             const int iy = c_oy[jj] + ky, ix = c_ox[jj] + kx;
-            if (iy >= 0 && iy < (p.cH << p.cUp) && ix >= 0 && ix < (p.cW << p.cUp)) mask |= 1u << (ky * p.cKW + kx);
+            if (iy >= 0 && iy < (p.cH << (p.cUp & 1)) && ix >= 0 && ix < (p.cW << (p.cUp >> 1))) mask |= 1u << (ky * p.cKW + kx);
           }
       }
       c_mask[jj] = mask;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int iy = c_oy[jj] + s_ky, ix = c_ox[jj] + s_kx;
-          a_voff[jj] = ((c_mask[jj] >> tap) & 1) ? (uint32_t)((((iy >> 1) * p.cW + (ix >> 1)) * p.cCin + s_c0) * 2 + c_kel) : 0x80000000u;
+          a_voff[jj] = ((c_mask[jj] >> tap) & 1) ? (uint32_t)((((iy >> (p.cUp & 1)) * p.cW + (ix >> (p.cUp >> 1))) * p.cCin + s_c0) * 2 + c_kel) : 0x80000000u;
         }
       } else {
         const int toff = ((s_ky * p.cW + s_kx) * p.cCin + s_c0) * 2 + c_kel;

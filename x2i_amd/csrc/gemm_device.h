@@ -23,7 +23,7 @@ struct GemmP {
   int act, out_f32;
   int tilesM, tilesN;
   // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
-  int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp = 1: nearest-neighbour x2 upsampling fused into the gather
+  int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp: nearest-neighbour x2 upsampling fused into the gather, bit 0 = along H, bit 1 = along W
   int cPadW;                                       // padding along W (cPad: along H)
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0, q_vperm;   // q_vperm: V^T span-permuted (x2i_vt_pos)

@@ -27,7 +27,8 @@ RING = 16           # fragment ring slots (4 accumulator registers each)
 NEG_BIG = "0xf149f2ca"   # -1.0e30f
 ABL = os.environ.get("X2I_ATTN_ABL", "")
 if ABL == "none":
-    ABL = ""            # measurement only (tools/r03_attn_abl.sh): nobar / nosync / nolgk / novalu give wrong results
+    ABL = ""            # measurement only (tools/attn_w16_sweep_build.sh): nobar / nosync / nolgk / novalu / noread / nodma give wrong results
+ABLS = set(filter(None, ABL.split("+")))   # several at once: X2I_ATTN_ABL=novalu+noread+nolgk+nosync+nodma = the MFMA stream alone
 
 # ------------------------------------------------------------------------------------------------ register map
 _v, _a = 32, 0      # v0..v31 belong to the statement's operands
@@ -251,9 +252,9 @@ def n_mfmas(us):
 def sync_wait():
     """Ring hand-over, part 1: every fragment read of this iteration has been issued (and had time to return) above.  Wait for them
     and for this wave's pieces of the tiles the NEXT iteration reads, barrier; the slots this iteration read are free."""
-    if ABL == "nosync":
+    if "nosync" in ABLS:
         return []
-    return ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ([] if ABL == "nobar" else ["s_barrier"])
+    return ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ([] if "nobar" in ABLS else ["s_barrier"])
 
 
 def sync_dma(par):
@@ -264,6 +265,8 @@ def sync_dma(par):
     pairs = [(f"s_add_u32 m0, %[kdst], {par * 0x4000 + j * 4096}", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds") for j in range(4)]
     pairs += [(f"s_add_u32 m0, %[vdst], {par * 0x4000 + j * 4096}", f"buffer_load_dwordx4 %[vd{j}], %[vr], %[so2] offen lds") for j in range(4)]
     post = ["s_add_u32 %[so], %[so], 0x4000", "s_add_u32 %[so2], %[so2], 128"]   # 64 keys x 256 B per K tile; 64 keys x 2 B per V^T row
+    if "nodma" in ABLS:
+        pairs = [(m0, "s_nop 0") for m0, _ in pairs]
     return pairs, post
 
 
@@ -292,7 +295,8 @@ class Stream:
 
     def read_upto_unit(self, L, unit_limit):
         while self.next < min(unit_limit, len(self.us)):
-            L.append(frag_read(self.us[self.next], self.next, self.par))
+            if "noread" not in ABLS:
+                L.append(frag_read(self.us[self.next], self.next, self.par))
             self.q.append(self.next)
             self.next += 1
             assert len(self.q) <= 15
@@ -303,7 +307,7 @@ class Stream:
         assert self.next > k
         tgt = k + 1 if (k % 2 == 0 and (k + 1) in self.q) else k
         pos = self.q.index(tgt)
-        if ABL != "nolgk":
+        if "nolgk" not in ABLS:
             L.append(f"s_waitcnt lgkmcnt({len(self.q) - 1 - pos})")
         self.q = self.q[pos + 1:]
 
@@ -385,7 +389,7 @@ def _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, dry):
         p1 = []
     va = p1 + p2
     total_cost = sum(3 * min(len(e), 8) if isinstance(e, list) else issue_cost(e[2] if isinstance(e, tuple) else e) for e in va)
-    if ABL == "novalu" or dry:      # (novalu: measurement only: the MFMA / LDS / DMA stream alone)
+    if "novalu" in ABLS or dry:      # (novalu: measurement only: the MFMA / LDS / DMA stream alone)
         va = []
     decide_at = max([k for k, e in enumerate(va) if isinstance(e, list)], default=-1)
     vi = 0

@@ -9,6 +9,7 @@ around them, the single-head 512-wide mid-block attention runs as two GEMMs arou
 (S = q k^T is materialised: 512 MiB per 1024^2 image, once per image).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -27,6 +28,7 @@ class _Conv(nn.Module):
         self.weight = _p(cout, cin, k, k, device=device)
         self.bias = _p(cout, device=device)
         self._packed = None
+        self._phases = None
 
     def packed(self, cin_pad=None, cout_pad=None):
         """[Cout, ky, kx, Cin] bf16; optionally zero-padded along Cin (16 -> 64) or Cout."""
@@ -41,6 +43,21 @@ class _Conv(nn.Module):
                 b = torch.nn.functional.pad(b, (0, cout_pad - b.shape[0]))
             self._packed = (w.reshape(w.shape[0], -1).contiguous(), b.contiguous(), key)
         return self._packed[0], self._packed[1]
+
+    def packed_up_phases(self):
+        """Upsample2D's conv (nearest x2, then 3 x 3, padding 1) in its COLUMN-PHASE form: output column 2x + px of the doubled grid sees the
+        source columns {x - 1, x} (px = 0) or {x, x + 1} (px = 1) only -- two of the three taps of every filter row read the same source
+        pixel -- so each phase is a 3 x 2 convolution whose coinciding taps' weights are added (in f32, rounded to bf16 once):
+        6/9 of the multiply-adds, no doubled tensor.  Returns (w_px0, w_px1, bias), w_px*: bf16 [Cout, 3 * 2 * Cin] in (ky, kx, ci) order.
+        (The rows stay in the fused-upsample gather, x2i_conv_desc.up = 2: a row split would need a doubled output row pitch.)"""
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), "up_phases")
+        if getattr(self, "_phases", None) is None or self._phases[3] != key:
+            w = self.weight.float().permute(0, 2, 3, 1)                       # [Cout, ky, kx, Cin]
+            w0 = torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 2)         # px = 0: source columns x - 1, x
+            w1 = torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2)         # px = 1: source columns x, x + 1
+            pk = lambda t: t.to(torch.bfloat16).reshape(t.shape[0], -1).contiguous()   # noqa: E731
+            self._phases = (pk(w0), pk(w1), self.bias.contiguous(), key)
+        return self._phases[:3]
 
 
 class _Vec(nn.Module):
@@ -195,12 +212,16 @@ class AutoencoderKL(nn.Module):
         if any(c % 64 for c in block_out_channels):
             raise ValueError("x2i_amd VAE: block_out_channels must be multiples of 64 (implicit-GEMM conv)")
         self.decoder = _Decoder(self.config, device)
+        # X2I_VAE_UP_PHASES=0 (read once, here): Upsample2D's conv as ONE 3 x 3 conv with the x2 upsampling in its gather (A/B; the product form
+        # is the column-phase pair of _Conv.packed_up_phases: same result within the tolerance of one more bf16 rounding of summed weights)
+        self.up_phases = os.environ.get("X2I_VAE_UP_PHASES", "1") != "0"
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
         for m in self.modules():
             if isinstance(m, _Conv):
                 m._packed = None
+                m._phases = None
         return r
 
     def load_state_dict(self, sd, strict=True):
@@ -228,8 +249,17 @@ class AutoencoderKL(nn.Module):
             for j in range(len(blk.resnets)):
                 x = blk.resnets[j].run(x, H, W, G)
             if hasattr(blk, "upsamplers"):
-                w, b = blk.upsamplers[0].conv.packed()
-                x = ops.conv2d_nhwc(x, w, b, H, W, co, co, 3, 3, 1, 1, up=True)  # F.interpolate(nearest, x2) + conv
+                if self.up_phases:
+                    # F.interpolate(nearest, x2) + conv as two 3 x 2 column-phase convolutions on the un-doubled columns (6/9 of the work)
+                    w0, w1, b = blk.upsamplers[0].conv.packed_up_phases()
+                    y = torch.empty((B, 2 * H, 2 * W, co), device=x.device, dtype=torch.bfloat16)
+                    for px, wp in ((0, w0), (1, w1)):
+                        ops.conv2d_nhwc(x, wp, b, H, W, co, co, 3, 2, 1, 1, up=2, pad_w=1 - px, out_w=W, out=y, ldc=2 * co, c_offset=px * co,
+                                        c_batch_stride=4 * H * W * co)
+                    x = y
+                else:
+                    w, b = blk.upsamplers[0].conv.packed()
+                    x = ops.conv2d_nhwc(x, w, b, H, W, co, co, 3, 3, 1, 1, up=True)  # F.interpolate(nearest, x2) + conv, fused gather
                 H, W = 2 * H, 2 * W
         n = ops.groupnorm_nhwc(x, d.conv_norm_out.weight, d.conv_norm_out.bias, G, 1e-6, act=ACT_SILU)
         w, b = d.conv_out.packed(cout_pad=8)  # 3 -> 8 output channels so that rows are 16-byte aligned
