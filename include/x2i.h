@@ -22,7 +22,7 @@
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
  *   - ABI version 3 (x2i_abi_version).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
- *     zero-initialised descriptor means what it meant in version 1), appends `out_w` (0 = computed) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
+ *     zero-initialised descriptor means what it meant in version 1), appends `out_w`, `out_h`, `out_row_pitch` (0 = computed / dense) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
  *     library (x2i_amd/_lib.py checks).
  */
 #ifndef X2I_H
@@ -182,6 +182,10 @@ typedef struct x2i_conv_desc {
                      * along W is pad_w_p1 - 1 and `pad` is the padding along H (nn.Conv2d(padding=(pad, pad_w_p1 - 1))) */
   int32_t out_w;    /* 0: the output has (W' + 2 pad_w - KW) / stride + 1 columns (W' = W, or 2 W with up = 1).  Otherwise: exactly out_w columns --
                      * left padding pad_w, right padding whatever out_w implies (zero fill): asymmetric padding, M = OH * out_w */
+  int32_t out_h;    /* the same for the rows: 0 = computed; otherwise out_h output rows (top padding `pad`, bottom padding implied) */
+  int32_t out_row_pitch; /* 0: output row oy of a batch item starts at C + oy * OW * ldc (dense).  Otherwise at C + oy * out_row_pitch (elements,
+                          * multiple of 8): with ldc = 2 Cout and a pitch of two full rows, the four (row, column) phases of an upsampling
+                          * convolution interleave into one NHWC tensor.  Plain bf16 epilogue only (no residual / second output / f32) */
 } x2i_conv_desc;
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
 

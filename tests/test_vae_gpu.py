@@ -69,6 +69,19 @@ def test_upsample_conv_column_phase_form(C, Co, H, W):
     e_phase, e_fused = rel_l2(y.permute(0, 3, 1, 2), ref), rel_l2(fused.permute(0, 3, 1, 2), ref)
     assert e_phase < 1e-2 and e_phase < 2.0 * e_fused + 1e-3, (e_phase, e_fused)
     assert rel_l2(y, fused) < 1e-2
+    # all four (row, column) phases: 2 x 2 taps on the un-doubled image, interleaved through ldc = 2 Cout and x2i_conv_desc.out_row_pitch,
+    # top / left padding 1 - py / 1 - px, bottom / right implied by out_h / out_w
+    wp, bb = conv.packed_up_phases(rows=True)
+    y4 = torch.zeros((B, 2 * H, 2 * W, Co), device=DEV, dtype=torch.bfloat16)
+    for py in (0, 1):
+        for px in (0, 1):
+            ops.conv2d_nhwc(xn, wp[py][px], bb, H, W, C, Co, 2, 2, 1, 1 - py, pad_w=1 - px, out_h=H, out_w=W, out=y4, ldc=2 * Co,
+                            out_row_pitch=4 * W * Co, c_offset=(py * 2 * W + px) * Co, c_batch_stride=4 * H * W * Co)
+            if (py, px) == (0, 0):   # only this phase's pixels are written
+                assert float(y4[:, 1::2].float().abs().max()) == 0.0 and float(y4[:, :, 1::2].float().abs().max()) == 0.0
+    e4 = rel_l2(y4.permute(0, 3, 1, 2), ref)
+    assert e4 < 1e-2 and e4 < 2.0 * e_fused + 1e-3, (e4, e_fused)
+    assert rel_l2(y4, fused) < 1e-2
 
 
 def test_groupnorm_four_channels_per_group():
@@ -104,9 +117,10 @@ def test_vae_decode_vs_oracle_reduced_width():
     ref = OV.vae_decode({k: rb(v) for k, v in sd.items()}, rb(z), cfg)
     assert img.shape == ref.shape == (2, 3, 64, 96)
     assert rel_l2(img, ref) < 3e-2
-    vae.up_phases = False     # Upsample2D's conv as one fused-gather 3 x 3 conv (A/B form): same image within the same bound
-    img1 = vae.decode(z.to(DEV), return_dict=False)[0]
-    assert rel_l2(img1, ref) < 3e-2 and rel_l2(img, img1) < 2e-2
+    for form in (0, 1):       # Upsample2D's conv as one fused-gather 3 x 3 conv / as two column phases (A/B forms): same image within the same bound
+        vae.up_phases = form
+        img1 = vae.decode(z.to(DEV), return_dict=False)[0]
+        assert rel_l2(img1, ref) < 3e-2 and rel_l2(img, img1) < 2e-2
 
 
 def test_vae_decode_flux_config_small_latent():

@@ -40,7 +40,8 @@ class GemmArgs(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
-                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32), ("pad_w_p1", C.c_int32), ("out_w", C.c_int32)]
+                ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32), ("pad_w_p1", C.c_int32), ("out_w", C.c_int32), ("out_h", C.c_int32),
+                ("out_row_pitch", C.c_int32)]
 
 
 class QkvDesc(C.Structure):

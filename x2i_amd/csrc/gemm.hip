@@ -72,7 +72,7 @@ static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0;
   p.gm = 4;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
@@ -223,7 +223,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     const int up_h = cd->up ? 1 : 0, up_w = cd->up == 1 ? 1 : 0, up = up_h | (up_w << 1);
     const int pad_w = cd->pad_w_p1 <= 0 ? cd->pad : cd->pad_w_p1 - 1;
     if (cd->KH * cd->KW > 32) return x2i_set_error(X2I_ERR_SHAPE, "conv: at most 32 filter taps (KH=%d KW=%d)", cd->KH, cd->KW);
-    const int OH = ((cd->H << up_h) + 2 * cd->pad - cd->KH) / cd->stride + 1;
+    int OH = ((cd->H << up_h) + 2 * cd->pad - cd->KH) / cd->stride + 1;
+    if (cd->out_h) {
+      if (cd->out_h < 0 || (cd->out_h - 1) * cd->stride - cd->pad >= (cd->H << up_h)) return x2i_set_error(X2I_ERR_SHAPE, "conv: out_h=%d lies outside the input (H=%d pad=%d)", cd->out_h, cd->H, cd->pad);
+      OH = cd->out_h;
+    }
     int OW = ((cd->W << up_w) + 2 * pad_w - cd->KW) / cd->stride + 1;
     if (cd->out_w) {   // fewer output columns than the symmetric padding gives: the caller's right-hand padding is smaller than pad_w (or larger: zero fill)
       if (cd->out_w < 0 || (cd->out_w - 1) * cd->stride - pad_w >= (cd->W << up_w)) return x2i_set_error(X2I_ERR_SHAPE, "conv: out_w=%d lies outside the input (W=%d pad_w=%d)", cd->out_w, cd->W, pad_w);
@@ -233,6 +237,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       return x2i_set_error(X2I_ERR_SHAPE, "conv: M=%d K=%d do not match OH*OW=%d, KH*KW*Cin=%d", a->M, a->K, OH * OW, cd->KH * cd->KW * cd->Cin);
     if ((long long)cd->H * cd->W * cd->Cin * 2 >= 0x7f000000LL) return x2i_set_error(X2I_ERR_SHAPE, "conv: image too large");
     p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad; p.cPadW = pad_w; p.cUp = up;
+    if (cd->out_row_pitch) {
+      if (cd->out_row_pitch < (long long)(OW - 1) * a->ldc + a->N || (cd->out_row_pitch & 7) || a->res || a->C2 || a->out_f32)
+        return x2i_set_error(X2I_ERR_SHAPE, "conv: out_row_pitch=%d must hold a row of %d pixels at ldc=%d, be a multiple of 8, and goes with the plain bf16 epilogue only", cd->out_row_pitch, OW, (int)a->ldc);
+      p.cRowPitch = cd->out_row_pitch;
+    }
   }
   p.tilesM = (a->M + BM - 1) / BM; p.tilesN = (a->N + BN - 1) / BN;
   const bool fast = (a->K % BK == 0) && (conv || a->lda % 8 == 0) && (a->ldw % 8 == 0) && (((uintptr_t)a->A & 15) == 0) &&
@@ -476,7 +485,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = 0;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   if (qd) {

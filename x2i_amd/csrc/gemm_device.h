@@ -25,6 +25,7 @@ struct GemmP {
   // implicit-GEMM convolution view of A (NHWC input [batch][cH][cW][cCin], K ordered [ky][kx][ci]); cCin % 64 == 0
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp: nearest-neighbour x2 upsampling fused into the gather, bit 0 = along H, bit 1 = along W
   int cPadW;                                       // padding along W (cPad: along H)
+  int cRowPitch;                                   // conv: elements between two output ROWS of C (0 = cOW * ldc, dense): x2i_conv_desc.out_row_pitch
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0, q_vperm;   // q_vperm: V^T span-permuted (x2i_vt_pos)
   int gm;
@@ -99,6 +100,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // Shared epilogue: the wave owns MT x NT 16x16 accumulator tiles; lane owns row m = mrow + i*16 and the four
 // consecutive columns n = ncol + j*16 + 0..3 of each tile (operands were swapped in the MFMA).
+// element offset of output row m inside one batch item of C: m * ldc, or -- convolutions with an output row pitch (x2i_conv_desc.out_row_pitch:
+// the phases of an upsampling convolution interleave in rows AND columns) -- (m / OW) * pitch + (m % OW) * ldc
+__device__ __forceinline__ long long c_row_off(const GemmP& p, int m) {
+  if (p.cRowPitch) {
+    const int oy = m / p.cOW;
+    return (long long)oy * p.cRowPitch + (long long)(m - oy * p.cOW) * p.ldc;
+  }
+  return (long long)m * p.ldc;
+}
+
 template <int ACT, bool RES, bool OUTF32, bool HASC2, int MT, int NT>
 __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT][NT], int z, int mrow, int ncol) {
   // ---- epilogue: lane owns m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4 + 0..3
@@ -143,7 +154,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bv[r], ACT);
-          const long long coff = (long long)z * p.c_bs + (long long)m * p.ldc + n;
+          const long long coff = (long long)z * p.c_bs + c_row_off(p, m) + n;
           if (full) {
             if constexpr (RES) {
               const uint2 r2 = *(const uint2*)(rz + (long long)m * p.ldr + n);
@@ -258,7 +269,7 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
         const int row = it * 8 + srow;
         const bf16x8_t d = *(const bf16x8_t*)(wave_lds + it * 1024 + lane * 16);
         const int m = m_wave + row, n = n_wave + ((sch ^ ((row >> 1) & 7)) << 3);
-        if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(Cz + (long long)m * p.ldc + n) = d;
+        if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(Cz + c_row_off(p, m) + n) = d;
       }
       return;
     }
@@ -316,7 +327,7 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
       const int row = it * 8 + (lane >> 3), c = lane & 7;
       const bf16x8_t d = *(const bf16x8_t*)(wave_lds + row * EPI_ROW_BYTES + c * 16);
       const int m = m_wave + row, n = n_wave + c * 8;
-      if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + (long long)m * p.ldc + n) = d;
+      if (m < p.M && n + 7 < p.N) *(bf16x8_t*)(dst + c_row_off(p, m) + n) = d;
     }
     if (NPASS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }

@@ -414,11 +414,12 @@ from ._lib import ACT_RELU, ConvDesc  # noqa: E402
 
 def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=None, act=ACT_NONE, bias2=None, res=None,
                 c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None, up=False, pad_w=None, B=None,
-                a_batch_stride=None, a_offset=0, out_w=None):
+                a_batch_stride=None, a_offset=0, out_w=None, out_h=None, out_row_pitch=0):
     """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout].
     pad_w: padding along W when it differs from `pad` (along H).  B / a_batch_stride / a_offset: the input is a window of `H` rows of a
     larger NHWC tensor (elements between two images / in front of the window).  up: True / 1 = nearest x2 upsampling in front of the conv,
-    2 = along H only; out_w: number of output columns when the right-hand padding differs from pad_w (include/x2i.h: x2i_conv_desc)."""
+    2 = along H only; out_w / out_h: number of output columns / rows when the right-hand / bottom padding differs from pad_w / pad;
+    out_row_pitch: elements between two output rows when they are not dense (include/x2i.h: x2i_conv_desc)."""
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")
     _req(w_packed, torch.bfloat16, "w")
@@ -426,7 +427,7 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     up = int(up)
     uh, uw = (2 if up else 1), (2 if up == 1 else 1)  # nearest-neighbour x2 upsampling fused in front of the conv
     pw = pad if pad_w is None else pad_w
-    OH = (H * uh + 2 * pad - KH) // stride + 1
+    OH = (H * uh + 2 * pad - KH) // stride + 1 if out_h is None else out_h
     OW = (W * uw + 2 * pw - KW) // stride + 1 if out_w is None else out_w
     if out is None:
         out = torch.empty((B, OH, OW, Cout), device=x.device, dtype=torch.bfloat16)
@@ -451,7 +452,8 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     a.act = act
     a.out_f32 = 0
     a.w_batch_stride = 0
-    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, up, 0 if pad_w is None else pad_w + 1, 0 if out_w is None else out_w)
+    d = ConvDesc(H, W, Cin, KH, KW, stride, pad, up, 0 if pad_w is None else pad_w + 1, 0 if out_w is None else out_w,
+                 0 if out_h is None else out_h, out_row_pitch)
     check(lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(d), _stream()), "conv2d_nhwc")
     return out
 

@@ -44,20 +44,28 @@ class _Conv(nn.Module):
             self._packed = (w.reshape(w.shape[0], -1).contiguous(), b.contiguous(), key)
         return self._packed[0], self._packed[1]
 
-    def packed_up_phases(self):
-        """Upsample2D's conv (nearest x2, then 3 x 3, padding 1) in its COLUMN-PHASE form: output column 2x + px of the doubled grid sees the
-        source columns {x - 1, x} (px = 0) or {x, x + 1} (px = 1) only -- two of the three taps of every filter row read the same source
-        pixel -- so each phase is a 3 x 2 convolution whose coinciding taps' weights are added (in f32, rounded to bf16 once):
-        6/9 of the multiply-adds, no doubled tensor.  Returns (w_px0, w_px1, bias), w_px*: bf16 [Cout, 3 * 2 * Cin] in (ky, kx, ci) order.
-        (The rows stay in the fused-upsample gather, x2i_conv_desc.up = 2: a row split would need a doubled output row pitch.)"""
-        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), "up_phases")
-        if getattr(self, "_phases", None) is None or self._phases[3] != key:
-            w = self.weight.float().permute(0, 2, 3, 1)                       # [Cout, ky, kx, Cin]
-            w0 = torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 2)         # px = 0: source columns x - 1, x
-            w1 = torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2)         # px = 1: source columns x, x + 1
+    def packed_up_phases(self, rows=False):
+        """Upsample2D's conv (nearest x2, then 3 x 3, padding 1) in PHASE form: output column 2x + px of the doubled grid sees the source
+        columns {x - 1, x} (px = 0) or {x, x + 1} (px = 1) only -- two of the three taps of every filter row read the same source pixel --
+        and likewise output row 2y + py the source rows {y - 1, y} / {y, y + 1}.  A phase is a small convolution on the UN-doubled image
+        whose coinciding taps' weights are added (in f32, rounded to bf16 once); no doubled tensor exists.
+        rows = False: the two column phases, 3 x 2 taps with the rows still doubled in the gather (x2i_conv_desc.up = 2), 6/9 of the
+        multiply-adds: returns (w_px0, w_px1, bias), bf16 [Cout, 3 * 2 * Cin] in (ky, kx, ci) order.
+        rows = True: all four (py, px) phases, 2 x 2 taps, 4/9 of the multiply-adds (the phases interleave through ldc = 2 Cout and
+        x2i_conv_desc.out_row_pitch): returns ([[w00, w01], [w10, w11]], bias), bf16 [Cout, 2 * 2 * Cin]."""
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), "up_phases", rows)
+        if getattr(self, "_phases", None) is None or self._phases[-1] != key:
+            w = self.weight.float().permute(0, 2, 3, 1)                         # [Cout, ky, kx, Cin]
+            cols = [torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 2),       # px = 0: source columns x - 1, x
+                    torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2)]       # px = 1: source columns x, x + 1
             pk = lambda t: t.to(torch.bfloat16).reshape(t.shape[0], -1).contiguous()   # noqa: E731
-            self._phases = (pk(w0), pk(w1), self.bias.contiguous(), key)
-        return self._phases[:3]
+            if rows:
+                both = [[torch.stack([c[:, 0], c[:, 1] + c[:, 2]], 1) for c in cols],    # py = 0: source rows y - 1, y
+                        [torch.stack([c[:, 0] + c[:, 1], c[:, 2]], 1) for c in cols]]    # py = 1: source rows y, y + 1
+                self._phases = ([[pk(t) for t in r] for r in both], self.bias.contiguous(), key)
+            else:
+                self._phases = (pk(cols[0]), pk(cols[1]), self.bias.contiguous(), key)
+        return self._phases[:-1]
 
 
 class _Vec(nn.Module):
@@ -212,9 +220,10 @@ class AutoencoderKL(nn.Module):
         if any(c % 64 for c in block_out_channels):
             raise ValueError("x2i_amd VAE: block_out_channels must be multiples of 64 (implicit-GEMM conv)")
         self.decoder = _Decoder(self.config, device)
-        # X2I_VAE_UP_PHASES=0 (read once, here): Upsample2D's conv as ONE 3 x 3 conv with the x2 upsampling in its gather (A/B; the product form
-        # is the column-phase pair of _Conv.packed_up_phases: same result within the tolerance of one more bf16 rounding of summed weights)
-        self.up_phases = os.environ.get("X2I_VAE_UP_PHASES", "1") != "0"
+        # X2I_VAE_UP_PHASES (read once, here): how Upsample2D's conv runs -- 2 (product): four 2 x 2 phase convolutions on the un-doubled image;
+        # 1: two 3 x 2 column phases; 0: ONE 3 x 3 conv with the x2 upsampling in its gather.  Same result within the tolerance of one more
+        # bf16 rounding of summed weights (_Conv.packed_up_phases; tests/test_vae_gpu.py)
+        self.up_phases = int(os.environ.get("X2I_VAE_UP_PHASES", "2"))
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
@@ -249,10 +258,19 @@ class AutoencoderKL(nn.Module):
             for j in range(len(blk.resnets)):
                 x = blk.resnets[j].run(x, H, W, G)
             if hasattr(blk, "upsamplers"):
-                if self.up_phases:
-                    # F.interpolate(nearest, x2) + conv as two 3 x 2 column-phase convolutions on the un-doubled columns (6/9 of the work)
+                y = torch.empty((B, 2 * H, 2 * W, co), device=x.device, dtype=torch.bfloat16) if self.up_phases else None
+                if self.up_phases == 2:
+                    # F.interpolate(nearest, x2) + conv as four 2 x 2 phase convolutions on the un-doubled image (4/9 of the work): phase
+                    # (py, px) writes the pixels (2y + py, 2x + px): column stride 2 Cout, row pitch two full rows
+                    wp, b = blk.upsamplers[0].conv.packed_up_phases(rows=True)
+                    for py in (0, 1):
+                        for px in (0, 1):
+                            ops.conv2d_nhwc(x, wp[py][px], b, H, W, co, co, 2, 2, 1, 1 - py, pad_w=1 - px, out_h=H, out_w=W, out=y, ldc=2 * co,
+                                            out_row_pitch=4 * W * co, c_offset=(py * 2 * W + px) * co, c_batch_stride=4 * H * W * co)
+                    x = y
+                elif self.up_phases:
+                    # ... as two 3 x 2 column-phase convolutions, the rows doubled in the gather (6/9 of the work; A/B form)
                     w0, w1, b = blk.upsamplers[0].conv.packed_up_phases()
-                    y = torch.empty((B, 2 * H, 2 * W, co), device=x.device, dtype=torch.bfloat16)
                     for px, wp in ((0, w0), (1, w1)):
                         ops.conv2d_nhwc(x, wp, b, H, W, co, co, 3, 2, 1, 1, up=2, pad_w=1 - px, out_w=W, out=y, ldc=2 * co, c_offset=px * co,
                                         c_batch_stride=4 * H * W * co)
