@@ -298,10 +298,17 @@ def vae_decode_line(B, images_s_denoise, passes=3):
     torch.cuda.synchronize()
     ms_img = e0.elapsed_time(e1) / passes / B
     fl = decode_flops(vae.config, 128, 128)
+    fl_exec = decode_flops(vae.config, 128, 128, up_phases=vae.up_phases)
+    form = {0: "one 3x3 conv, x2 upsampling in the gather", 1: "two 3x2 column phases", 2: "four 2x2 phases"}[vae.up_phases]
+    moments = vae.epilogue_moments
     del vae
-    return dict(ms_per_image=ms_img, flop_per_image=fl, achieved=fl / (ms_img * 1e-3) / 1e12, unit="TFLOP/s", frac=fl / (ms_img * 1e-3) / PEAK_BF16,
+    return dict(ms_per_image=ms_img, flop_per_image=fl, flop_executed_per_image=fl_exec, achieved=fl / (ms_img * 1e-3) / 1e12, unit="TFLOP/s",
+                frac=fl / (ms_img * 1e-3) / PEAK_BF16, frac_executed=fl_exec / (ms_img * 1e-3) / PEAK_BF16,
                 images_s_incl_decode=1.0 / (1.0 / images_s_denoise + ms_img * 1e-3), measured="live (HIP events, this run)", batch=B,
-                note="FLUX VAE decoder at 1024^2, random-init weights; outside the timed region of `value` (BASELINE metric = projector + denoise loop)")
+                upsample_conv_form=form, groupnorm_statistics="conv epilogue moments" if moments else "statistics pass per GroupNorm",
+                note="FLUX VAE decoder at 1024^2, random-init weights; outside the timed region of `value` (BASELINE metric = projector + denoise loop). "
+                     "flop_per_image / frac: the reference formulation's FLOPs (a 3x3 conv on the doubled image per Upsample2D); "
+                     "flop_executed_per_image: what the phase form of those convs executes")
 
 
 def gemm_roofline_fp8(B, rounds=6, per_round=8):

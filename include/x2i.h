@@ -22,7 +22,7 @@
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
  *   - ABI version 3 (x2i_abi_version).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
- *     zero-initialised descriptor means what it meant in version 1), appends `out_w`, `out_h`, `out_row_pitch` (0 = computed / dense) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
+ *     zero-initialised descriptor means what it meant in version 1), appends `out_w`, `out_h`, `out_row_pitch` (0 = computed / dense) and the `moments` fields (NULL = off) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
  *     library (x2i_amd/_lib.py checks).
  */
 #ifndef X2I_H
@@ -186,8 +186,18 @@ typedef struct x2i_conv_desc {
   int32_t out_row_pitch; /* 0: output row oy of a batch item starts at C + oy * OW * ldc (dense).  Otherwise at C + oy * out_row_pitch (elements,
                           * multiple of 8): with ldc = 2 Cout and a pitch of two full rows, the four (row, column) phases of an upsampling
                           * convolution interleave into one NHWC tensor.  Plain bf16 epilogue only (no residual / second output / f32) */
+  int32_t moments_accumulate; /* 1: add this launch's moments to `moments` instead of overwriting them (the phases of one tensor) */
+  int32_t reserved0;          /* 0 */
+  float* moments;         /* NULL, or f32 [batch][N][2]: (sum, sum of squares) of the bf16 outputs over the M pixels of each batch item, per channel
+                           * QUAD: entry [c] with c % 4 == 0 holds the sums over channels c .. c+3, the other three entries are zero -- what
+                           * x2i_groupnorm_nhwc_from_moments_bf16 needs when its groups are whole quads and it has no per-channel pre_add (group
+                           * sums are sums of quads).  Written by the epilogue (per-row-block sums, added in a fixed order by two small kernels:
+                           * deterministic), so the GroupNorm behind the conv needs no statistics pass.  Needs the whole-line bf16 epilogue (N,
+                           * ldc, c_batch_stride multiples of 8, 16-byte aligned C) */
+  float* moments_scratch; /* caller-owned, x2i_conv_moments_scratch_floats(M, N, batch) floats, 16-byte aligned (required with `moments`) */
 } x2i_conv_desc;
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
+int64_t x2i_conv_moments_scratch_floats(int32_t M, int32_t N, int32_t batch);
 
 /* Conv2d(3 -> Cout, k=3, stride=2, pad=1) on an NHWC bf16 image (lightcontrol_flux.py:594); w f32 [Cout][3][3][3]
  * (ky,kx,ci), bias f32 [Cout]; y NHWC bf16 [B][H/2][W/2][Cout], Cout % 16 == 0 and <= 64. */

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/x2i.h but not exported by libx2i_hip.so"
     bound = set(_lib.SIGNATURES) | {"x2i_abi_version", "x2i_last_error", "x2i_is_ablation_build", "x2i_groupnorm_scratch_floats",
-                                    "x2i_streamk_workspace_bytes", "x2i_groupnorm_moments_scratch_floats"}
+                                    "x2i_streamk_workspace_bytes", "x2i_groupnorm_moments_scratch_floats", "x2i_conv_moments_scratch_floats"}
     assert declared == bound, (declared ^ bound)
     ver = int(re.search(r"#define X2I_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 3   # header, library and binding move together

@@ -84,6 +84,39 @@ def test_upsample_conv_column_phase_form(C, Co, H, W):
     assert rel_l2(y4, fused) < 1e-2
 
 
+@pytest.mark.parametrize("C,Co,H,W,res", [(64, 128, 20, 24, False), (128, 256, 40, 48, False), (128, 256, 33, 40, True), (64, 128, 17, 23, True),
+                                          (256, 512, 32, 32, False)])
+def test_conv_epilogue_channel_moments(C, Co, H, W, res):
+    """x2i_conv_desc.moments: the conv epilogue's (sum, sum of squares) of the bf16 outputs per channel quad -- both tile kernels (Cout = 128: 128^2,
+    Cout >= 256 with >= 1024 pixels: 256^2), ragged last tiles, with and without the residual epilogue, accumulation over two launches -- against the
+    sums of the stored tensor, bit-reproducible, and feeding groupnorm_nhwc_from_moments = groupnorm_nhwc of the same tensor."""
+    from x2i_amd import ops
+    B = 2
+    x = bf(seeded((B, H, W, C), 21)).to(DEV)
+    w = bf(seeded((Co, 3, 3, C), 22) / 24).reshape(Co, -1).contiguous().to(DEV)
+    b = bf(seeded((Co,), 23)).to(DEV)
+    r = bf(seeded((B, H, W, Co), 24)).to(DEV) if res else None
+    mom = torch.full((B, Co, 2), 7.0, device=DEV)
+    y = ops.conv2d_nhwc(x, w, b, H, W, C, Co, 3, 3, 1, 1, res=r, moments=mom)
+    y0 = ops.conv2d_nhwc(x, w, b, H, W, C, Co, 3, 3, 1, 1, res=r)
+    assert torch.equal(y, y0)                                             # the outputs do not change
+    yf = y.float().reshape(B, H * W, Co)
+    want = torch.stack([yf.sum(1), (yf * yf).sum(1)], -1)                 # per channel ...
+    quad = want.reshape(B, Co // 4, 4, 2).sum(2)
+    want = torch.zeros_like(want)
+    want[:, 0::4] = quad                                                  # ... stored per channel quad (entry c % 4 == 0), zeros elsewhere
+    assert float((mom - want).abs().max() / want.abs().max()) < 2e-5
+    mom2 = torch.zeros_like(mom)
+    ops.conv2d_nhwc(x, w, b, H, W, C, Co, 3, 3, 1, 1, res=r, moments=mom2)
+    assert torch.equal(mom, mom2)                                         # fixed summation order
+    ops.conv2d_nhwc(x, w, b, H, W, C, Co, 3, 3, 1, 1, res=r, moments=mom2, moments_accumulate=True)
+    assert float((mom2 - 2 * want).abs().max() / want.abs().max()) < 4e-5
+    gw, gb = bf(1 + 0.1 * seeded((Co,), 25)).to(DEV), bf(0.1 * seeded((Co,), 26)).to(DEV)
+    a1 = ops.groupnorm_nhwc_from_moments(y, mom, gw, gb, 32, 1e-6, act=3)
+    a0 = ops.groupnorm_nhwc(y, gw, gb, 32, 1e-6, act=3)
+    assert rel_l2(a1, a0) < 2e-3
+
+
 def test_groupnorm_four_channels_per_group():
     from x2i_amd import ops
     x, w, b = bf(seeded((2, 128, 9, 11), 4, 2.0) + 0.2), bf(1 + 0.1 * seeded((128,), 5)), bf(0.1 * seeded((128,), 6))
@@ -121,6 +154,9 @@ def test_vae_decode_vs_oracle_reduced_width():
         vae.up_phases = form
         img1 = vae.decode(z.to(DEV), return_dict=False)[0]
         assert rel_l2(img1, ref) < 3e-2 and rel_l2(img, img1) < 2e-2
+    vae.up_phases, vae.epilogue_moments = 2, False     # every GroupNorm with a statistics pass of its own (A/B form)
+    img2 = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert rel_l2(img2, ref) < 3e-2 and rel_l2(img, img2) < 2e-2
 
 
 def test_vae_decode_flux_config_small_latent():

@@ -41,7 +41,8 @@ class GemmArgs(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
                 ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32), ("pad_w_p1", C.c_int32), ("out_w", C.c_int32), ("out_h", C.c_int32),
-                ("out_row_pitch", C.c_int32)]
+                ("out_row_pitch", C.c_int32), ("moments_accumulate", C.c_int32), ("reserved0", C.c_int32),
+                ("moments", C.c_void_p), ("moments_scratch", C.c_void_p)]
 
 
 class QkvDesc(C.Structure):
@@ -142,6 +143,9 @@ def load():
     lib.x2i_is_ablation_build.restype = C.c_int
     lib.x2i_groupnorm_moments_scratch_floats.argtypes = [_i32, _i32]
     lib.x2i_groupnorm_moments_scratch_floats.restype = C.c_int64
+    if not (_VARIANT and not hasattr(lib, "x2i_conv_moments_scratch_floats")):   # (tools only: a variant library built from an older commit)
+        lib.x2i_conv_moments_scratch_floats.argtypes = [_i32, _i32, _i32]
+        lib.x2i_conv_moments_scratch_floats.restype = C.c_int64
     lib.x2i_streamk_workspace_bytes.argtypes = []
     lib.x2i_streamk_workspace_bytes.restype = C.c_int64
     for name, argtypes in SIGNATURES.items():

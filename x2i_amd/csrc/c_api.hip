@@ -222,6 +222,7 @@ int x2i_ln_modulate_fp8(const void* X, int64_t x_bs, int32_t ldx, void* Y, int64
                                     mod_bs, eps, (hipStream_t)stream);
 }
 
+int64_t x2i_conv_moments_scratch_floats(int32_t M, int32_t N, int32_t batch) { return (M > 0 && N > 0 && batch > 0) ? x2i_conv_moments_scratch(M, N, batch) : 0; }
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream) {
   if (!conv) return x2i_set_error(X2I_ERR_ARG, "conv2d: null descriptor");
   return x2i_launch_gemm_conv(args, conv, (hipStream_t)stream);

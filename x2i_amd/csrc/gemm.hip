@@ -72,7 +72,7 @@ static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0; p.cMom = nullptr; p.cMomBlocks = 0;
   p.gm = 4;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
@@ -209,6 +209,65 @@ int x2i_launch_gemm_pair(const x2i_gemm_args* a0, const x2i_qkv_desc* q0, const 
   return x2i_check_launch("gemm_pair");
 }
 
+// ---- channel moments from the conv epilogue (x2i_conv_desc.moments): the kernels write per-row-block sums (gemm_device.h: mom_flush), two small
+// passes add them in a fixed order: MOM_SLABS slabs of row blocks, then the slabs (+ the caller's running moments when accumulating)
+constexpr int MOM_SLABS = 64;
+// Sum of rows [r0, r1) of a row-major f32 matrix with n2 <= 1024 columns (n2 % 4 == 0), by one 256-thread block: n2 / 4 lanes of 16 bytes per
+// row, 256 / lanes row groups side by side (four loads in flight each), the groups added through LDS in a fixed order: deterministic.  The sum
+// of columns 4l .. 4l+3 is returned to thread l < n2 / 4.  (The first form -- one thread per column walking all its rows -- ran at the latency
+// of one load per row: 27 + 17 us per convolution, as much as the statistics pass it replaces.)
+__device__ __forceinline__ f32x4_t mom_block_sum(const float* __restrict__ src, int r0, int r1, int n2, f32x4_t* red) {
+  const int lanes = n2 >> 2, groups = 256 / lanes;
+  const int l = threadIdx.x % lanes, g = threadIdx.x / lanes;
+  f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (g < groups) {
+    const float* p = src + 4 * l;
+    int rb = r0 + g;
+    for (; rb + 3 * groups < r1; rb += 4 * groups) {
+      a0 += *(const f32x4_t*)(p + (long long)rb * n2);
+      a1 += *(const f32x4_t*)(p + (long long)(rb + groups) * n2);
+      a2 += *(const f32x4_t*)(p + (long long)(rb + 2 * groups) * n2);
+      a3 += *(const f32x4_t*)(p + (long long)(rb + 3 * groups) * n2);
+    }
+    for (; rb < r1; rb += groups) a0 += *(const f32x4_t*)(p + (long long)rb * n2);
+  }
+  f32x4_t v = (a0 + a1) + (a2 + a3);
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (g == 0)
+    for (int gg = 1; gg < groups; ++gg) v += red[gg * lanes + l];
+  return v;
+}
+// partial sums f32 [batch][blocks][n2] (n2 = N / 2: (sum, sum of squares) per channel quad) -> tmp f32 [batch][MOM_SLABS][n2]
+__global__ __launch_bounds__(256) void conv_moments_slabs_kernel(const float* __restrict__ part, float* __restrict__ tmp, int blocks, int n2) {
+  __shared__ f32x4_t red[256];
+  const int z = blockIdx.y, s = blockIdx.x;
+  const int per = (blocks + MOM_SLABS - 1) / MOM_SLABS;
+  const int b0 = min(blocks, s * per), b1 = min(blocks, b0 + per);
+  const f32x4_t v = mom_block_sum(part + (long long)z * blocks * n2, b0, b1, n2, red);
+  if ((int)threadIdx.x < (n2 >> 2)) *(f32x4_t*)(tmp + ((long long)z * MOM_SLABS + s) * n2 + 4 * threadIdx.x) = v;
+}
+// tmp -> moments f32 [batch][N][2]: the quad's sums at its first channel, zeros at the other three
+__global__ __launch_bounds__(256) void conv_moments_finish_kernel(const float* __restrict__ tmp, float* __restrict__ mom, int n2, int accumulate) {
+  __shared__ f32x4_t red[256];
+  const int z = blockIdx.x;
+  const f32x4_t v = mom_block_sum(tmp + (long long)z * MOM_SLABS * n2, 0, MOM_SLABS, n2, red);
+  if ((int)threadIdx.x < (n2 >> 2)) {   // this thread: quads 2 l and 2 l + 1 = channels 8 l and 8 l + 4
+    float* dst = mom + (long long)z * n2 * 4 + (long long)threadIdx.x * 16;
+    if (accumulate) {
+      dst[0] += v[0]; dst[1] += v[1]; dst[8] += v[2]; dst[9] += v[3];
+    } else {
+      *(f32x4_t*)dst = (f32x4_t){v[0], v[1], 0.f, 0.f};
+      *(f32x4_t*)(dst + 4) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      *(f32x4_t*)(dst + 8) = (f32x4_t){v[2], v[3], 0.f, 0.f};
+      *(f32x4_t*)(dst + 12) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+long long x2i_conv_moments_scratch(int M, int N, int batch) {   // row blocks of 64 rows at most two per 128-row tile (the finer of the two kernels) + the slab sums
+  return (long long)batch * (((long long)(M + 127) / 128 * 2) + MOM_SLABS) * (N / 2);
+}
+
 static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream) {
   if (!a || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
   const bool conv = cd != nullptr;
@@ -217,6 +276,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   GemmP p;
   fill_gemm_p(a, qd, p);
   if (conv) {
+    if (a->gate) return x2i_set_error(X2I_ERR_ARG, "conv: a gated residual is not part of the convolution epilogues (residual: plain add)");
     if (cd->Cin % 64 || cd->H <= 0 || cd->W <= 0 || cd->KH <= 0 || cd->KW <= 0 || cd->stride <= 0)
       return x2i_set_error(X2I_ERR_SHAPE, "conv: Cin must be a multiple of 64 (Cin=%d)", cd->Cin);
     if (cd->up < 0 || cd->up > 2) return x2i_set_error(X2I_ERR_ARG, "conv: up must be 0, 1 (x2 along H and W) or 2 (x2 along H only), got %d", cd->up);
@@ -237,6 +297,13 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       return x2i_set_error(X2I_ERR_SHAPE, "conv: M=%d K=%d do not match OH*OW=%d, KH*KW*Cin=%d", a->M, a->K, OH * OW, cd->KH * cd->KW * cd->Cin);
     if ((long long)cd->H * cd->W * cd->Cin * 2 >= 0x7f000000LL) return x2i_set_error(X2I_ERR_SHAPE, "conv: image too large");
     p.cH = cd->H; p.cW = cd->W; p.cCin = cd->Cin; p.cOW = OW; p.cKW = cd->KW; p.cStride = cd->stride; p.cPad = cd->pad; p.cPadW = pad_w; p.cUp = up;
+    if (cd->moments) {
+      if (!cd->moments_scratch) return x2i_set_error(X2I_ERR_ARG, "conv: moments without moments_scratch (x2i_conv_moments_scratch_floats)");
+      if (a->N > 2048) return x2i_set_error(X2I_ERR_SHAPE, "conv: moments serve N <= 2048 (N=%d)", a->N);
+      if ((a->N & 7) || (a->ldc & 7) || (a->c_batch_stride & 7) || (((uintptr_t)a->C) & 15) || a->out_f32 || a->C2 || (((uintptr_t)cd->moments_scratch) & 15))
+        return x2i_set_error(X2I_ERR_ALIGN, "conv: moments need the whole-line bf16 epilogue (N, ldc, c_batch_stride multiples of 8, 16-byte aligned C and scratch, no f32 / second output)");
+      p.cMom = cd->moments_scratch;
+    }
     if (cd->out_row_pitch) {
       if (cd->out_row_pitch < (long long)(OW - 1) * a->ldc + a->N || (cd->out_row_pitch & 7) || a->res || a->C2 || a->out_f32)
         return x2i_set_error(X2I_ERR_SHAPE, "conv: out_row_pitch=%d must hold a row of %d pixels at ldc=%d, be a multiple of 8, and goes with the plain bf16 epilogue only", cd->out_row_pitch, OW, (int)a->ldc);
@@ -372,6 +439,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     pm.gm = pick_gm(tn, a->K);
     pm.M = (tm_main < tm_all) ? tm_main * BM2 : a->M;
     pm.tilesM = tm_main; pm.tilesN = tn;
+    pm.cMomBlocks = tm_main * 2;   // (conv: 128-row wave tiles, two per 256-row tile)
     if (kernp) {
       rc = x2i_ensure_dynamic_smem((const void*)kernp, SMEM2P_BYTES);
       if (rc) return rc;
@@ -401,6 +469,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     const int rc = x2i_ensure_dynamic_smem((const void*)kern, 4 * TILE_BYTES);
     if (rc) return rc;
     dim3 grid(p.tilesM * p.tilesN, a->batch);
+    p.cMomBlocks = p.tilesM * 2;    // (conv: 64-row wave tiles, two per 128-row tile)
     hipLaunchKernelGGL(kern, grid, dim3(256), 4 * TILE_BYTES, stream, p);
     opt.last_gemm_tile = 128;
   } else if (conv) {
@@ -419,6 +488,17 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     dim3 grid((a->N + 127) / 128, gy, gz);
     hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(128), 0, stream, p, a->batch);
     opt.last_gemm_tile = 0;
+  }
+  if (conv && cd->moments) {
+    int rc = x2i_check_launch("conv");
+    if (rc) return rc;
+    const int blocks = (opt.last_gemm_tile == 128 ? (a->M + BM - 1) / BM : (a->M + BM2 - 1) / BM2) * 2, n2 = a->N / 2;
+    float* tmp = cd->moments_scratch + (long long)a->batch * blocks * n2;
+    hipLaunchKernelGGL(conv_moments_slabs_kernel, dim3(MOM_SLABS, a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, tmp, blocks, n2);
+    rc = x2i_check_launch("conv_moments_slabs");
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)tmp, cd->moments, n2, cd->moments_accumulate ? 1 : 0);
+    return x2i_check_launch("conv_moments_finish");
   }
   return x2i_check_launch("gemm");
 }
@@ -485,7 +565,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = 0;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0; p.cMom = nullptr; p.cMomBlocks = 0;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   if (qd) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   if constexpr (!OUTF32) {
     // whole-line stores through LDS (see epilogue_store_lds); needs 16-byte aligned rows and N % 8 == 0
     if (((p.N | p.ldc) & 7) == 0 && (!RES || (p.ldr & 3) == 0) && ((((uintptr_t)p.C) | ((uintptr_t)p.C2)) & 15) == 0 && (p.c_bs & 7) == 0) {
-      epilogue_store_lds<ACT, RES, HASC2, 4>(p, acc, z, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (EPI_WAVE_BYTES / 2));
+      epilogue_store_lds<ACT, RES, HASC2, 4, CONV>(p, acc, z, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (EPI_WAVE_BYTES / 2));
       return;
     }
   }

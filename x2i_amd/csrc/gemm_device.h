@@ -26,6 +26,7 @@ struct GemmP {
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp: nearest-neighbour x2 upsampling fused into the gather, bit 0 = along H, bit 1 = along W
   int cPadW;                                       // padding along W (cPad: along H)
   int cRowPitch;                                   // conv: elements between two output ROWS of C (0 = cOW * ldc, dense): x2i_conv_desc.out_row_pitch
+  float* cMom; int cMomBlocks;                     // conv: per-row-block channel-quad moments of the bf16 outputs, f32 [batch][cMomBlocks][N / 4][2] (nullptr: off)
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0, q_vperm;   // q_vperm: V^T span-permuted (x2i_vt_pos)
   int gm;
@@ -197,7 +198,36 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
 constexpr int EPI_ROW_BYTES = 144;
 constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // 18 KiB per wave, 144 KiB per workgroup
 
-template <int ACT, bool RES, bool HASC2, int MT>
+// Channel moments from the epilogue (x2i_conv_desc.moments): a lane holds rows i*16 + (lane & 15), columns n .. n+3 (one channel QUAD) of column
+// block j; `lo`, `hi` are the bf16 pairs it is about to store (the ROUNDED outputs -- what the GroupNorm behind the conv will read).  mom_add
+// accumulates the quad's sum and sum of squares over the lane's rows with four v_dot2c_f32_bf16 (pair . ones, pair . pair: exact products, f32
+// sums), mom_flush sums the 16 lanes of a DPP row (row_ror 8, 4, 2, 1: fixed order) and lets lane (lane & 15) == 0 write the quad's (sum, sum of squares) of
+// this wave tile's row block.
+typedef __attribute__((ext_vector_type(2))) __bf16 mom_bf2_t;
+__device__ __forceinline__ void mom_add(float& ms, float& mq, uint32_t lo, uint32_t hi, bool valid) {
+  if (!valid) return;
+  const mom_bf2_t a = __builtin_bit_cast(mom_bf2_t, lo), b = __builtin_bit_cast(mom_bf2_t, hi), one = __builtin_bit_cast(mom_bf2_t, 0x3f803f80u);
+  ms = __builtin_amdgcn_fdot2_f32_bf16(a, one, ms, false);
+  ms = __builtin_amdgcn_fdot2_f32_bf16(b, one, ms, false);
+  mq = __builtin_amdgcn_fdot2_f32_bf16(a, a, mq, false);
+  mq = __builtin_amdgcn_fdot2_f32_bf16(b, b, mq, false);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+__device__ __forceinline__ void mom_flush(const GemmP& p, float ms, float mq, int z, int row_block, int n, int lane) {
+  const float s = row16_sum(ms), q = row16_sum(mq);
+  if ((lane & 15) == 0 && n + 3 < p.N) {   // partial sums: f32 [batch][row blocks][N / 4][2]
+    float* dst = p.cMom + (((long long)z * p.cMomBlocks + row_block) * (p.N >> 2) + (n >> 2)) * 2;
+    *(float2*)dst = make_float2(s, q);
+  }
+}
+
+template <int ACT, bool RES, bool HASC2, int MT, bool MOM = false>
 __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc)[MT][4], int z, int m_wave, int n_wave, int lane,
                                                    char* wave_lds) {
   const int mlane = lane & 15, ng = lane >> 4;
@@ -223,21 +253,23 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
         const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((long long)m * p.ldr + n) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (__attribute__((address_space(3))) void*)(wave_lds + it * 1024), 16, off, 0, 0, 0);
       }
-      float bvv[4][4], gvv[4][4];
+      // (MOM = the convolution kernels: no gate there -- the launcher refuses one -- and gate = 1 is exactly `+`: sixteen registers less, which
+      // keeps the 128^2 kernel's residual + moments form at two workgroups per CU)
+      float bvv[4][4], gvv[MOM ? 1 : 4][4];
       static_for<4>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const int n = n_wave + j * 16 + ng * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bvv[j][r] = 0.f, gvv[j][r] = 1.f;
+        for (int r = 0; r < 4; ++r) bvv[j][r] = 0.f, gvv[MOM ? 0 : j][r] = 1.f;
         if (n + 3 < p.N) {
           if (p.bias) {
             const uint2 bb = *(const uint2*)(p.bias + n);
             bvv[j][0] = __uint_as_float(bb.x << 16); bvv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
             bvv[j][2] = __uint_as_float(bb.y << 16); bvv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
           }
-          if (gz) {
+          if (!MOM && gz) {
             const f32x4_t g4 = *(const f32x4_t*)(gz + n);
-            gvv[j][0] = g4[0]; gvv[j][1] = g4[1]; gvv[j][2] = g4[2]; gvv[j][3] = g4[3];
+            gvv[MOM ? 0 : j][0] = g4[0]; gvv[MOM ? 0 : j][1] = g4[1]; gvv[MOM ? 0 : j][2] = g4[2]; gvv[MOM ? 0 : j][3] = g4[3];
           }
           if (b2) {
             const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
@@ -248,6 +280,7 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the region is private to this wave: no barrier needed
       static_for<4>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
+        float ms = 0.f, mq = 0.f;
         static_for<MT>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
           const int row = i * 16 + mlane;
@@ -256,12 +289,24 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] + bvv[j][r], ACT);
-          v[0] = fmaf(gvv[j][0], v[0], __uint_as_float(r2.x << 16));
-          v[1] = fmaf(gvv[j][1], v[1], __uint_as_float(r2.x & 0xffff0000u));
-          v[2] = fmaf(gvv[j][2], v[2], __uint_as_float(r2.y << 16));
-          v[3] = fmaf(gvv[j][3], v[3], __uint_as_float(r2.y & 0xffff0000u));
-          *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          if constexpr (MOM) {   // (fmaf(1, v, r) == v + r: one rounding either way)
+            v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+            v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+          } else {
+            v[0] = fmaf(gvv[j][0], v[0], __uint_as_float(r2.x << 16));
+            v[1] = fmaf(gvv[j][1], v[1], __uint_as_float(r2.x & 0xffff0000u));
+            v[2] = fmaf(gvv[j][2], v[2], __uint_as_float(r2.y << 16));
+            v[3] = fmaf(gvv[j][3], v[3], __uint_as_float(r2.y & 0xffff0000u));
+          }
+          const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          *(uint2*)slot = pk;
+          if constexpr (MOM) {
+            if (p.cMom) mom_add(ms, mq, pk.x, pk.y, m_wave + row < p.M);
+          }
         });
+        if constexpr (MOM) {
+          if (p.cMom) mom_flush(p, ms, mq, z, m_wave / (MT * 16), n_wave + j * 16 + ng * 4, lane);
+        }
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -296,6 +341,7 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
           bv[0] += t4[0]; bv[1] += t4[1]; bv[2] += t4[2]; bv[3] += t4[3];
         }
       }
+      float ms = 0.f, mq = 0.f;
       static_for<MT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int mrel = i * 16 + mlane;
@@ -316,8 +362,15 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
         }
-        *(uint2*)(wave_lds + mrel * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        *(uint2*)(wave_lds + mrel * EPI_ROW_BYTES + (j * 16 + ng * 4) * 2) = pk;
+        if constexpr (MOM) {
+          if (p.cMom && pass == 0) mom_add(ms, mq, pk.x, pk.y, m_wave + mrel < p.M);
+        }
       });
+      if constexpr (MOM) {
+        if (p.cMom && pass == 0) mom_flush(p, ms, mq, z, m_wave / (MT * 16), n, lane);
+      }
     });
     // the region is private to this wave: LDS operations of one wave complete in order, only the data hazard matters
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

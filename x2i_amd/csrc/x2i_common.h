@@ -63,6 +63,7 @@ int x2i_num_cus();  // compute units of the current device (cached)
 bool x2i_side_stream(hipStream_t main, hipStream_t* side, hipEvent_t* fork, hipEvent_t* join);
 struct x2i_gemm_args;
 bool x2i_streamk_workspace(const x2i_gemm_args* a, float** slabs, unsigned** flags, int* rc);  // the caller's workspace, validated
+long long x2i_conv_moments_scratch(int M, int N, int batch);   // gemm.hip: floats of x2i_conv_desc.moments_scratch
 int x2i_gemm_sk_slabs();                          // slabs per workspace (2 x max tiles: FX double buffer)
 int x2i_gemm_sk_max_tiles();                      // (gemm.hip: the constants of gemm_device.h)
 long long x2i_gemm_sk_slab_bytes();

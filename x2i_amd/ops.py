@@ -414,12 +414,14 @@ from ._lib import ACT_RELU, ConvDesc  # noqa: E402
 
 def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=None, act=ACT_NONE, bias2=None, res=None,
                 c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None, up=False, pad_w=None, B=None,
-                a_batch_stride=None, a_offset=0, out_w=None, out_h=None, out_row_pitch=0):
+                a_batch_stride=None, a_offset=0, out_w=None, out_h=None, out_row_pitch=0, moments=None, moments_accumulate=False):
     """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout].
     pad_w: padding along W when it differs from `pad` (along H).  B / a_batch_stride / a_offset: the input is a window of `H` rows of a
     larger NHWC tensor (elements between two images / in front of the window).  up: True / 1 = nearest x2 upsampling in front of the conv,
     2 = along H only; out_w / out_h: number of output columns / rows when the right-hand / bottom padding differs from pad_w / pad;
-    out_row_pitch: elements between two output rows when they are not dense (include/x2i.h: x2i_conv_desc)."""
+    out_row_pitch: elements between two output rows when they are not dense; moments: f32 [B, Cout, 2] that receives (or, with
+    moments_accumulate, is added) the (sum, sum of squares) of the bf16 outputs per channel QUAD (entry c % 4 == 0; the others are zero) --
+    the statistics input of groupnorm_nhwc_from_moments without pre_add, written by the conv epilogue (include/x2i.h: x2i_conv_desc)."""
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")
     _req(w_packed, torch.bfloat16, "w")
@@ -454,6 +456,13 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     a.w_batch_stride = 0
     d = ConvDesc(H, W, Cin, KH, KW, stride, pad, up, 0 if pad_w is None else pad_w + 1, 0 if out_w is None else out_w,
                  0 if out_h is None else out_h, out_row_pitch)
+    if moments is not None:
+        _req(moments, torch.float32, "moments")
+        n = int(lib.x2i_conv_moments_scratch_floats(a.M, a.N, a.batch))
+        key = (x.device, "conv_moments")
+        if key not in _gn_scratch or _gn_scratch[key].numel() < n:
+            _gn_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+        d.moments, d.moments_scratch, d.moments_accumulate = moments.data_ptr(), _gn_scratch[key].data_ptr(), 1 if moments_accumulate else 0
     check(lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(d), _stream()), "conv2d_nhwc")
     return out
 

@@ -106,16 +106,31 @@ class _Res(nn.Module):
         if cin != cout:
             self.conv_shortcut = _Conv(cin, cout, 1, device)
 
-    def run(self, x, H, W, G):
-        n = ops.groupnorm_nhwc(x, self.norm1.weight, self.norm1.bias, G, 1e-6, act=ACT_SILU)
+    def run(self, x, H, W, G, mom=None, want=False):
+        """mom: channel moments of x left by the conv that produced it (None: a statistics pass reads x); want: return (y, moments of y).
+        With moments the GroupNorms here read their input once (normalise) instead of twice (x2i_conv_desc.moments)."""
+        n = _gn(x, mom, self.norm1, G)
         w, b = self.conv1.packed()
-        h = ops.conv2d_nhwc(n, w, b, H, W, self.cin, self.cout, 3, 3, 1, 1)
-        n = ops.groupnorm_nhwc(h, self.norm2.weight, self.norm2.bias, G, 1e-6, act=ACT_SILU)
+        m1 = _mom(x, self.cout) if want else None
+        h = ops.conv2d_nhwc(n, w, b, H, W, self.cin, self.cout, 3, 3, 1, 1, moments=m1)
+        n = _gn(h, m1, self.norm2, G)
         if hasattr(self, "conv_shortcut"):
             w, b = self.conv_shortcut.packed()
             x = ops.conv2d_nhwc(x, w, b, H, W, self.cin, self.cout, 1, 1, 1, 0)
         w, b = self.conv2.packed()
-        return ops.conv2d_nhwc(n, w, b, H, W, self.cout, self.cout, 3, 3, 1, 1, res=x)
+        m2 = _mom(x, self.cout) if want else None
+        y = ops.conv2d_nhwc(n, w, b, H, W, self.cout, self.cout, 3, 3, 1, 1, res=x, moments=m2)
+        return (y, m2) if want else y
+
+
+def _mom(x, c):
+    return torch.empty((x.shape[0], c, 2), device=x.device, dtype=torch.float32)
+
+
+def _gn(x, mom, norm, G, act=ACT_SILU):
+    if mom is None:
+        return ops.groupnorm_nhwc(x, norm.weight, norm.bias, G, 1e-6, act=act)
+    return ops.groupnorm_nhwc_from_moments(x, mom, norm.weight, norm.bias, G, 1e-6, act=act)
 
 
 class _Attn(nn.Module):
@@ -126,9 +141,9 @@ class _Attn(nn.Module):
         self.to_q, self.to_k, self.to_v = _Lin(c, c, device), _Lin(c, c, device), _Lin(c, c, device)
         self.to_out = _Seq({0: _Lin(c, c, device)})
 
-    def run(self, x, H, W, G):
+    def run(self, x, H, W, G, mom=None):
         B, C, T = x.shape[0], self.c, H * W
-        h = ops.groupnorm_nhwc(x, self.group_norm.weight, self.group_norm.bias, G, 1e-6)  # [B,H,W,C] == [B,T,C]
+        h = _gn(x, mom, self.group_norm, G, act=ACT_NONE)  # [B,H,W,C] == [B,T,C]
         q = ops.gemm(h, self.to_q.weight, self.to_q.bias, M=B * T)
         k = ops.gemm(h, self.to_k.weight, self.to_k.bias, M=B * T)
         # V^T[c][t] = sum_j Wv[c][j] h[t][j]  (one GEMM per image with h as the "weight"); the bias of to_v is added after
@@ -188,9 +203,10 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-def decode_flops(cfg, H, W):
+def decode_flops(cfg, H, W, up_phases=0):
     """Algorithmic FLOPs of one `decode` of an [*, latent_channels, H, W] latent (2 * Cin * Cout * k^2 per output pixel of every
-    convolution, 2 M N K of the mid-block attention's linears and its two T x T products), un-padded channel counts."""
+    convolution, 2 M N K of the mid-block attention's linears and its two T x T products), un-padded channel counts.
+    up_phases = 1 / 2: the FLOPs the HIP path EXECUTES when Upsample2D's convs run in column-phase / four-phase form (6/9, 4/9 of theirs)."""
     rev = list(reversed(cfg.block_out_channels))
     conv = lambda ci, co, k, h, w: 2.0 * ci * co * k * k * h * w   # noqa: E731
     res = lambda ci, co, h, w: conv(ci, co, 3, h, w) + conv(co, co, 3, h, w) + (conv(ci, co, 1, h, w) if ci != co else 0.0)   # noqa: E731
@@ -203,7 +219,7 @@ def decode_flops(cfg, H, W):
             fl += res(prev if j == 0 else co, co, H, W)
         if i != len(rev) - 1:
             H, W = 2 * H, 2 * W
-            fl += conv(co, co, 3, H, W)
+            fl += conv(co, co, 3, H, W) * {0: 1.0, 1: 6.0 / 9.0, 2: 4.0 / 9.0}[up_phases]
         prev = co
     return fl + conv(rev[-1], cfg.out_channels, 3, H, W)
 
@@ -224,6 +240,8 @@ class AutoencoderKL(nn.Module):
         # 1: two 3 x 2 column phases; 0: ONE 3 x 3 conv with the x2 upsampling in its gather.  Same result within the tolerance of one more
         # bf16 rounding of summed weights (_Conv.packed_up_phases; tests/test_vae_gpu.py)
         self.up_phases = int(os.environ.get("X2I_VAE_UP_PHASES", "2"))
+        # X2I_VAE_EPI_MOMENTS=0: every GroupNorm takes its statistics in a pass of its own (A/B); default: from the producing conv's epilogue
+        self.epilogue_moments = os.environ.get("X2I_VAE_EPI_MOMENTS", "1") != "0"
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
@@ -248,17 +266,20 @@ class AutoencoderKL(nn.Module):
         x = torch.zeros((B, H, W, 64), device=z.device, dtype=torch.bfloat16)  # latent channels zero-padded to one K-step
         x[..., :Cz] = z.to(torch.bfloat16).permute(0, 2, 3, 1)
         rev = list(reversed(cfg.block_out_channels))
+        em = self.epilogue_moments   # the convs' epilogues leave the channel moments the next GroupNorm needs (no statistics pass over the tensor)
         w, b = d.conv_in.packed(cin_pad=64)
-        x = ops.conv2d_nhwc(x, w, b, H, W, 64, rev[0], 3, 3, 1, 1)
-        x = d.mid_block.resnets[0].run(x, H, W, G)
-        x = d.mid_block.attentions[0].run(x, H, W, G)
-        x = d.mid_block.resnets[1].run(x, H, W, G)
+        mom = _mom(x, rev[0]) if em else None
+        x = ops.conv2d_nhwc(x, w, b, H, W, 64, rev[0], 3, 3, 1, 1, moments=mom)
+        x, mom = d.mid_block.resnets[0].run(x, H, W, G, mom, True) if em else (d.mid_block.resnets[0].run(x, H, W, G), None)
+        x = d.mid_block.attentions[0].run(x, H, W, G, mom)      # (its output comes from a plain GEMM: the next norm1 takes its own statistics)
+        x, mom = d.mid_block.resnets[1].run(x, H, W, G, None, True) if em else (d.mid_block.resnets[1].run(x, H, W, G), None)
         for i, co in enumerate(rev):
             blk = d.up_blocks[i]
             for j in range(len(blk.resnets)):
-                x = blk.resnets[j].run(x, H, W, G)
+                x, mom = blk.resnets[j].run(x, H, W, G, mom, True) if em else (blk.resnets[j].run(x, H, W, G), None)
             if hasattr(blk, "upsamplers"):
                 y = torch.empty((B, 2 * H, 2 * W, co), device=x.device, dtype=torch.bfloat16) if self.up_phases else None
+                mom = _mom(x, co) if em else None
                 if self.up_phases == 2:
                     # F.interpolate(nearest, x2) + conv as four 2 x 2 phase convolutions on the un-doubled image (4/9 of the work): phase
                     # (py, px) writes the pixels (2y + py, 2x + px): column stride 2 Cout, row pitch two full rows
@@ -266,20 +287,21 @@ class AutoencoderKL(nn.Module):
                     for py in (0, 1):
                         for px in (0, 1):
                             ops.conv2d_nhwc(x, wp[py][px], b, H, W, co, co, 2, 2, 1, 1 - py, pad_w=1 - px, out_h=H, out_w=W, out=y, ldc=2 * co,
-                                            out_row_pitch=4 * W * co, c_offset=(py * 2 * W + px) * co, c_batch_stride=4 * H * W * co)
+                                            out_row_pitch=4 * W * co, c_offset=(py * 2 * W + px) * co, c_batch_stride=4 * H * W * co,
+                                            moments=mom, moments_accumulate=(py, px) != (0, 0))
                     x = y
                 elif self.up_phases:
                     # ... as two 3 x 2 column-phase convolutions, the rows doubled in the gather (6/9 of the work; A/B form)
                     w0, w1, b = blk.upsamplers[0].conv.packed_up_phases()
                     for px, wp in ((0, w0), (1, w1)):
                         ops.conv2d_nhwc(x, wp, b, H, W, co, co, 3, 2, 1, 1, up=2, pad_w=1 - px, out_w=W, out=y, ldc=2 * co, c_offset=px * co,
-                                        c_batch_stride=4 * H * W * co)
+                                        c_batch_stride=4 * H * W * co, moments=mom, moments_accumulate=px == 1)
                     x = y
                 else:
                     w, b = blk.upsamplers[0].conv.packed()
-                    x = ops.conv2d_nhwc(x, w, b, H, W, co, co, 3, 3, 1, 1, up=True)  # F.interpolate(nearest, x2) + conv, fused gather
+                    x = ops.conv2d_nhwc(x, w, b, H, W, co, co, 3, 3, 1, 1, up=True, moments=mom)  # F.interpolate(nearest, x2) + conv, fused gather
                 H, W = 2 * H, 2 * W
-        n = ops.groupnorm_nhwc(x, d.conv_norm_out.weight, d.conv_norm_out.bias, G, 1e-6, act=ACT_SILU)
+        n = _gn(x, mom, d.conv_norm_out, G)
         w, b = d.conv_out.packed(cout_pad=8)  # 3 -> 8 output channels so that rows are 16-byte aligned
         y = ops.conv2d_nhwc(n, w, b, H, W, rev[-1], 8, 3, 3, 1, 1)
         img = y[..., :cfg.out_channels].permute(0, 3, 1, 2).contiguous()
