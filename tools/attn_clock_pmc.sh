@@ -19,7 +19,7 @@ for mode in ("alone", "seq"):
     cnt, dur = {}, []
     for f in glob.glob(f"{sys.argv[1]}/{mode}/*/p_counter_collection.csv") + glob.glob(f"{sys.argv[1]}/{mode}/p_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "attn_w4" not in r["Kernel_Name"]:
+            if "attn_w4" not in r["Kernel_Name"] and "attn_w16" not in r["Kernel_Name"]:   # (whichever the product call launches)
                 continue
             cnt.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "Start_Timestamp" in r:

@@ -19,7 +19,7 @@ for f in glob.glob(sys.argv[1] + "/*/p_counter_collection.csv"):
         n = r["Kernel_Name"]
         if "attn" not in n:
             continue
-        key = ("w4" if "attn_w4" in n else "pp" if "attn_pp" in n else "fwd4")
+        key = ("w16" if "attn_w16" in n else "w4" if "attn_w4" in n else "attn16" if "attn16" in n else "pp" if "attn_pp" in n else "fwd4")
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
 for k, e in out.items():
@@ -30,7 +30,7 @@ for k, e in out.items():
         e["frac_active"] = e.get("SQ_ACTIVE_INST_ANY", 0) / w
         # SQ_WAVE_CYCLES counts QUAD-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs.  One wave per SIMD
         # (the hand-scheduled kernel): SIMD cycles = 4 * wave quad-cycles; two waves per SIMD (ping-pong, 4-wave x 2 workgroups): 2 *
-        waves_per_simd = 1 if k == "w4" else 2
+        waves_per_simd = 1 if k in ("w4", "w16") else 2
         e["mfma_busy_frac_of_simd_cycles"] = e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4.0 * w / waves_per_simd)
 print(json.dumps(out, indent=1, sort_keys=True))
 PY

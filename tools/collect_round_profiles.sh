@@ -40,6 +40,10 @@ python tools/microbench.py > "$OUT/${TAG}_microbench.log" 2>&1
 python tools/fp8_bench.py > "$OUT/${TAG}_fp8_bench.log" 2>&1
 python tools/conv_bench.py 4 > "$OUT/${TAG}_conv_bench.log" 2>&1
 python tools/attn_bench.py 4 > "$OUT/${TAG}_attn_bench.log" 2>&1
+python tools/attn_w16_clock.py 2 > "$OUT/${TAG}_attn_w16_clock.log" 2>&1
+python tools/vae_bench.py > "$OUT/${TAG}_vae_bench.log" 2>&1
+X2I_VAE_EPI_MOMENTS=0 X2I_VAE_UP_PHASES=0 python tools/vae_bench.py > "$OUT/${TAG}_vae_bench_round4_form.log" 2>&1
+python tools/conv_probe.py > "$OUT/${TAG}_conv_probe.log" 2>&1
 timeout 600 python tools/train_bench.py 1 2 > "$OUT/${TAG}_train_bench.log" 2>&1
 python tools/fx_bench.py > "$OUT/${TAG}_fx_bench.log" 2>&1
 python tools/gemm_r2_probe.py --quick > "$OUT/${TAG}_gemm_r2_probe.log" 2>&1
@@ -48,6 +52,7 @@ bash tools/attn_clock_pmc.sh "$OUT/attn_clock" > /dev/null 2>&1; cp "$OUT/attn_c
 cd /tmp
 run_stats bench_b4_1024_fp8 python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dtype fp8 --no-roofline
 run_stats bench_config5 python "$R/bench.py" --config 5 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+run_stats vae_b4 python "$R/tools/vae_bench.py"
 bash "$R/tools/pmc_collect.sh" "$OUT/pmc" all > "$OUT/pmc.log" 2>&1
 cp "$OUT/pmc/summary.json" "$OUT/${TAG}_pmc_gemm_attn.json"
 bash "$R/tools/clock_watch.sh" "$OUT/${TAG}_clock_power_during_bench.log" -- python "$R/bench.py" --no-cpu-baseline --no-fp8-lines --steps 6 > /dev/null 2>&1

@@ -44,8 +44,9 @@ if which in ("all", "attn"):
     Q, K_, VT = rnd(B, H, Spad, 128), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)
     O = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
-        # the PRODUCT call: Q carries softmax_scale * log2(e) (x2i_qkv_desc.q_scale) and the kernel gets scale = ln 2 -> attn_w4_kernel
-        ops.attention((Q.float() * (math.log2(math.e) / math.sqrt(128))).bfloat16(), K_, VT, O, B, H, S, Spad, D, S * D, math.log(2.0))
+        # the PRODUCT call: Q carries softmax_scale * log2(e) (x2i_qkv_desc.q_scale) and the kernel gets scale = ln 2 -> attn_w16_kernel on a span-permuted V^T (attn_w4_kernel with X2I_ATTN_W16=0)
+        ops.attention((Q.float() * (math.log2(math.e) / math.sqrt(128))).bfloat16(), K_, VT, O, B, H, S, Spad, D, S * D, math.log(2.0),
+                      vt_perm=ops.attention_prefers_vt_perm(H, S, math.log(2.0)))
     torch.cuda.synchronize()
 if which == "conv":
     # ControlNeXt ResnetBlock conv2 (3x3, 128 -> 128 at 512^2) with / without the residual, and the 256-wide one
