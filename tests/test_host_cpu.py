@@ -218,6 +218,36 @@ def test_c_abi_argument_validation_returns_codes_without_a_gpu():
     a.M = 64
     assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"OH*OW=48" in lib.x2i_last_error()
 
+    # the round-5 fields of x2i_conv_desc: up in {0, 1, 2}; out_w / out_h (one-sided padding) must leave the last tap inside the padded input; an output
+    # row pitch goes with the plain bf16 epilogue only; moments need their scratch, whole-line outputs and no gate anywhere near a convolution
+    cd = _lib.ConvDesc(H=8, W=8, Cin=64, KH=3, KW=3, stride=1, pad=1, up=3)
+    a.M, a.N, a.K, a.ldc = 64, 64, 9 * 64, 64
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"up must be" in lib.x2i_last_error()
+    cd = _lib.ConvDesc(H=8, W=8, Cin=64, KH=2, KW=2, stride=1, pad=1, up=0, pad_w_p1=2, out_w=12, out_h=8)
+    a.K = 4 * 64
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"out_w=12 lies outside" in lib.x2i_last_error()
+    cd.out_w, cd.out_h = 8, 12
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"out_h=12 lies outside" in lib.x2i_last_error()
+    cd.out_h, cd.out_row_pitch = 8, 100
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"out_row_pitch" in lib.x2i_last_error()
+    cd.out_row_pitch, a.res = 1024, 0x1000
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"plain bf16 epilogue only" in lib.x2i_last_error()
+    a.res, cd.out_row_pitch, cd.moments = None, 0, 0x1000
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"moments_scratch" in lib.x2i_last_error()
+    cd.moments_scratch, a.ldc = 0x1000, 60
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"whole-line bf16 epilogue" in lib.x2i_last_error()
+    a.ldc, a.res, a.gate = 64, 0x1000, 0x1000
+    assert lib.x2i_conv2d_nhwc_bf16(C.byref(a), C.byref(cd), None) < 0 and b"gated residual" in lib.x2i_last_error()
+    a.res, a.gate = None, None
+    assert lib.x2i_conv_moments_scratch_floats(1024 * 1024, 128, 4) == 4 * (16384 + 64) * 64 and lib.x2i_conv_moments_scratch_floats(0, 128, 4) == 0
+    # the span-permuted V^T: only the 16 x 16 x 32 kernel reads it, and that one wants 16-byte aligned output rows
+    assert lib.x2i_attention_vp_bf16(fake, fake, fake, fake, 1, 1, 100, 100, 128, 12800, 0.1, None) < 0 and b"Spad" in lib.x2i_last_error()
+    assert lib.x2i_attention_vp_bf16(fake, fake, None, fake, 1, 1, 128, 128, 128, 16384, 0.1, None) < 0
+    _lib.set_option("attn_w16", 0)
+    assert lib.x2i_attention_prefers_vt_perm(24, 4608, 0.6931471805599453) == 0
+    _lib.set_option("attn_w16", 1)
+    assert lib.x2i_attention_prefers_vt_perm(24, 4608, 0.6931471805599453) == 1 and lib.x2i_attention_prefers_vt_perm(24, 4608, 0.0883883) == 0
+
     assert lib.x2i_attention_bf16(fake, fake, fake, fake, 1, 1, 100, 100, 128, 12800, 0.1, None) < 0  # Spad % 128
     assert lib.x2i_qkv_split_bf16(None, fake, 384, 384, 1, 64, 0, 1, None, None, fake, fake, fake, fake, fake, fake, fake, 100, 1e-6, None) < 0
     assert lib.x2i_groupnorm_nhwc_bf16(fake, fake, 1, 64, 60, 4, fake, fake, 1e-5, 0, None, None, fake, None) < 0  # C % 8
