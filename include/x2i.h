@@ -58,6 +58,8 @@ const char* x2i_last_error(void);
  * the environment.  Names: "gemm_tile" (0 auto | 128 | 256), "gemm_min256", "gemm_gm" (0 auto), "gemm_split_tail" (1),
  * "gemm_w4" (1: 4-wave hand-scheduled 256^2 kernel; 0: the 8-wave form), "gemm_persist" (1: one workgroup per CU walks the output
  * tiles), "gemm_fp8_persist" (1: x2i_gemm_fp8 / x2i_gemm_qkv_fp8 take the persistent four-wave form too; 0: the one-tile e4m3 kernel, bit-identical),
+ * "gemm_fx_nk" (96: the K split of "gemm_fx" applies from this many 64-wide K-tiles, i.e. K >= 6144; 48 adds the K = 3072 gated-residual launches:
+ *  +0.5 % at 512^2 batch 1, measured, not the default),
  * "gemm_fx" (DEFAULT 2: as 1, but only for items with at most HALF a round of 256^2 tiles -- a 512^2 sample's 72; 0: never; 1: a gated-residual launch whose batch ITEM has fewer 256^2 output tiles than the chip has CUs, with K >= 6144, is cut along K
  * over all CUs -- every part summed from zero in parallel, the parts of a tile added in a fixed order by the workgroup that holds the last
  * one; needs the workspace.  Decided and cut by the item's shape alone, so a sample's result does not depend on its batch; deterministic;

@@ -129,7 +129,7 @@ static bool fx_for(const x2i_gemm_args* a0, const x2i_gemm_args* a1, int cus, in
   *rc = X2I_OK;
   if (!(opt.gemm_fx && opt.gemm_streamk && opt.gemm_tile == 0 && cus <= SK_MAX_TILES && a0->workspace)) return false;
   const int nk = a0->K / BK;
-  if (nk < 96 || !a0->res || a0->act != X2I_ACT_NONE || a0->C2 || a0->out_f32) return false;
+  if (nk < opt.gemm_fx_nk || !a0->res || a0->act != X2I_ACT_NONE || a0->C2 || a0->out_f32) return false;
   if (a1 && (a1->batch != a0->batch || !a1->res || a1->act != X2I_ACT_NONE || a1->C2 || a1->out_f32)) return false;
   const long long T0 = (long long)((a0->M + BM2 - 1) / BM2) * ((a0->N + BN2 - 1) / BN2);
   const long long T1 = a1 ? (long long)((a1->M + BM2 - 1) / BM2) * ((a1->N + BN2 - 1) / BN2) : 0;

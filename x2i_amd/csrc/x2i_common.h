@@ -35,6 +35,7 @@ struct X2IOptions {
   int gemm_pair;          // 1 = x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 issue ONE grouped persistent launch when they can (0: always two launches)
   int gemm_streamk;       // 1 = the persistent kernel splits the tiles of a partly filled last round along K (chained partial accumulators,
                           // bit-identical results; default); 0 = whole tiles only (+ the peeled 128^2 tail launch)          X2I_GEMM_STREAMK
+  int gemm_fx_nk;         // K-tiles from which the split of gemm_fx applies (default 96 = K >= 6144)   X2I_GEMM_FX_NK
   int gemm_fx;            // launches with fewer 256^2 tiles per batch item than CUs and a deep K (>= 96 K-tiles) are cut along K over all CUs (parallel split
                           // with fix-up, gemm256p.hip FX; not bit-identical to whole tiles -- the K sum is associated differently; decided by the
                           // item's shape alone).  2 (DEFAULT) = items with at most half a round of tiles (512^2 samples); 1 = every item below one
