@@ -201,6 +201,14 @@ typedef struct x2i_conv_desc {
 int x2i_conv2d_nhwc_bf16(const x2i_gemm_args* args, const x2i_conv_desc* conv, x2i_stream_t stream);
 int64_t x2i_conv_moments_scratch_floats(int32_t M, int32_t N, int32_t batch);
 
+/* Conv2d(Cin -> Cout <= 4, k=3, stride=1, pad=1) on NHWC bf16: the VAE decoder's conv_out (diffusers Decoder.conv_out, 128 -> 3 channels at the
+ * image resolution; infer/inference_qwenvl.py:213-214).  x [B][H][W][Cin], Cin in {32, 64, 96, 128}; w bf16 [Cout][3][3][Cin] (ky,kx,ci);
+ * bias bf16 [Cout] or NULL; y [B][H][W][ldy] with ldy % 4 == 0: channels 0 .. 3 of every pixel are written (those behind Cout as zeros),
+ * the rest of a pixel is left alone.  The output channels ride in the ROWS of the 16 x 16 x 32 MFMA, 16 neighbouring pixels in its columns
+ * (csrc/conv_narrow.hip) -- as an implicit GEMM three channels would pay for a 128-column tile. */
+int x2i_conv3x3_narrow_bf16(const void* x, const void* w, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                            int32_t ldy, x2i_stream_t stream);
+
 /* Conv2d(3 -> Cout, k=3, stride=2, pad=1) on an NHWC bf16 image (lightcontrol_flux.py:594); w f32 [Cout][3][3][3]
  * (ky,kx,ci), bias f32 [Cout]; y NHWC bf16 [B][H/2][W/2][Cout], Cout % 16 == 0 and <= 64. */
 int x2i_conv_stem_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W,

@@ -117,6 +117,33 @@ def test_conv_epilogue_channel_moments(C, Co, H, W, res):
     assert rel_l2(a1, a0) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 21, 128, 3), (1, 64, 80, 128, 3), (1, 37, 16, 64, 4), (3, 5, 130, 32, 1), (1, 130, 70, 96, 2)])
+def test_conv3x3_narrow_output(B, H, W, Cin, Cout):
+    """x2i_conv3x3_narrow_bf16 (the VAE's conv_out shape: up to four output channels in the rows of the 16 x 16 x 32 MFMA, a wave walking down a
+    16-pixel strip with three rotating row accumulators): ragged widths / heights (partial strips, row blocks of any length, one-row images
+    handled by the same loop), all supported Cin, against F.conv2d in fp32 on the bf16 inputs and against the implicit-GEMM conv."""
+    from x2i_amd import ops
+    x = bf(seeded((B, Cin, H, W), 31))
+    w = bf(seeded((Cout, Cin, 3, 3), 32) / 20)
+    b = bf(seeded((Cout,), 33))
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.full((B, H, W, 8), 5.0, device=DEV, dtype=torch.bfloat16)
+    ops.conv3x3_narrow(xn, wp, b.to(DEV), Cout, out=y, ldy=8)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    assert rel_l2(y[..., :Cout].permute(0, 3, 1, 2), ref) < 6e-3
+    assert float(y[..., Cout:4].float().abs().max() if Cout < 4 else 0.0) == 0.0 and bool((y[..., 4:] == 5.0).all())   # zeros behind Cout, the rest untouched
+    w8 = torch.zeros((8, 9 * Cin), dtype=torch.bfloat16, device=DEV)
+    w8[:Cout] = wp
+    b8 = torch.zeros((8,), dtype=torch.bfloat16, device=DEV)
+    b8[:Cout] = b.to(DEV)
+    if Cin % 64 == 0:
+        g = ops.conv2d_nhwc(xn, w8, b8, H, W, Cin, 8, 3, 3, 1, 1)
+        assert rel_l2(y[..., :Cout], g[..., :Cout]) < 6e-3
+    y2 = ops.conv3x3_narrow(xn, wp, None, Cout)
+    assert y2.shape == (B, H, W, 4) and rel_l2(y2[..., :Cout].permute(0, 3, 1, 2), ref - b.float().view(1, -1, 1, 1)) < 6e-3
+
+
 def test_groupnorm_four_channels_per_group():
     from x2i_amd import ops
     x, w, b = bf(seeded((2, 128, 9, 11), 4, 2.0) + 0.2), bf(1 + 0.1 * seeded((128,), 5)), bf(0.1 * seeded((128,), 6))
@@ -154,6 +181,10 @@ def test_vae_decode_vs_oracle_reduced_width():
         vae.up_phases = form
         img1 = vae.decode(z.to(DEV), return_dict=False)[0]
         assert rel_l2(img1, ref) < 3e-2 and rel_l2(img, img1) < 2e-2
+    vae.up_phases, vae.narrow_conv_out = 2, False   # conv_out as an implicit GEMM with 3 -> 8 padded channels (A/B form): only the last conv's summation order differs
+    img3 = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert rel_l2(img3, ref) < 3e-2 and rel_l2(img, img3) < 3e-3
+    vae.narrow_conv_out = True
     vae.up_phases, vae.epilogue_moments = 2, False     # every GroupNorm with a statistics pass of its own (A/B form)
     img2 = vae.decode(z.to(DEV), return_dict=False)[0]
     assert rel_l2(img2, ref) < 3e-2 and rel_l2(img, img2) < 2e-2

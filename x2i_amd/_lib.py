@@ -72,6 +72,7 @@ SIGNATURES = {
     "x2i_ln_modulate_fp8": [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64,
                             _f32, _vp],
     "x2i_conv_stem_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "x2i_conv3x3_narrow_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "x2i_groupnorm_nhwc_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "x2i_groupnorm_moments_f32": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "x2i_groupnorm_nhwc_from_moments_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -242,6 +242,11 @@ int x2i_gemm_qkv_bf16(const x2i_gemm_args* args, const x2i_qkv_desc* qkv, x2i_st
   return x2i_launch_gemm_qkv(args, qkv, (hipStream_t)stream);
 }
 
+int x2i_conv3x3_narrow_bf16(const void* x, const void* w, const void* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                            int32_t ldy, x2i_stream_t stream) {
+  return x2i_launch_conv3x3_narrow(x, w, bias, y, B, H, W, Cin, Cout, ldy, (hipStream_t)stream);
+}
+
 int x2i_conv_stem_bf16(const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t H, int32_t W, int32_t Cout,
                        x2i_stream_t stream) {
   return x2i_launch_conv_stem(x, w, bias, y, B, H, W, Cout, (hipStream_t)stream);

@@ -14,6 +14,8 @@ int x2i_launch_quantize_rows_fp8(const void* x, long long rows, int cols, long l
 int x2i_launch_ln_modulate_fp8(const void* X, long long x_bs, int ldx, void* Y, long long y_bs, int ldy, void* Y8, long long y8_bs,
                                int ldy8, float* row_scale, int B, int S, int D, int S0, const float* shift0, const float* scale0,
                                const float* shift1, const float* scale1, long long mod_bs, float eps, hipStream_t stream);
+int x2i_launch_conv3x3_narrow(const void* x, const void* w, const void* bias, void* y, int B, int H, int W, int Cin, int Cout, int ldy,
+                              hipStream_t stream);   // conv_narrow.hip
 int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout,
                          hipStream_t stream);
 long long x2i_groupnorm_scratch(int B, int G);

@@ -467,6 +467,19 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     return out
 
 
+def conv3x3_narrow(x, w_packed, bias, Cout, out=None, ldy=4):
+    """Conv2d(Cin -> Cout <= 4, 3 x 3, stride 1, padding 1) on NHWC bf16 [B,H,W,Cin] (include/x2i.h: x2i_conv3x3_narrow_bf16): returns
+    [B,H,W,ldy] whose channels 0 .. 3 are written (zeros behind Cout).  w_packed: bf16 [Cout, 9 * Cin] in (ky, kx, ci) order."""
+    lib = _lib.load()
+    _req(x, torch.bfloat16, "x")
+    _req(w_packed, torch.bfloat16, "w")
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, ldy), device=x.device, dtype=torch.bfloat16)
+    check(lib.x2i_conv3x3_narrow_bf16(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, Cout, ldy, _stream()), "conv3x3_narrow")
+    return out
+
+
 def conv_stem(x_nhwc, w, bias, Cout):
     """Conv2d(3->Cout, k3, s2, p1): x bf16 NHWC [B,H,W,3]; w f32 [Cout,3,3,3] (ky,kx,ci)."""
     lib = _lib.load()

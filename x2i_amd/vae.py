@@ -242,6 +242,8 @@ class AutoencoderKL(nn.Module):
         self.up_phases = int(os.environ.get("X2I_VAE_UP_PHASES", "2"))
         # X2I_VAE_EPI_MOMENTS=0: every GroupNorm takes its statistics in a pass of its own (A/B); default: from the producing conv's epilogue
         self.epilogue_moments = os.environ.get("X2I_VAE_EPI_MOMENTS", "1") != "0"
+        # X2I_VAE_NARROW_CONV_OUT=0: conv_out as an implicit GEMM on the 128-column tile kernel (A/B); default: the narrow-output MFMA kernel
+        self.narrow_conv_out = os.environ.get("X2I_VAE_NARROW_CONV_OUT", "1") != "0"
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
@@ -302,8 +304,12 @@ class AutoencoderKL(nn.Module):
                     x = ops.conv2d_nhwc(x, w, b, H, W, co, co, 3, 3, 1, 1, up=True, moments=mom)  # F.interpolate(nearest, x2) + conv, fused gather
                 H, W = 2 * H, 2 * W
         n = _gn(x, mom, d.conv_norm_out, G)
-        w, b = d.conv_out.packed(cout_pad=8)  # 3 -> 8 output channels so that rows are 16-byte aligned
-        y = ops.conv2d_nhwc(n, w, b, H, W, rev[-1], 8, 3, 3, 1, 1)
+        if self.narrow_conv_out and cfg.out_channels <= 4 and rev[-1] in (32, 64, 96, 128):
+            w, b = d.conv_out.packed()             # three output channels in the rows of the 16 x 16 x 32 MFMA (x2i_conv3x3_narrow_bf16)
+            y = ops.conv3x3_narrow(n, w, b, cfg.out_channels)
+        else:
+            w, b = d.conv_out.packed(cout_pad=8)  # implicit GEMM, 3 -> 8 output channels so that rows are 16-byte aligned (A/B form)
+            y = ops.conv2d_nhwc(n, w, b, H, W, rev[-1], 8, 3, 3, 1, 1)
         img = y[..., :cfg.out_channels].permute(0, 3, 1, 2).contiguous()
         if not return_dict:
             return (img,)
