@@ -248,10 +248,11 @@ __global__ __launch_bounds__(256) void conv_moments_slabs_kernel(const float* __
   if ((int)threadIdx.x < (n2 >> 2)) *(f32x4_t*)(tmp + ((long long)z * MOM_SLABS + s) * n2 + 4 * threadIdx.x) = v;
 }
 // tmp -> moments f32 [batch][N][2]: the quad's sums at its first channel, zeros at the other three
-__global__ __launch_bounds__(256) void conv_moments_finish_kernel(const float* __restrict__ tmp, float* __restrict__ mom, int n2, int accumulate) {
+// (`rows` = MOM_SLABS behind the slab kernel, or the row blocks themselves when there are few of them: one launch instead of two)
+__global__ __launch_bounds__(256) void conv_moments_finish_kernel(const float* __restrict__ tmp, float* __restrict__ mom, int rows, int n2, int accumulate) {
   __shared__ f32x4_t red[256];
   const int z = blockIdx.x;
-  const f32x4_t v = mom_block_sum(tmp + (long long)z * MOM_SLABS * n2, 0, MOM_SLABS, n2, red);
+  const f32x4_t v = mom_block_sum(tmp + (long long)z * rows * n2, 0, rows, n2, red);
   if ((int)threadIdx.x < (n2 >> 2)) {   // this thread: quads 2 l and 2 l + 1 = channels 8 l and 8 l + 4
     float* dst = mom + (long long)z * n2 * 4 + (long long)threadIdx.x * 16;
     if (accumulate) {
@@ -493,11 +494,16 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     int rc = x2i_check_launch("conv");
     if (rc) return rc;
     const int blocks = (opt.last_gemm_tile == 128 ? (a->M + BM - 1) / BM : (a->M + BM2 - 1) / BM2) * 2, n2 = a->N / 2;
+    if (blocks <= 128) {   // few row blocks (small images / small batches live here): the finishing block adds them itself, in the same fixed tree
+      hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, cd->moments, blocks, n2,
+                         cd->moments_accumulate ? 1 : 0);
+      return x2i_check_launch("conv_moments_finish");
+    }
     float* tmp = cd->moments_scratch + (long long)a->batch * blocks * n2;
     hipLaunchKernelGGL(conv_moments_slabs_kernel, dim3(MOM_SLABS, a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, tmp, blocks, n2);
     rc = x2i_check_launch("conv_moments_slabs");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)tmp, cd->moments, n2, cd->moments_accumulate ? 1 : 0);
+    hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)tmp, cd->moments, MOM_SLABS, n2, cd->moments_accumulate ? 1 : 0);
     return x2i_check_launch("conv_moments_finish");
   }
   return x2i_check_launch("gemm");
