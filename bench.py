@@ -158,6 +158,59 @@ def _in_step_gemm_rate(B):
                 "Appendix C) / their summed rocprofv3 kernel time" % steps)
 
 
+_PIPE_ALONE = None
+
+
+def matrix_pipe_alone_live(variants=((1, "bf16 16x16x32, operands rotating"), (3, "bf16 16x16x32, one operand held x8"), (2, "e4m3 16x16x128")),
+                           launches=6, iters=300000):
+    """What the power management lets the matrix pipe ALONE do on THIS box, measured live: the register-resident MFMA
+    streams of tools/ubench/mfma_power.hip -- one wave per SIMD on every CU, random operands and accumulators in registers, no memory
+    traffic in the loop -- launched from the measurement library tools/ubench/libx2i_ubench.so (never the product .so), `launches` launches
+    of ~0.13 s per variant (sustained: the first launch of a variant is dropped), HIP events on the launch stream, sclk / socket power
+    sampled beside them.  Returns None when the library is absent (the bench line then carries the committed-profile figure)."""
+    import ctypes
+    global _PIPE_ALONE
+    if _PIPE_ALONE is not None:
+        return _PIPE_ALONE
+    path = os.path.join(ROOT, "tools", "ubench", "libx2i_ubench.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.x2i_ubench_data_bytes.restype = ctypes.c_longlong
+    lib.x2i_ubench_flop_per_iter.restype = ctypes.c_double
+    lib.x2i_ubench_flop_per_iter.argtypes = [ctypes.c_int]
+    lib.x2i_ubench_mfma_pipe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    n = int(lib.x2i_ubench_data_bytes())
+    data = (torch.rand(n // 2, device="cuda") * 4 - 2).bfloat16()     # random bf16 in [-2, 2): the stand-alone tool's operands
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for var, name in variants:
+        fl = float(lib.x2i_ubench_flop_per_iter(var))
+        it = iters // 2 if var == 2 else iters
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        with ClockPowerSampler(torch.cuda.current_device()) as smp:
+            for e0, e1 in ev:
+                e0.record()
+                rc = lib.x2i_ubench_mfma_pipe(var, it, ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(stream))
+                e1.record()
+                if rc:
+                    return None
+            torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev[1:])
+        t = ts[len(ts) // 2]
+        out[var] = dict(stream=name, achieved=fl * it / t / 1e12, unit="TFLOP/s", ms_per_launch=t * 1e3, clock_power=smp.summary())
+    del data
+    bf = out[1]
+    res = dict(achieved=bf["achieved"], frac_of_peak=bf["achieved"] * 1e12 / PEAK_BF16, unit="TFLOP/s", measured="live (this run; tools/ubench/libx2i_ubench.so, HIP events)",
+               clock_power=bf["clock_power"], operand_held=out.get(3), e4m3=out.get(2),
+               note="v_mfma_f32_16x16x32_bf16 on random operands held in registers, one wave per SIMD on every CU, no memory traffic, %d launches of "
+                    "%.0f ms (median of all but the first): what the power management lets the matrix pipe alone do on this box" % (launches, bf["ms_per_launch"]))
+    if out.get(2):
+        res["e4m3"]["frac_of_peak"] = out[2]["achieved"] * 1e12 / PEAK_FP8
+    _PIPE_ALONE = res
+    return res
+
+
 def gemm_roofline(B, rounds=6, per_round=8):
     """Dominant kernel: the bf16 MFMA GEMM.  Times the two largest launch shapes of a single-stream block -- proj_mlp + bias + GELU
     (M=B*4608, N=12288, K=3072) and proj_out + bias (N=3072, K=15360; in the model this launch also adds the gated residual) -- with
@@ -198,15 +251,16 @@ def gemm_roofline(B, rounds=6, per_round=8):
         except (KeyError, ValueError):
             traffic = None
     alg_bytes = sum(2.0 * (M * K + N * K + M * N) for (M, N, K, _) in shapes)
+    pipe = matrix_pipe_alone_live() or dict(achieved=1941.0, frac_of_peak=0.776, unit="TFLOP/s", measured="committed profile (builder's box, not this run)",
+                                            source="profiles/r05o_mfma_power_sustained_fixed_ubench.log",
+                                            note="v_mfma_f32_16x16x32_bf16 on random operands held in registers, no memory traffic, sustained "
+                                                 "(tools/ubench/libx2i_ubench.so was not built: committed figure)")
     return dict(bound="mfma", achieved=flt / t_med / 1e12, peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=flt / t_med / PEAK_BF16,
                 frac_best=flt / t_min / PEAK_BF16, frac_worst=flt / t_max / PEAK_BF16,
                 probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", statistic="median round (frac), fastest (frac_best)",
                            us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times], clock_power=power),
                 measured="live (HIP events on the launch stream, this run)",
-                matrix_pipe_alone=dict(achieved=1941.0, frac_of_peak=0.776, unit="TFLOP/s", measured="committed profile (builder's box, not this run)",
-                                       source="profiles/r05o_mfma_power_sustained_fixed_ubench.log",
-                                       note="v_mfma_f32_16x16x32_bf16 on random operands held in registers, no memory traffic, sustained: what the power "
-                                            "management lets the matrix pipe do on this part (2.05 GHz at 1.25 kW); zeros run at the full 2.4 GHz"),
+                matrix_pipe_alone=pipe, frac_of_pipe_alone=(flt / t_med / 1e12) / pipe["achieved"],
                 in_step=_in_step_gemm_rate(B),
                 traffic=traffic, traffic_measured="committed PMC profile (builder's box, not this run)" if traffic is not None else None,
                 traffic_source=src, algorithmic_bytes=alg_bytes, kernel="gemm256p_kernel (bf16 instantiations)",
@@ -344,7 +398,10 @@ def gemm_roofline_fp8(B, rounds=6, per_round=8):
     pair = sorted(times[0][r] + times[1][r] for r in range(rounds))
     t_med, t_min = pair[len(pair) // 2], pair[0]
     alg_bytes = (B * S * D + 4 * D * D + B * S * 4 * D) + (B * S * 5 * D + 5 * D * D + 2 * 2 * B * S * D)
+    pipe = matrix_pipe_alone_live()
+    p8 = pipe.get("e4m3") if pipe else None
     return dict(bound="mfma", achieved=fl / t_med / 1e12, peak=PEAK_FP8 / 1e12, unit="TFLOP/s", frac=fl / t_med / PEAK_FP8,
+                matrix_pipe_alone=p8, frac_of_pipe_alone=(fl / t_med / 1e12) / p8["achieved"] if p8 else None,
                 frac_best=fl / t_min / PEAK_FP8, measured="live (HIP events on the launch stream, this run)", traffic=None, algorithmic_bytes=float(alg_bytes), kernel=kernel,
                 probe=dict(rounds=rounds, launches_per_round=per_round, order="interleaved", clock_power=power,
                            us_per_launch=[[round(t * 1e6, 1) for t in row] for row in times]),
@@ -683,7 +740,7 @@ def main(argv=None):
                                            "model_tflops_per_gpu": fl * N / (ms8 * 1e-3) / 1e12,
                                            "gemm_flops_on_e4m3": 0.72 if mode == "mlp" else 0.97}
                 r8 = gemm_roofline_fp8(B)
-                line["fp8_mlp"]["roofline"] = line["fp8_all"]["roofline"] = {k: r8[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_best", "kernel", "shapes")}
+                line["fp8_mlp"]["roofline"] = line["fp8_all"]["roofline"] = {k: r8[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_best", "frac_of_pipe_alone", "kernel", "shapes")}
                 model.enable_fp8(None)
                 ops.streamk_check(sync=True)
             if not args.no_cpu_baseline and world == 1 and args.config == 2:

@@ -86,16 +86,42 @@ VT = torch.zeros((4, H, 128, Sj), device=DEV, dtype=torch.bfloat16)
 nq, nk = (torch.ones((128,), device=DEV, dtype=torch.bfloat16) for _ in range(2))
 ang = torch.randn((Sj, 64), device=DEV, generator=g)
 cos, sin = torch.cos(ang).repeat_interleave(2, 1).contiguous(), torch.sin(ang).repeat_interleave(2, 1).contiguous()
-for it in range(4):
+# round 6: what the fused epilogue's ~75 us per launch ARE -- the same launch with parts of the epilogue removed (measurement
+# library only, wrong results by design): per-kind mean gap between two K-loop statements over the first 16 workgroups, and the launch time
+PARTS = ((80, "product epilogue"), (86, "no cos / sin loads"), (87, "no 16-lane RMS reduction"), (88, "no Q / K stores"), (89, "no V^T stores"),
+         (90, "q / k tiles parked only"), (91, "v tiles parked only"), (79, "no epilogue at all"))
+
+
+def launch_us(mode, iters=10):
+    f = lambda: ops.gemm_qkv(A, Wq, bq, Q, Kk, VT, nq, nk, cos, sin, M=M, H=H, Spad=Sj, tok_off=0, rows_per_sample=Sj, vt_perm=True, _act2=mode, _bias2=dbg.view(torch.float32))  # noqa: E731
+    for _ in range(3):
+        f()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+for mode, what in PARTS if "--qkv-parts" in sys.argv else PARTS[:1]:
+    us = launch_us(mode)
     dbg.zero_()
-    ops.gemm_qkv(A, Wq, bq, Q, Kk, VT, nq, nk, cos, sin, M=M, H=H, Spad=Sj, tok_off=0, rows_per_sample=Sj, _act2=80, _bias2=dbg.view(torch.float32))
-torch.cuda.synchronize()
-t = dbg.view(16, 32, 2).cpu()
-print("== fused QKV epilogue (tiles of the q / k / v sections in the XCD order)")
-for w in (0, 1, 2):
-    row = t[w]
-    n = int((row[:, 0] > 0).sum())
-    dur = [(int(row[i, 1]) - int(row[i, 0])) / 100 for i in range(n)]
-    gap = [(int(row[i + 1, 0]) - int(row[i, 1])) / 100 for i in range(n - 1)]
-    print(f"wg {w}: {n} units; K-loop us: " + " ".join(f"{d:.1f}" for d in dur))
-    print("        gaps us: " + " ".join(f"{d:.2f}" for d in gap))
+    ops.gemm_qkv(A, Wq, bq, Q, Kk, VT, nq, nk, cos, sin, M=M, H=H, Spad=Sj, tok_off=0, rows_per_sample=Sj, vt_perm=True, _act2=mode, _bias2=dbg.view(torch.float32))
+    torch.cuda.synchronize()
+    t = dbg.view(16, 32, 2).cpu()
+    print(f"== fused QKV epilogue, {what}: {us:.1f} us per launch (tiles of the q / k / v sections in the XCD order)")
+    gaps = []
+    for w in range(16):
+        row = t[w]
+        n = int((row[:, 0] > 0).sum())
+        dur = [(int(row[i, 1]) - int(row[i, 0])) / 100 for i in range(n)]
+        gap = [(int(row[i + 1, 0]) - int(row[i, 1])) / 100 for i in range(n - 1)]
+        gaps += gap
+        if w < 3:
+            print(f"wg {w}: {n} units; K-loop us: " + " ".join(f"{d:.1f}" for d in dur))
+            print("        gaps us: " + " ".join(f"{d:.2f}" for d in gap))
+    if gaps:
+        gs = sorted(gaps)
+        print(f"   mean gap {sum(gaps) / len(gaps):.2f} us, median {gs[len(gs) // 2]:.2f}, min {gs[0]:.2f}, max {gs[-1]:.2f} over {len(gaps)} gaps of 16 workgroups")

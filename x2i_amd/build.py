@@ -56,6 +56,25 @@ def _link(lib, objs, changed, verbose):
         print("up to date:", lib)
 
 
+# third, tiny library: register-resident MFMA streams for bench.py's live `matrix_pipe_alone` figure (tools/ubench/mfma_pipe_lib.hip).
+# Measurement only: never linked into, or loaded by, the product library / package.
+UBENCH_SRC = os.path.join(HERE, "..", "tools", "ubench", "mfma_pipe_lib.hip")
+LIB_UBENCH = os.path.join(HERE, "..", "tools", "ubench", "libx2i_ubench.so")
+
+
+def build_ubench(force=False, verbose=True):
+    deps = [UBENCH_SRC, os.path.join(os.path.dirname(UBENCH_SRC), "mfma_power_kernel.h")]
+    if not force and os.path.exists(LIB_UBENCH) and os.path.getmtime(LIB_UBENCH) > max(os.path.getmtime(d) for d in deps):
+        return LIB_UBENCH
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-shared", "-fPIC", UBENCH_SRC, "-o", LIB_UBENCH]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (UBENCH_SRC, r.stdout, r.stderr))
+    if verbose:
+        print("built", os.path.normpath(LIB_UBENCH))
+    return LIB_UBENCH
+
+
 def build(force=False, verbose=True, ablate=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -70,6 +89,7 @@ def build(force=False, verbose=True, ablate=True):
     if ablate:
         objs = [(abl.get(n) or prod[n]) for n in prod]
         _link(LIB_ABLATE, [o for o, _ in objs], any(c for _, c in objs), verbose)
+    build_ubench(force, verbose)
     return LIB
 
 

@@ -483,6 +483,13 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
   };
   const TokMap tmap = tok_map(p, z, m_wave);
   auto token = [&](int m, int& b, int& st) { tok_of(tmap, m - m_wave, b, st); };  // rows m_wave <= m < m_wave + 128
+#ifdef X2I_ABLATION
+  // measurement only (tools/gemm_unit_timeline.py --qkv-parts; wrong results by design): 86 = no cos / sin loads, 87 = no 16-lane RMS reduction,
+  // 88 = no Q / K stores, 89 = no V^T stores, 90 = q / k tiles parked only (no read-back, arithmetic or stores), 91 = v tiles parked only
+  const int qabl = p.act2;
+#else
+  constexpr int qabl = 0;
+#endif
   if (sec < 2) {
     const int c = lane & 15, rsub = lane >> 4;  // 8-dim chunk of the head; row of the pass
     float w[8];
@@ -507,10 +514,15 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         int b, st;
         tok_of(tmap, valid ? dm : 0, b, st);
         const uint32_t co = (uint32_t)(st * 128 + c * 8) * 4u;
+        if (qabl == 86) {
+          cs[ps][0] = cs[ps][1] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+          cs[ps][2] = cs[ps][3] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        } else {
         cs[ps][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co, 0, 0));
         cs[ps][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co + 16, 0, 0));
         cs[ps][2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co, 0, 0));
         cs[ps][3] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co + 16, 0, 0));
+        }
         qoff[ps] = valid ? (uint32_t)(((b * p.q_H + head) * p.q_Spad + st) * 128 + c * 8) * 2u : 0x80000000u;
       }
     };
@@ -541,6 +553,10 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
     static_for<8>([&](auto qc) {
       constexpr int q16 = decltype(qc)::value;
       char* buf = stage + (q16 & 1) * 4096;
+      if (qabl == 90) {
+        if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
+        return;
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the chunk is parked
       bf16x8_t xv[4];                                       // its four passes' rows, requested together: one LDS round trip per chunk
@@ -560,8 +576,10 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[hf * 2 + ps][j]);
           float ss = sumsq8(x);
+          if (qabl != 87) {
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this token
+          }
           const float r = rms_rsqrt128(ss, p.q_eps);
           const float csv[8] = {cs[ps][0][0], cs[ps][0][1], cs[ps][0][2], cs[ps][0][3], cs[ps][1][0], cs[ps][1][1], cs[ps][1][2], cs[ps][1][3]};
           const float snv[8] = {cs[ps][2][0], cs[ps][2][1], cs[ps][2][2], cs[ps][2][3], cs[ps][3][0], cs[ps][3][1], cs[ps][3][2], cs[ps][3][3]};
@@ -574,8 +592,12 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (2 * q16 + hf + 1 < 16) load_cs(2 * q16 + hf + 1);  // in front of this half's stores (see the header comment)
         __builtin_amdgcn_sched_barrier(0);
+        if (qabl != 88) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) __builtin_amdgcn_raw_buffer_store_b128(outv[ps], q_rsrc, so[ps], 0, 0);
+        } else {
+          asm volatile("" ::"v"(outv[0]), "v"(outv[1]));
+        }
       });
       // (parking the next chunk HERE, behind this chunk's stores.  In front of the compute it would hide one more LDS round trip, but
       // with that order the kernel's Q, K AND V^T all come out wrong -- deterministically, also with a full LDS wait behind the park and
@@ -611,6 +633,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         });
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (qabl == 91) return;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int dp = it * 8 + dp_lo;  // dim pair of this 64-dim half
@@ -621,7 +644,9 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
           v[k] = *(const uint32_t*)(stage + row * 128 + (((dp >> 2) ^ fsw(row)) << 4) + ((dp & 3) << 2));
         }
         const int m = m_wave + cp * 64 + ch_lo * 8;
-        if (m < p.M) {
+        if (qabl == 89) {
+          asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        } else if (m < p.M) {
           const int d = h * 64 + dp * 2;
           int b, st;
           token(m, b, st);
@@ -885,7 +910,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
   };
   if (n_units == 0) return;  // (workgroup-uniform)
 #ifdef X2I_ABLATION
-  if (p.act2 >= 81) {  // measurement only: start offsets -- 82: by workgroup, spread over 80 us; 81 / 83 / 84 / 85: by XCD (w & 7) x 10 / 5 / 2.5 / 20 us
+  if (p.act2 >= 81 && p.act2 <= 85) {  // measurement only: start offsets -- 82: by workgroup, spread over 80 us; 81 / 83 / 84 / 85: by XCD (w & 7) x 10 / 5 / 2.5 / 20 us
     int n = (w & 7) * 10;
     if (p.act2 == 82) n = (((w * 167) & 255) * 80) >> 8;
     if (p.act2 == 83) n = (w & 7) * 5;
