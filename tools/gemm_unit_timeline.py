@@ -86,10 +86,9 @@ VT = torch.zeros((4, H, 128, Sj), device=DEV, dtype=torch.bfloat16)
 nq, nk = (torch.ones((128,), device=DEV, dtype=torch.bfloat16) for _ in range(2))
 ang = torch.randn((Sj, 64), device=DEV, generator=g)
 cos, sin = torch.cos(ang).repeat_interleave(2, 1).contiguous(), torch.sin(ang).repeat_interleave(2, 1).contiguous()
-# round 6: what the fused epilogue's ~75 us per launch ARE -- the same launch with parts of the epilogue removed (measurement
-# library only, wrong results by design): per-kind mean gap between two K-loop statements over the first 16 workgroups, and the launch time
-PARTS = ((80, "product epilogue"), (86, "no cos / sin loads"), (87, "no 16-lane RMS reduction"), (88, "no Q / K stores"), (89, "no V^T stores"),
-         (90, "q / k tiles parked only"), (91, "v tiles parked only"), (79, "no epilogue at all"))
+# (round 6: the split of this epilogue into its parts is tools/qkv_parts.py on PRODUCT-flag builds -- this build's timestamps and spills run the
+# q / k epilogue at 2.5x the product's time, profiles/r04ad_*, r06a_qkv_parts_measurement_build.log)
+PARTS = ((80, "product epilogue"), (79, "no epilogue at all"))
 
 
 def launch_us(mode, iters=10):
@@ -105,7 +104,7 @@ def launch_us(mode, iters=10):
     return s.elapsed_time(e) / iters * 1e3
 
 
-for mode, what in PARTS if "--qkv-parts" in sys.argv else PARTS[:1]:
+for mode, what in PARTS:
     us = launch_us(mode)
     dbg.zero_()
     ops.gemm_qkv(A, Wq, bq, Q, Kk, VT, nq, nk, cos, sin, M=M, H=H, Spad=Sj, tok_off=0, rows_per_sample=Sj, vt_perm=True, _act2=mode, _bias2=dbg.view(torch.float32))

@@ -269,6 +269,25 @@ long long x2i_conv_moments_scratch(int M, int N, int batch) {   // row blocks of
   return (long long)batch * (((long long)(M + 127) / 128 * 2) + MOM_SLABS) * (N / 2);
 }
 
+static int pad_w_of(const x2i_conv_desc* cd) { return cd->pad_w_p1 <= 0 ? cd->pad : cd->pad_w_p1 - 1; }
+// behind a convolution launch: the per-row-block partial moments (`blocks` row blocks per batch item) -> x2i_conv_desc.moments
+static int conv_moments_tail(const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream, int blocks) {
+  int rc = x2i_check_launch("conv");
+  if (rc || !cd->moments) return rc;
+  const int n2 = a->N / 2;
+  if (blocks <= 128) {   // few row blocks (small images / small batches live here): the finishing block adds them itself, in the same fixed tree
+    hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, cd->moments, blocks, n2,
+                       cd->moments_accumulate ? 1 : 0);
+    return x2i_check_launch("conv_moments_finish");
+  }
+  float* tmp = cd->moments_scratch + (long long)a->batch * blocks * n2;
+  hipLaunchKernelGGL(conv_moments_slabs_kernel, dim3(MOM_SLABS, a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, tmp, blocks, n2);
+  rc = x2i_check_launch("conv_moments_slabs");
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)tmp, cd->moments, MOM_SLABS, n2, cd->moments_accumulate ? 1 : 0);
+  return x2i_check_launch("conv_moments_finish");
+}
+
 static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream) {
   if (!a || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
   const bool conv = cd != nullptr;
@@ -346,6 +365,29 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // convolutions with >= 256 output channels: the full-line kernel's implicit-GEMM form (option conv256 = 0: 128^2 tiles, A/B)
   bool conv256 = false;
   if (conv && a->N >= 256 && a->N % 8 == 0 && tiles256 >= min256 && a->M >= 1024 && opt.conv256) conv256 = use256 = true;
+  // ... on the persistent four-wave core (gemm256c.hip: the linear kernels' hand-scheduled K-loop with the gather as a scalar tap offset + a
+  // padding mask per piece row) when the gather is affine in the tap (no fused upsampling), the whole batch fits one 2 GB descriptor and the
+  // epilogue is one it instantiates; bit-identical to the eight-wave form (option conv_w4 = 0)
+  if (conv256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
+      (((uintptr_t)a->C) & 15) == 0 && (long long)a->M < (1LL << 24) &&
+      ((long long)(a->batch - 1) * a->a_batch_stride + (long long)cd->H * cd->W * cd->Cin) * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
+      (long long)a->M * a->ldc * 2 < 0x7f000000LL && (!cd->out_row_pitch || (long long)(a->M / p.cOW) * cd->out_row_pitch * 2 < 0x7f000000LL) &&
+      (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL))) {
+    if (kern_t kc = pick_gemm256c(p.act, res)) {
+      int rc = x2i_ensure_dynamic_smem((const void*)kc, SMEM2P_BYTES);
+      if (rc) return rc;
+      GemmP pm = p;
+      pm.tilesM = (a->M + BM2 - 1) / BM2; pm.tilesN = (a->N + BN2 - 1) / BN2;
+      pm.gm = pick_gm(pm.tilesN, a->K);
+      pm.nbatch = a->batch;
+      pm.cMomBlocks = pm.tilesM * 2;
+      const int cus = x2i_num_cus();
+      const long long tiles = (long long)pm.tilesM * pm.tilesN * a->batch;
+      hipLaunchKernelGGL(kc, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pm);
+      opt.last_gemm_tile = 5256;   // (read-back for tests: the persistent four-wave convolution kernel)
+      return conv_moments_tail(a, cd, stream, pm.tilesM * 2);
+    }
+  }
   // small batches: a launch whose batch item has fewer 256^2 tiles than the chip has CUs, with a deep K, is cut along K over all CUs
   // (parallel split with fix-up, fx_for above); decided by the item's shape alone
   if (!conv && !qd && fast && kern2 && opt.gemm_w4 == 1 && persistent_ok(a, nullptr)) {
@@ -490,22 +532,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(128), 0, stream, p, a->batch);
     opt.last_gemm_tile = 0;
   }
-  if (conv && cd->moments) {
-    int rc = x2i_check_launch("conv");
-    if (rc) return rc;
-    const int blocks = (opt.last_gemm_tile == 128 ? (a->M + BM - 1) / BM : (a->M + BM2 - 1) / BM2) * 2, n2 = a->N / 2;
-    if (blocks <= 128) {   // few row blocks (small images / small batches live here): the finishing block adds them itself, in the same fixed tree
-      hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, cd->moments, blocks, n2,
-                         cd->moments_accumulate ? 1 : 0);
-      return x2i_check_launch("conv_moments_finish");
-    }
-    float* tmp = cd->moments_scratch + (long long)a->batch * blocks * n2;
-    hipLaunchKernelGGL(conv_moments_slabs_kernel, dim3(MOM_SLABS, a->batch), dim3(256), 0, stream, (const float*)cd->moments_scratch, tmp, blocks, n2);
-    rc = x2i_check_launch("conv_moments_slabs");
-    if (rc) return rc;
-    hipLaunchKernelGGL(conv_moments_finish_kernel, dim3(a->batch), dim3(256), 0, stream, (const float*)tmp, cd->moments, MOM_SLABS, n2, cd->moments_accumulate ? 1 : 0);
-    return x2i_check_launch("conv_moments_finish");
-  }
+  if (conv && cd->moments) return conv_moments_tail(a, cd, stream, (opt.last_gemm_tile == 128 ? (a->M + BM - 1) / BM : (a->M + BM2 - 1) / BM2) * 2);
   return x2i_check_launch("gemm");
 }
 

@@ -6,349 +6,12 @@
 // GEMM kernel here: bit-identical results (tested).  Launcher: gemm.hip (plain and batched launches with whole-line bf16 epilogues; the batch items' tiles form one list).
 #include <type_traits>
 #include "gemm_device.h"
+#include "gemm256p_epi.h"
 #include "gemm256w_loop.inc"
 #include "gemm256f8_loop.inc"
 
 namespace x2i_gemm {
 namespace {
-
-constexpr int P_STAGE_OFF = 2 * TILE2_BYTES;  // 128 KiB: behind the two operand buffers
-constexpr int P_STAGE_WAVE = 8192;
-
-// Epilogue of one wave (128 x 128 outputs) in eight 32-row x 64-column chunks through a double-buffered 2 x 4 KiB staging area.
-// Image of a chunk: [32 rows][128 B], 16-byte chunk ch of row r at physical chunk ch ^ ((r >> 1) & 7); a lane parks its four
-// consecutive columns with one ds_write_b64, rows leave as whole 128-byte lines (16-byte stores, 8 lines per wave instruction).
-// Same arithmetic (explicit fmaf, same rounding points) as epilogue_store_lds of the one-tile kernels: bit-identical results.
-// The chunks run as a three-stage pipeline (what bounded the first, chunk-after-chunk form of this epilogue was not store
-// bandwidth but LATENCY: per chunk one LDS round trip for the parked values plus four more, each `ds_read_b128 -> s_waitcnt -> store`
-// behind its own exec-mask branch -- 7.5 us per tile against 1.3 us of K-loop hand-over, tools/gemm_unit_timeline.py):
-//   A(q): accumulators of chunk q -> bias / activation -> bf16 -> staging buffer q & 1      (VALU + 8-byte LDS writes)
-//   B(q): the chunk's four 16-byte row pieces back from LDS                                  (issued together, ONE wait)
-//   C(q): four buffer_store_dwordx4                                                          (no branches: rows >= M fall behind the
-//         descriptor's num_records, columns >= N get the out-of-range offset bit)
-// order  A(0) | B(0) A(1) C(0) | B(1) A(2) C(1) | ...: B(q)'s LDS latency hides behind A(q+1)'s VALU work, C(q) never waits for LDS.
-// RES: out = bf16(gate * act(acc + bias) + residual), one rounding as everywhere.  The residual comes STRAIGHT INTO REGISTERS in the
-// accumulator layout (a lane's four consecutive columns = one 8-byte load; the four column groups of a row share a 128-byte line, so
-// L2 sees every line once), two chunks ahead of its use.  (The first form of this epilogue fetched residual rows by LDS-DMA into the
-// staging buffer, one chunk ahead -- all the look-ahead 8 KiB allow -- and waited ~2 us per chunk for it: 17 us per tile.)
-// e4m3 operands (F8): the accumulators hold sum_k A8 W8; the value every epilogue starts from is
-//     deq(acc) + bias = fma(acc * (w_scale[n] * alpha), a_scale[z][m], bias[n])
-// -- a multiply and an explicitly spelled fma (two instructions per element; nothing left for the compiler to contract one way
-// here and another way there): the one-tile kernel (gemm256_fp8.hip) spells it the same way, and the two are bit-identical (tested).
-// The scales are fetched BEFORE the unit's K-loop statement (deq_load: branch-free vector loads, rows / columns beyond the
-// problem read a clamped address -- their results are dropped by the stores), so their latency hides behind the K-loop.
-template <bool F8> struct Deq {};
-template <> struct Deq<true> {
-  float sw[8][4];   // w_scale[n] * alpha of this lane's 4 columns per 16-column block
-  float sr[4][2];   // a_scale of rows m_wave + c * 32 + i * 16 + (lane & 15)
-};
-template <bool F8>
-__device__ __forceinline__ void deq_load(const GemmP& p, int z, int m_wave, int n_wave, int lane, Deq<F8>& d) {
-  if constexpr (F8) {
-    const int ng = lane >> 4, mlane = lane & 15;
-    static_for<8>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const int n = n_wave + j * 16 + ng * 4;
-      f32x4_t v = {1.f, 1.f, 1.f, 1.f};
-      if (p.f_sw) v = *(const f32x4_t*)(p.f_sw + (n < p.N ? n : 0));   // (N % 8 == 0 and 16-byte aligned scales: launcher)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) d.sw[j][r] = v[r] * p.f_alpha;
-    });
-    const float* sa = p.f_sa ? p.f_sa + (long long)z * p.f_sa_bs : nullptr;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) d.sr[c][i] = sa ? sa[min(m_wave + c * 32 + i * 16 + mlane, p.M - 1)] : 1.f;
-  }
-}
-
-// e4m3 OUTPUT epilogue of one wave (x2i_gemm_fp8 with out_fp8: GELU(ff.net.0 / proj_mlp) written as the next GEMM's A operand), same
-// three-stage pipeline over eight 32-row x 64-column chunks as epilogue_chunked_pipe below, on bytes: a chunk's staging image is
-// [32 rows][64 B] (16-byte piece pc of row r at pc ^ ((r >> 1) & 3): conflict-free 4-byte parks), a lane parks its four consecutive
-// columns as one packed dword, rows leave as 64-byte runs (16-byte stores, 16 rows per wave instruction).  Arithmetic of
-// epilogue_store_fp8 (gemm256_fp8.hip): sat(act(deq(acc) + bias) * out_inv_scale) -> v_cvt_pk_fp8_f32.
-template <int ACT, bool UNIT_OUT>
-__device__ __forceinline__ void epilogue_chunked_pipe_e4m3(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                           char* stage, const Deq<true>& dq) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int mlane = lane & 15, ng = lane >> 4;
-  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
-#ifdef X2I_ABLATION
-  if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer)
-#endif
-  float bv[8][4];
-  static_for<8>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int n = n_wave + j * 16 + ng * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
-    if (n + 3 < p.N) {
-      if (p.bias) {
-        const uint2 bb = *(const uint2*)(p.bias + n);
-        bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
-        bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
-      }
-      if (b2) {
-        const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
-        bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
-      }
-    }
-  });
-  const uint32_t c_bytes = (uint32_t)((long long)(p.M - 1) * p.ldc + p.N);
-  __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((uint8_t*)p.C + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
-  // store piece `it` (0 / 1) of a chunk: row it * 16 + (lane >> 2), 16-byte piece (lane & 3) ^ swizzle(row)
-  const int srow = lane >> 2, spc = lane & 3;
-  uint32_t voff[2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = it * 16 + srow;
-      const int n = n_wave + h * 64 + ((spc ^ ((row >> 1) & 3)) << 4);
-      voff[h][it] = (n + 15 < p.N) ? (uint32_t)((long long)(m_wave + row) * p.ldc + n) : 0x80000000u;
-    }
-  asm volatile("" ::: "memory");
-  auto stage_a = [&](auto qc, auto jc, int which) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int j = decltype(jc)::value;
-    constexpr int h = q >> 2, c = q & 3;
-    char* buf = stage + which * 2048;
-    // all eight accumulators of the quarter first (the reads are volatile asm -- see the bf16 form -- and a volatile statement between
-    // two elements pins their order: with the read inside the element loop the eight dependent chains -- multiply, fma, GELU's exp and
-    // rcp, clamp -- ran strictly one after the other, ~11 cycles per instruction; read up front, the compiler interleaves them)
-    float x[8];
-    static_for<2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t;   // (through a local: a variable that appears ONLY as an asm operand inside a lambda is not captured by clang)
-        const float a = acc[h][c][i][j][r];
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(a));
-        x[i * 4 + r] = t;
-      }
-    });
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e] * dq.sw[h * 4 + j][e & 3], dq.sr[c][e >> 2], bv[h * 4 + j][e & 3]);
-    apply_act8(x, ACT);   // (GELU: eight at once, x2i_common.h; a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if constexpr (!UNIT_OUT) x[e] *= p.f_oinv;   // (out_inv_scale == 1, the model's setting: the multiply is skipped -- x * 1 is x)
-      x[e] = __builtin_amdgcn_fmed3f(x[e], -448.f, 448.f);
-    }
-    static_for<2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[i * 4], x[i * 4 + 1], 0, false);
-      pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[i * 4 + 2], x[i * 4 + 3], pk, true);
-      const int row = i * 16 + mlane;
-      *(int*)(buf + row * 64 + ((j ^ ((row >> 1) & 3)) << 4) + (ng << 2)) = pk;
-    });
-  };
-  u32x4 d[2];
-  static_for<4>([&](auto jc) { stage_a(std::integral_constant<int, 0>{}, jc, 0); });
-  static_for<8>([&](auto qc) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int h = q >> 2, c = q & 3;
-    char* buf = stage + (q & 1) * 2048;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 2; ++it) d[it] = *(const u32x4*)(buf + it * 1024 + lane * 16);
-    const uint32_t soff = (uint32_t)((long long)c * 32 * p.ldc);
-    static_for<2>([&](auto hc) {
-      constexpr int hf = decltype(hc)::value;
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (q + 1 < 8) {
-        stage_a(std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2 * hf>{}, (q + 1) & 1);
-        stage_a(std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2 * hf + 1>{}, (q + 1) & 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_raw_buffer_store_b128(d[hf], c_rsrc, voff[h][hf], soff, 0);
-    });
-  });
-}
-
-// FXADD: the accumulators hold only the LAST K range of the tile (parallel split with fix-up); `npre` other workgroups have parked the
-// sums of the earlier ranges in slabs fx_slab0, fx_slab0 + 8, ... (accumulator layout, [64 tiles][256 threads][16 B]); they are fetched a
-// chunk ahead, summed in slab order and added to the accumulators in front of the bias: out = epi((p_0 + p_1 + ...) + acc).
-template <int ACT, bool HASC2, bool RES, bool F8 = false, bool FXADD = false>
-__device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
-                                                      char* stage, const Deq<F8>& dq, int fx_slab0 = 0, int npre = 0, int tid = 0) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const int mlane = lane & 15, ng = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
-  const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
-#ifdef X2I_ABLATION
-  if (p.act2 >= 80) b2 = nullptr;  // (measurement: bias2 carries the timestamp buffer, tools/gemm_unit_timeline.py)
-#endif
-  const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
-  float bv[8][4], gv[RES ? 8 : 1][4];
-  static_for<8>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    const int n = n_wave + j * 16 + ng * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bv[j][r] = 0.f;
-      if constexpr (RES) gv[j][r] = 1.f;
-    }
-    if (n + 3 < p.N) {
-      if (p.bias) {
-        const uint2 bb = *(const uint2*)(p.bias + n);
-        bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
-        bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
-      }
-      if constexpr (RES) {
-        if (gz) {
-          const f32x4_t g4 = *(const f32x4_t*)(gz + n);
-          gv[j][0] = g4[0]; gv[j][1] = g4[1]; gv[j][2] = g4[2]; gv[j][3] = g4[3];
-        }
-      }
-      if (b2) {
-        const f32x4_t t4 = *(const f32x4_t*)(b2 + n);
-        bv[j][0] += t4[0]; bv[j][1] += t4[1]; bv[j][2] += t4[2]; bv[j][3] += t4[3];
-      }
-    }
-  });
-  // residual: descriptor of this batch item, per-lane offsets of the (i = 0 / 1, j = 0) block of the chunk at (c = 0, h = 0); a
-  // chunk's eight 8-byte loads differ by the 16-row step (i), a 32-byte immediate (j) and the scalar chunk offset
-  __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
-  uint32_t roff[2] = {0, 0};
-  if constexpr (RES) {
-    r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)z * p.r_bs), 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) roff[i] = (uint32_t)(((long long)(m_wave + i * 16 + mlane) * p.ldr + n_wave + ng * 4) * 2);
-  }
-  // fix-up partials: window of two chunks, rp[q & 1][i][j] = sum over the predecessors' slabs of accumulator tile (2c + i, 4h + j)
-  f32x4_t rp[FXADD ? 2 : 1][2][4];
-  auto load_part = [&](auto qc) {
-    if constexpr (FXADD) {
-      constexpr int q = decltype(qc)::value;
-      constexpr int h = q >> 2, c = q & 3;
-      const float* base = p.sk_slabs + (long long)fx_slab0 * (SK_SLAB_BYTES / 4) + tid * 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float* src = base + ((2 * c + i) * 8 + 4 * h + j) * 1024;
-          f32x4_t sum = *(const f32x4_t*)src;
-          for (int u = 1; u < npre; ++u) sum += *(const f32x4_t*)(src + (long long)u * 8 * (SK_SLAB_BYTES / 4));   // (the XCD's workgroups, hence their slabs, are 8 apart)
-          rp[q & 1][i][j] = sum;
-        }
-    }
-  };
-  u32x2 rres[RES ? 3 : 1][2][4];   // residual window: chunk q lives in rres[q % 3]
-  auto load_res = [&](auto qc) {
-    if constexpr (RES) {
-      constexpr int q = decltype(qc)::value;
-      constexpr int h = q >> 2, c = q & 3;
-      const uint32_t soff = (uint32_t)(((long long)c * 32 * p.ldr + h * 64) * 2);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rres[q % 3][i][j] = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, roff[i] + j * 32, soff, 0);
-    }
-  };
-  // output descriptors of this batch item: rows at or behind M are out of range (dropped by the hardware)
-  const uint32_t c_bytes = (uint32_t)(((long long)(p.M - 1) * p.ldc + p.N) * 2);
-  __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)p.C + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t c2_rsrc = c_rsrc;
-  if constexpr (HASC2) c2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 + (long long)z * p.c_bs), 0, c_bytes, 0x00020000);
-  // per-lane store offsets of the chunk at (c = 0, h): piece `it` is row it*8 + srow, 16-byte column group sch ^ swizzle(row)
-  uint32_t voff[2][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + srow;
-      const int n = n_wave + h * 64 + ((sch ^ ((row >> 1) & 7)) << 3);
-      voff[h][it] = (n + 7 < p.N) ? (uint32_t)(((long long)(m_wave + row) * p.ldc + n) * 2) : 0x80000000u;
-    }
-  asm volatile("" ::: "memory");  // the bias loads stay in front of everything below
-  // A(q), column group j of the chunk (a quarter of the stage: 8 accumulator reads, bias / activation, two 8-byte parks)
-  auto stage_a = [&](auto qc, auto jc, int pass, int which) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int j = decltype(jc)::value;
-    constexpr int h = q >> 2, c = q & 3;
-    char* buf = stage + which * 4096;
-    float x[8];   // (the quarter's eight accumulators first, then eight independent chains; GELU breadth first: see the e4m3 form)
-    static_for<2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t;   // (through a local: a variable that appears ONLY as an asm operand inside a lambda is not captured by clang)
-        const float a = acc[h][c][i][j][r];
-        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(a));
-        x[i * 4 + r] = t;
-      }
-    });
-    static_for<2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = x[i * 4 + r];
-        if constexpr (FXADD) t = rp[q & 1][i][j][r] + t;
-        if constexpr (F8) t = fmaf(t * dq.sw[h * 4 + j][r], dq.sr[c][i], bv[h * 4 + j][r]);
-        else t = t + bv[h * 4 + j][r];
-        x[i * 4 + r] = t;
-      }
-    });
-    apply_act8(x, ACT);   // (GELU: eight at once, x2i_common.h; a breadth-first GELU with scheduling barriers between its steps was SLOWER: r04q)
-    static_for<2>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = x[i * 4 + r];
-      if constexpr (RES) {
-        const u32x2 r2 = rres[q % 3][i][j];
-        v[0] = fmaf(gv[h * 4 + j][0], v[0], __uint_as_float(r2[0] << 16));
-        v[1] = fmaf(gv[h * 4 + j][1], v[1], __uint_as_float(r2[0] & 0xffff0000u));
-        v[2] = fmaf(gv[h * 4 + j][2], v[2], __uint_as_float(r2[1] << 16));
-        v[3] = fmaf(gv[h * 4 + j][3], v[3], __uint_as_float(r2[1] & 0xffff0000u));
-      }
-      if (pass == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act2);
-      }
-      const int row = i * 16 + mlane;
-      char* slot = buf + row * 128 + ((((j << 1) | (ng >> 1)) ^ ((row >> 1) & 7)) << 4) + ((ng & 1) << 3);
-      *(uint2*)slot = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-    });
-  };
-  constexpr int NPASS = HASC2 ? 2 : 1;
-  constexpr int NST = 8 * NPASS;  // pipeline steps: (chunk, pass), pass-minor; step s uses staging buffer s & 1
-  u32x4 d[4];
-  auto run_a = [&](auto sc, auto jc) {
-    constexpr int s_ = decltype(sc)::value;
-    stage_a(std::integral_constant<int, s_ / NPASS>{}, jc, s_ % NPASS, s_ & 1);
-  };
-  load_part(std::integral_constant<int, 0>{});
-  load_part(std::integral_constant<int, 1>{});
-  load_res(std::integral_constant<int, 0>{});
-  load_res(std::integral_constant<int, 1>{});
-  static_for<4>([&](auto jc) { run_a(std::integral_constant<int, 0>{}, jc); });
-  static_for<NST>([&](auto sc) {
-    constexpr int s_ = decltype(sc)::value;
-    constexpr int q = s_ / NPASS, pass = s_ % NPASS;
-    constexpr int h = q >> 2, c = q & 3;
-    char* buf = stage + (s_ & 1) * 4096;
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (RES && s_ + 2 < NST) load_res(std::integral_constant<int, s_ + 2>{});   // (window slot of chunk s-1, consumed by A(s-1))
-    if constexpr (FXADD && s_ + 2 < NST) load_part(std::integral_constant<int, s_ + 2>{});   // (slot of chunk s, consumed by A(s) in step s - 1; HASC2 is never combined with FXADD)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A(s)'s writes have landed (and B(s-1)'s reads returned long ago)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) d[it] = *(const u32x4*)(buf + it * 1024 + lane * 16);   // B(s)
-    const uint32_t soff = (uint32_t)((long long)c * 32 * p.ldc * 2);
-    // A(s+1) into the other buffer, a quarter at a time, one store of C(s) behind each quarter: a wave's stores issue at roughly one per
-    // 150 cycles whatever sits between them (tools/ubench/store_issue.hip), so the VALU work between two stores is free
-    static_for<4>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (s_ + 1 < NST) run_a(std::integral_constant<int, s_ + 1>{}, jc);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_raw_buffer_store_b128(d[j], pass == 0 ? c_rsrc : c2_rsrc, voff[h][j], soff, 0);
-    });
-  });
-}
 
 // FX with every part parked ("A": a tile cut into P equal K ranges, one workgroup each, all at work at the same time): instead of ONE
 // finisher reading P - 1 slabs and running the whole epilogue while the others idle (measured on the single-block proj_out of a 512^2
@@ -483,13 +146,19 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
   };
   const TokMap tmap = tok_map(p, z, m_wave);
   auto token = [&](int m, int& b, int& st) { tok_of(tmap, m - m_wave, b, st); };  // rows m_wave <= m < m_wave + 128
-#ifdef X2I_ABLATION
-  // measurement only (tools/gemm_unit_timeline.py --qkv-parts; wrong results by design): 86 = no cos / sin loads, 87 = no 16-lane RMS reduction,
-  // 88 = no Q / K stores, 89 = no V^T stores, 90 = q / k tiles parked only (no read-back, arithmetic or stores), 91 = v tiles parked only
-  const int qabl = p.act2;
+  // measurement only (tools/qkv_parts_build.sh builds one library per value with -DX2I_QKV_ABL=<n>; wrong results by design; never defined in
+  // the product or the ablate library -- a RUN-TIME switch here costs the instantiation registers and distorts what it measures):
+  // 86 = no cos / sin loads, 87 = no 16-lane RMS reduction, 88 = no Q / K stores, 89 = no V^T stores, 90 = q / k tiles parked only (no
+  // read-back, arithmetic or stores), 91 = v tiles parked only, 92 = no epilogue at all
+#ifdef X2I_QKV_ABL
+  constexpr int qabl = X2I_QKV_ABL;
 #else
   constexpr int qabl = 0;
 #endif
+  if constexpr (qabl == 92) {
+    asm volatile("" ::X2I_GEMM256P_OPS_ACC_IN(acc));
+    return;
+  }
   if (sec < 2) {
     const int c = lane & 15, rsub = lane >> 4;  // 8-dim chunk of the head; row of the pass
     float w[8];
@@ -514,7 +183,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         int b, st;
         tok_of(tmap, valid ? dm : 0, b, st);
         const uint32_t co = (uint32_t)(st * 128 + c * 8) * 4u;
-        if (qabl == 86) {
+        if constexpr (qabl == 86) {
           cs[ps][0] = cs[ps][1] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
           cs[ps][2] = cs[ps][3] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         } else {
@@ -553,10 +222,10 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
     static_for<8>([&](auto qc) {
       constexpr int q16 = decltype(qc)::value;
       char* buf = stage + (q16 & 1) * 4096;
-      if (qabl == 90) {
+      if constexpr (qabl == 90) {
         if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
         return;
-      }
+      } else {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the chunk is parked
       bf16x8_t xv[4];                                       // its four passes' rows, requested together: one LDS round trip per chunk
@@ -576,7 +245,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
 #pragma unroll
           for (int j = 0; j < 8; ++j) x[j] = bf16_to_f32((bf16_t)xv[hf * 2 + ps][j]);
           float ss = sumsq8(x);
-          if (qabl != 87) {
+          if constexpr (qabl != 87) {
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this token
           }
@@ -592,7 +261,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (2 * q16 + hf + 1 < 16) load_cs(2 * q16 + hf + 1);  // in front of this half's stores (see the header comment)
         __builtin_amdgcn_sched_barrier(0);
-        if (qabl != 88) {
+        if constexpr (qabl != 88) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) __builtin_amdgcn_raw_buffer_store_b128(outv[ps], q_rsrc, so[ps], 0, 0);
         } else {
@@ -603,6 +272,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
       // with that order the kernel's Q, K AND V^T all come out wrong -- deterministically, also with a full LDS wait behind the park and
       // with M0 declared clobbered -- for a reason not found; tools/qkv_persistent_vs_onetile.py is the check)
       if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
+      }
     });
   } else {
     const int ch_lo = lane & 7, dp_lo = lane >> 3;
@@ -633,7 +303,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         });
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (qabl == 91) return;
+      if constexpr (qabl == 91) return;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int dp = it * 8 + dp_lo;  // dim pair of this 64-dim half
@@ -644,7 +314,7 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
           v[k] = *(const uint32_t*)(stage + row * 128 + (((dp >> 2) ^ fsw(row)) << 4) + ((dp & 3) << 2));
         }
         const int m = m_wave + cp * 64 + ch_lo * 8;
-        if (qabl == 89) {
+        if constexpr (qabl == 89) {
           asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
         } else if (m < p.M) {
           const int d = h * 64 + dp * 2;

@@ -554,6 +554,7 @@ kern_t pick_gemm128(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop, persistent over output tiles (gemm256p.hip)
+kern_t pick_gemm256c(int act, bool res);                     // implicit-GEMM convolutions on the same core (gemm256c.hip)
 kern_t pick_gemm256p_qkv();                                 // ... with the fused QKV epilogue (x2i_gemm_qkv_bf16)
 kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);
 kern_t pick_gemm256p_fx();        // gated-residual epilogue, parallel split with fix-up (launches that cannot fill the chip with whole tiles)

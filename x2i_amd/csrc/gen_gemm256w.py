@@ -86,6 +86,40 @@ def default_slots(variant=0):
     return s
 
 
+def conv_slots():
+    """Implicit-GEMM convolution form of the persistent loop (gemm256c.hip): the A pieces of a K-tile are the gather of ONE filter tap x 64
+    input channels, so a piece's address is base(pixel) + a per-K-tile SCALAR offset (tap offset + channel slice: affine in the tap) and the
+    only per-lane work is the zero padding -- bit `tap` of the pixel's invalid-tap mask turns the offset out of range:
+      ("VA", jj):  tv = (mk[jj] << sh) & 0x80000000 | va[jj]   (sh = 31 - tap: two VALU instructions in a gap in front of piece jj)
+      ("ADV", n):  ten SALU steps behind the last A piece that move (koffa, sh, cc, rc) to the next K-tile: koffa += 128, and at the end of a
+                   tap's channel slices the tap advances (sh -= 1), at the end of a filter row koffa jumps to the next image row."""
+    s = default_slots()
+    for k in (121, 122):
+        s[k] = [e for e in s[k] if e[0] != "CNT"]
+    for jj, k in {0: 52, 1: 55, 2: 79, 3: 82, 4: 85, 5: 88, 6: 91, 7: 113}.items():
+        s.setdefault(k, []).append(("VA", jj))
+    for n in range(10):
+        s.setdefault(117 + n // 2, []).append(("ADV", n))
+    s.setdefault(123, []).append(("CNT", 0))
+    s.setdefault(124, []).append(("CNT", 1))
+    return {k: v for k, v in s.items() if v}
+
+
+ADV_LINES = ["s_add_u32 %[koffa], %[koffa], 128",
+             "s_sub_u32 %[cc], %[cc], 1",
+             "s_cmp_eq_u32 %[cc], 0",
+             "s_cselect_b32 %[cc], %[ccs], %[cc]",
+             "s_cselect_b32 %[tmp], 1, 0",
+             "s_sub_u32 %[sh], %[sh], %[tmp]",
+             "s_sub_u32 %[rc], %[rc], 1",
+             "s_cmp_eq_u32 %[rc], 0",
+             "s_cselect_b32 %[rc], %[rcs], %[rc]",
+             "s_cselect_b32 %[tmp], %[rowjump], 0",
+             "s_add_u32 %[koffa], %[koffa], %[tmp]"]
+# (eleven instructions in ten steps: the last step carries two)
+CONV_STATE_INIT = ["s_mov_b32 %[koffa], 0", "s_mov_b32 %[sh], 31", "s_mov_b32 %[cc], %[ccs]", "s_mov_b32 %[rc], %[rcs]"]
+
+
 def emit_event(ev, st):
     """-> list of asm lines; st = running stream state used to derive the wait counts."""
     kind = ev[0]
@@ -104,6 +138,15 @@ def emit_event(ev, st):
     if kind == "XA":
         return ["v_xor_b32 %[la], 0x10000, %[la]"]
     mode = st.get("mode", "W")
+    conv = st.get("conv", False)
+    if kind == "VA":
+        k = ev[1] & 3
+        m, v = ("nmk", "na") if mode in ("B1", "B2") else ("mk", "va")
+        return [f"v_lshlrev_b32 %[tv{k}], %[sh], %[{m}{ev[1]}]", f"v_and_or_b32 %[tv{k}], %[tv{k}], %[cmsb], %[{v}{ev[1]}]"]
+    if kind == "ADV":
+        return ADV_LINES[ev[1]:ev[1] + 1] if ev[1] < 9 else ADV_LINES[9:]
+    if kind == "TL" and conv and mode == "B1" and ev[1] == 0:
+        return ["s_mov_b32 %[koff], %[nk0b]"] + CONV_STATE_INIT   # the next unit starts at tap 0, channel slice 0
     if kind == "TL":
         if mode == "W":  # one-tile kernel: fetch tile min(t + 2, nk - 1)
             return [["s_add_u32 %[tl], %[tl], 1", "s_min_u32 %[tmp], %[tl], %[nkm1]", "s_lshl_b32 %[koff], %[tmp], 7"][ev[1]]]
@@ -121,6 +164,8 @@ def emit_event(ev, st):
     if kind == "DA":
         st["vm"].append(("A", st["iter"], ev[1]))
         v, r = ("na", "nra") if mode in ("B1", "B2") else ("va", "ra")
+        if conv:
+            return [f"buffer_load_dwordx4 %[tv{ev[1] & 3}], %[{r}], %[koffa] offen" + st["aux_a"] + " lds"]
         return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[{r}], %[koff] offen" + st["aux_a"] + " lds"]
     if kind == "XD":
         return ["s_xor_b32 %[dma], %[dma], 0x10000"] + (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" else [])
@@ -198,7 +243,11 @@ def check(slots):
         assert e0[0].startswith("M0") and e1[0].startswith("D") and e0[1] == e1[1] and e0[0][2] == e1[0][1], (e0, e1)
         assert p1[0] > p0[0], "M0 write and its piece must be separated by an MFMA"
     # SCC: the compare must be the last SCC-writing scalar instruction of the body
-    assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0W", "M0A", "XD") or e == ("CNT", 0))
+    assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0W", "M0A", "XD", "ADV") or e == ("CNT", 0))
+    for j in range(8):
+        if ("VA", j) in pos:   # convolution form: a piece's offset is made in an earlier gap, its temporary is free again (piece j - 4 issued)
+            assert pos[("VA", j)][0] < pos[("DA", j)][0] and (j < 4 or pos[("DA", j - 4)][0] < pos[("VA", j)][0])
+            assert all(pos[("ADV", n)][0] > pos[("DA", 7)][0] for n in range(10))
     assert pos[("LGK", "all")] > max(pos[("R0A", j)] for j in range(8))
     del bars
 
@@ -248,25 +297,32 @@ def generate(aux_a="", aux_w="", variant=0):
     return L, st["vm_n"]
 
 
-def generate_persistent(aux_a="", aux_w=""):
+def generate_persistent(aux_a="", aux_w="", conv=False):
     """Seamless form for the persistent kernel: PRO (first output tile of a workgroup: K-tiles 0 and 1, first fragments), MAIN (the nk
     K-tiles of one output tile; the last two iterations fetch K-tiles 0 / 1 of the NEXT output tile through the `na` / `nw` offsets and
     leave its first fragments in wa / aa, so the next MAIN starts multiplying at once), DRAIN (after the last tile)."""
-    slots = default_slots()
+    slots = conv_slots() if conv else default_slots()
     check(slots)
-    st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A")
-    P = ["s_nop 4", "s_mov_b32 %[koff], %[k0b]"]
+    st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A", conv=conv)
+
+    def a_piece(jj, buf):   # prologue A piece: plain offset, or the convolution gather's masked offset + scalar tap offset
+        m0 = [f"s_add_u32 m0, %[dma], {buf * 65536 + jj * 4096}"]
+        if conv:   # (the two VALU instructions are the wait state between the M0 write and the piece)
+            return m0 + emit_event(("VA", jj), dict(mode="A")) + [f"buffer_load_dwordx4 %[tv{jj & 3}], %[ra], %[koffa] offen" + aux_a + " lds"]
+        return m0 + ["s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
+    P = ["s_nop 4", "s_mov_b32 %[koff], %[k0b]"] + (CONV_STATE_INIT if conv else [])
     for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
+        P += a_piece(jj, 0)
     for jj in range(8):
         P += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
-    P += ["s_add_u32 %[koff], %[k0b], 128"]
+    P += ["s_add_u32 %[koff], %[k0b], 128"] + (ADV_LINES if conv else [])
     for jj in range(8):
         P += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
         st["vm"].append(("W", -1, jj))
     for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {65536 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
+        P += a_piece(jj, 1)
         st["vm"].append(("A", -1, jj))
+    P += ADV_LINES if conv else []
     P += ["s_waitcnt vmcnt(16)", "s_barrier"]
     for j in range(8):
         P.append(f"ds_read_b128 %[wa{j}], %[lw]" + (f" offset:{j * 2048}" if j else ""))
@@ -353,6 +409,22 @@ def main():
         txt += [f'  "{l}\\n" \\' for l in L[:-1]]
         txt.append(f'  "{L[-1]}\\n"')
         txt.append("")
+    # convolution form of the persistent statements (gemm256c.hip)
+    P, MC, MZ, D, vmc = generate_persistent(conv=True)
+    txt.append("// implicit-GEMM convolution form (gemm256c.hip) -- additional operands: mk0..7 / nmk0..7 \"v\" = invalid-tap masks of this / the next unit's")
+    txt.append("// piece rows (bit t = filter tap t lies outside the image), tv0..3 \"=&v\" scratch, c8 \"s\" = 0x80000000, koffa / sh / cc / rc \"+s\" = the gather")
+    txt.append("// state of the K-tile to fetch (byte offset of its tap + channel slice, 31 - tap, channel slices / K-tiles left in the tap / filter row),")
+    txt.append("// ccs / rcs / rowjump \"s\" = Cin / 64, KW * Cin / 64, (W - KW) * Cin * 2; tmp \"=&s\" scratch.  A unit is a whole tile (k0b = nk0b = 0).")
+    for name, L in (("X2I_GEMM256C_PRO", P), ("X2I_GEMM256C_MAIN", MC)):
+        txt.append(f"// {name}: {len(L)} lines" + (f"; vmcnt W / A: {vmc['W']} / {vmc['A']}" if "MAIN" in name else ""))
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{l}\\n" \\' for l in L[:-1]]
+        txt.append(f'  "{L[-1]}\\n"')
+        txt.append("")
+    mk = ", ".join(f'[mk{n}] "v"(mk[{n}])' for n in range(NF)) + ", " + ", ".join(f'[nmk{n}] "v"(nmk[{n}])' for n in range(NF))
+    txt.append(f"#define X2I_GEMM256C_OPS_MASK(mk, nmk) {mk}")
+    tv = ", ".join(f'[tv{n}] "=&v"(tv[{n}])' for n in range(4))
+    txt.append(f"#define X2I_GEMM256C_OPS_TMP(tv) {tv}")
     # operand lists (the asm statement itself is written out in gemm256w.hip)
     accs = ", ".join(f'[c{i * NF + j}] "+a"(acc[{j >> 2}][{i}][{j & 3}])' for i in range(NF) for j in range(NF))
     txt.append("// acc[h][i][jj]: rows 16i.., columns 64h + 16jj.. of the 128 x 128 wave tile (two halves in the layout the shared epilogues take)")
