@@ -319,3 +319,17 @@ def test_graph_policy_first_seen_shape_runs_once_and_graphs_form_an_lru():
     pipe2.graph_cache_bytes = 1
     pipe2._evict()
     assert len(pipe2._graphs) == 1
+    # every cached graph reports the device bytes it pins (static inputs + workspace + the capture's private pool: reserved-memory growth)
+    assert all(e[3] > 0 for e in pipe2._graphs.values())
+    # an option change (options select kernels; a kernel's first launch is not capturable) makes the next call of a known shape an EAGER pass
+    # under the new option state, and the capture follows on the call after it
+    from x2i_amd import _lib
+    n_eager, n_cap = pipe.graph_stats["eager"], pipe.graph_stats["captures"]
+    old = _lib.set_option("gemm_pair", 0)
+    try:
+        d = pipe(**inputs(40, 47), use_graph=True).images
+        assert pipe.graph_stats["eager"] == n_eager + 1 and pipe.graph_stats["captures"] == n_cap
+        e = pipe(**inputs(40, 47), use_graph=True).images
+        assert pipe.graph_stats["captures"] == n_cap + 1 and torch.equal(d, e)
+    finally:
+        _lib.set_option("gemm_pair", old)

@@ -144,9 +144,8 @@ def load():
     lib.x2i_is_ablation_build.restype = C.c_int
     lib.x2i_groupnorm_moments_scratch_floats.argtypes = [_i32, _i32]
     lib.x2i_groupnorm_moments_scratch_floats.restype = C.c_int64
-    if not (_VARIANT and not hasattr(lib, "x2i_conv_moments_scratch_floats")):   # (tools only: a variant library built from an older commit)
-        lib.x2i_conv_moments_scratch_floats.argtypes = [_i32, _i32, _i32]
-        lib.x2i_conv_moments_scratch_floats.restype = C.c_int64
+    lib.x2i_conv_moments_scratch_floats.argtypes = [_i32, _i32, _i32]
+    lib.x2i_conv_moments_scratch_floats.restype = C.c_int64
     lib.x2i_streamk_workspace_bytes.argtypes = []
     lib.x2i_streamk_workspace_bytes.restype = C.c_int64
     for name, argtypes in SIGNATURES.items():
@@ -160,13 +159,25 @@ def load():
     return lib
 
 
+_option_epoch = 0
+
+
 def set_option(name, value):
     """A/B / tuning switch of the library (include/x2i.h: x2i_set_option); returns the previous value."""
+    global _option_epoch
     lib = load()
     old = C.c_int64(0)
     check(lib.x2i_get_option(name.encode(), C.byref(old)), "get_option")
     check(lib.x2i_set_option(name.encode(), int(value)), "set_option")
+    if old.value != int(value):
+        _option_epoch += 1
     return old.value
+
+
+def option_epoch():
+    """Number of option CHANGES made through set_option since import.  Options select kernels; FluxPipeline keys its graph policy on this so
+    that a capture always follows an eager pass under the same option state (pipeline.py)."""
+    return _option_epoch
 
 
 def get_option(name):

@@ -10,23 +10,18 @@
 
 namespace {
 
-// PERSIST (round 6): one workgroup per CU walks the work items w, w + G, ... (item = 256 queries of one head) and re-enters the statement per item --
-// the same instruction stream, the same results; what it removes is a workgroup's dispatch (512 registers per lane: nothing else fits on the CU
-// beside it, so every dispatch is exposed)
-template <bool PERSIST>
 __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                        bf16_t* __restrict__ O, int H, int S, int Spad, int ldo, long long o_bs, float scale_log2,
-                                                       int nbatch, float* __restrict__ lse, int prescale, int nitems) {
+                                                       int nbatch, float* __restrict__ lse, int prescale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int nqt = nitems / (H * nbatch);
- for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-  int bid = item;
+  const int nqt = gridDim.x / (H * nbatch);
+  int bid = blockIdx.x;
   {
-    const int T = nitems, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int qt = bid % nqt, h = (bid / nqt) % H, b = bid / (nqt * H);
@@ -88,9 +83,6 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
                  [lim] "v"(lim), [hi] "v"(g), [kr] "s"(k_rsrc), [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2),
                  [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt), [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale)
                : "memory", "vcc", "scc", "m0", X2I_ATTN_W16_CLOBBERS);
-  if constexpr (!PERSIST) break;
-  __syncthreads();   // every wave is done with the K / V^T rings before the next item's first tiles land
- }
 }
 
 }  // namespace
@@ -99,18 +91,10 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
 int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
                              float scale_log2, int prescale, hipStream_t stream, float* lse) {
   if ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7) || (long long)S * ldo * 2 >= 0x7f000000LL) return X2I_ERR_STATE;
-  const int nitems = ((S + 255) / 256) * H * B;
-  const int cus = x2i_num_cus();
-  if (x2i_options().attn_persist && nitems > cus) {
-    const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<true>, 65536);
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
-                       ldo, o_bs, scale_log2, B, lse, prescale, nitems);
-    return x2i_check_launch("attention (w16, persistent)");
-  }
-  const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<false>, 65536);
+  const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel, 65536);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_w16_kernel<false>, dim3(nitems), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo,
-                     o_bs, scale_log2, B, lse, prescale, nitems);
+  dim3 grid(((S + 255) / 256) * H * B);
+  hipLaunchKernelGGL(attn_w16_kernel, grid, dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo,
+                     o_bs, scale_log2, B, lse, prescale);
   return x2i_check_launch("attention (w16)");
 }

@@ -320,8 +320,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     if (cd->moments) {
       if (!cd->moments_scratch) return x2i_set_error(X2I_ERR_ARG, "conv: moments without moments_scratch (x2i_conv_moments_scratch_floats)");
       if (a->N > 2048) return x2i_set_error(X2I_ERR_SHAPE, "conv: moments serve N <= 2048 (N=%d)", a->N);
-      if ((a->N & 7) || (a->ldc & 7) || (a->c_batch_stride & 7) || (((uintptr_t)a->C) & 15) || a->out_f32 || a->C2 || (((uintptr_t)cd->moments_scratch) & 15))
-        return x2i_set_error(X2I_ERR_ALIGN, "conv: moments need the whole-line bf16 epilogue (N, ldc, c_batch_stride multiples of 8, 16-byte aligned C and scratch, no f32 / second output)");
+      // (exactly the kernels' own condition for their whole-line epilogue, where the partial sums are written: with a residual whose ldr is no
+      // multiple of 4 they would take the element-wise epilogue and the reduce kernels would sum uninitialised scratch)
+      if ((a->N & 7) || (a->ldc & 7) || (a->c_batch_stride & 7) || (((uintptr_t)a->C) & 15) || a->out_f32 || a->C2 || (((uintptr_t)cd->moments_scratch) & 15) ||
+          (a->res && (a->ldr & 3)))
+        return x2i_set_error(X2I_ERR_ALIGN, "conv: moments need the whole-line bf16 epilogue (N, ldc, c_batch_stride multiples of 8, ldr a multiple of 4, 16-byte aligned C and scratch, no f32 / second output)");
       p.cMom = cd->moments_scratch;
     }
     if (cd->out_row_pitch) {

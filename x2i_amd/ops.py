@@ -123,6 +123,11 @@ def _set_ws(a):
         a.workspace, a.workspace_bytes = ws.buf.data_ptr(), ws.nbytes
 
 
+def option_epoch():
+    """x2i_set_option changes since import (x2i_amd/_lib.py): part of FluxPipeline's graph key."""
+    return _lib.option_epoch()
+
+
 def streamk_poll():
     """Enqueue an asynchronous read of every live workspace's give-up marker on the current stream (no synchronisation)."""
     for ws in list(_sk_all):

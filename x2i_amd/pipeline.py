@@ -261,7 +261,9 @@ class FluxPipeline:
 
         key = (B, prompt_embeds.shape[1], height, width, num_inference_steps, float(guidance_scale), hint is not None,
                getattr(self.transformer, "_fp8_mode", None),  # a graph captured on the bf16 path must not serve the e4m3 path
-               self.hoist_modulation)
+               self.hoist_modulation,
+               ops.option_epoch())   # x2i_set_option calls since import: options select kernels, and a kernel's first launch raises its dynamic-LDS
+                                     # attribute (not capturable) -- an eager pass under the CURRENT options must come before a capture
         entry = self._graphs.get(key) if use_graph else None
         if entry is None and not (use_graph and key in self._seen):
             # eager launch sequence: the caller's choice, or a key seen for the FIRST time -- its pass IS the answer (and the warm-up of
@@ -275,16 +277,21 @@ class FluxPipeline:
                 self._seen.pop(next(iter(self._seen)))
             return FluxPipelineOutput(latents) if return_dict else (latents,)
         if entry is None:
+            # what the graph pins: static inputs + its workspace + the capture's private pool.  Measured as the growth of RESERVED memory around
+            # all three (activations freed during the capture return to the graph's private pool: they lower memory_allocated but stay pinned),
+            # with the cache emptied first so that the growth is this graph's and not a refill of cached blocks
+            torch.cuda.synchronize(device)
+            torch.cuda.empty_cache()
+            before = torch.cuda.memory_reserved(device)
             static = dict(pe=prompt_embeds.clone(), pooled=pooled_prompt_embeds.clone(), lat=latents.clone(),
                           hint=None if hint is None else hint.clone())
             # the graph owns its stream-K workspace (ops.streamk_scope): two graphs replayed on two streams never share one
-            torch.cuda.synchronize(device)
-            before = torch.cuda.memory_allocated(device)
             aux["sk_ws"] = ops.StreamKWorkspace(device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), ops.streamk_scope(aux["sk_ws"]):
                 body(static["pe"], static["pooled"], static["lat"], static["hint"])
-            nbytes = max(0, torch.cuda.memory_allocated(device) - before)   # static inputs + workspace + the capture's private pool
+            torch.cuda.synchronize(device)
+            nbytes = max(0, torch.cuda.memory_reserved(device) - before)
             entry = [graph, static, aux, nbytes]  # ids / guidance / schedule tensors must outlive the call: the graph reads them
             self._graphs[key] = entry
             self.graph_stats["captures"] += 1

@@ -240,6 +240,9 @@ class AutoencoderKL(nn.Module):
         # 1: two 3 x 2 column phases; 0: ONE 3 x 3 conv with the x2 upsampling in its gather.  Same result within the tolerance of one more
         # bf16 rounding of summed weights (_Conv.packed_up_phases; tests/test_vae_gpu.py)
         self.up_phases = int(os.environ.get("X2I_VAE_UP_PHASES", "2"))
+        if self.up_phases not in (0, 1, 2):
+            raise ValueError("X2I_VAE_UP_PHASES must be 0 (one 3x3 conv, upsampling in the gather), 1 (two column phases) or 2 (four phases), got %d"
+                             % self.up_phases)
         # X2I_VAE_EPI_MOMENTS=0: every GroupNorm takes its statistics in a pass of its own (A/B); default: from the producing conv's epilogue
         self.epilogue_moments = os.environ.get("X2I_VAE_EPI_MOMENTS", "1") != "0"
         # X2I_VAE_NARROW_CONV_OUT=0: conv_out as an implicit GEMM on the 128-column tile kernel (A/B); default: the narrow-output MFMA kernel
