@@ -282,8 +282,9 @@ int x2i_qkv_split_bf16(const void* qkv0, const void* qkv1, int32_t ld0, int32_t 
 typedef struct x2i_qkv_desc {
   const void* norm_q;  /* bf16 [128] RMSNorm weights for the q / k heads of these rows */
   const void* norm_k;
-  const float* cos;    /* f32 [S,128] interleaved-pair RoPE tables over joint positions */
-  const float* sin;
+  const float* cos;    /* f32 [S,128] interleaved-pair RoPE tables over joint positions (cos[s][2k] == cos[s][2k+1]: FluxPosEmbed's repeat_interleave) */
+  const float* sin;    /* ... or NULL: `cos` then points at the PAIR-form table f32 [S,64,2] = (cos, sin) of dim pair k -- the same values in
+                        * half the bytes; the persistent kernel's q / k epilogue fetches it two half chunks ahead (same results, bit for bit) */
   void* Q;             /* bf16 [B,H,Spad,128] */
   void* K;
   void* VT;            /* bf16 [B,H,128,Spad] */

@@ -221,6 +221,10 @@ def test_gemm_qkv_fp8_equals_gemm_fp8_then_qkv_split(B, H, St, Si):
               a_scale_batch_stride=Si, w_scale=sw) if St > 0 else dict(M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=sx, w_scale=sw)
     ops.gemm_qkv_fp8(X8, W8, bias, Q2, K2, V2, nq, nk, cos, sin, vt_perm=True, **kw)
     assert torch.equal(V2, span_permute(V1)) and torch.equal(Q2, Q1) and torch.equal(K2, K1)
+    # the pair-form RoPE table (x2i_qkv_desc.sin == NULL) on the e4m3 form: bit-identical
+    Q3, K3, V3 = bufs()
+    ops.gemm_qkv_fp8(X8, W8, bias, Q3, K3, V3, nq, nk, ops.rope_pairs(cos, sin), None, vt_perm=True, **kw)
+    assert torch.equal(V3, V2) and torch.equal(Q3, Q2) and torch.equal(K3, K2)
 
 
 def _tiny(fp8, mode="mlp"):

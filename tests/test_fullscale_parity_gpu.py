@@ -324,3 +324,37 @@ def test_full_depth_four_step_latents_and_decoded_psnr_bf16_and_fp8(full_dev_mod
         print(f"full-depth 4-step @512^2 {k}: final-latent rel-L2 {e:.3e}, decoded PSNR {psnr:.1f} dB")
         assert torch.isfinite(l.float()).all()
         assert e < bounds[k][0] and psnr > bounds[k][1], (k, e, psnr)
+
+
+def test_fp8_final_latent_drift_over_seeds(full_dev_model):
+    """the e4m3 tolerance as a TEST over several seeds instead of one figure in prose.  Full depth and width (19 + 38 blocks),
+    4 Euler steps, 512 x 512, B = 1, five (prompt, noise) seeds: rel-L2 of the final packed latents of each opt-in e4m3 configuration against the
+    bf16 HIP path on the same inputs (whose own distance to the fp32 oracle is 7.0e-3, asserted <= 2e-2 above).  Measured on MI355X
+    (profiles/r06g_test_fp8_drift_over_seeds.log): fp8_mlp 5.3e-2 .. 6.0e-2, fp8_all 5.7e-2 .. 6.4e-2 -- NEITHER configuration stays within the
+    5e-2 that SURVEY.md section 8(d) proposed for the final latents (the single-seed 4.9e-2 of the test above was a 2 % margin, not a bound;
+    BASELINE.md says so since round 6).  Asserted: the stated drift of these opt-in speed configurations, fp8_mlp <= 6.5e-2, fp8_all <= 7e-2."""
+    from x2i_amd.pipeline import FluxPipeline, FlowMatchEulerDiscreteScheduler
+    m = full_dev_model
+    H = W = 512
+    pipe = FluxPipeline(m, FlowMatchEulerDiscreteScheduler(**OS.SCHEDULER_SCHNELL))
+    worst = {"fp8_mlp": 0.0, "fp8_all": 0.0}
+    try:
+        for seed in (3, 11, 29, 47, 101):
+            pe, pooled = bf(seeded((1, 512, 4096), seed)).to(DEV), bf(seeded((1, 768), seed + 1)).to(DEV)
+            noise = bf(OS.pack_latents(torch.randn((1, 16, H // 8, W // 8), generator=torch.Generator().manual_seed(seed)))).to(DEV)
+
+            def sample():
+                return pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, num_inference_steps=4, guidance_scale=3.5, height=H, width=W,
+                            output_type="latent", latents=noise).images.float().cpu()
+            m.enable_fp8(None)
+            ref = sample()
+            for mode in ("mlp", "all"):
+                m.enable_fp8(mode)
+                e = rel_l2(sample(), ref)
+                worst["fp8_" + mode] = max(worst["fp8_" + mode], e)
+                print(f"seed {seed}: fp8_{mode} final-latent rel-L2 vs the bf16 HIP path {e:.3e}")
+    finally:
+        m.enable_fp8(None)
+    print("worst over 5 seeds:", worst)
+    assert worst["fp8_mlp"] < 6.5e-2, worst
+    assert worst["fp8_all"] < 7e-2, worst

@@ -463,6 +463,18 @@ def test_gemm_qkv_fused_equals_gemm_then_qkv_split(ops, opt, B, H, St, Si, tile)
     else:
         ops.gemm_qkv(X, W, bias, Q2, K2, V2, nq, nk, cos, sin, M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S, vt_perm=True)
     assert torch.equal(V2, span_permute(V1)) and torch.equal(Q2, Q1) and torch.equal(K2, K1)
+    # x2i_qkv_desc.sin == NULL: `cos` is the PAIR-form table f32 [S,64,2] (ops.rope_pairs) -- the same values in half the bytes, fetched two
+    # half chunks ahead by the persistent kernel's q / k epilogue (round 6): bit-identical Q / K / V^T on every kernel form of this case
+    pairs = ops.rope_pairs(cos, sin)
+    assert pairs.shape == (S, 64, 2) and torch.equal(pairs[:, :, 0], cos[:, 0::2]) and torch.equal(pairs[:, :, 1], sin[:, 1::2])
+    Q4, K4, V4 = bufs()
+    if St > 0:
+        ops.gemm_qkv_pair(dict(g_img, Q=Q4, K=K4, VT=V4, cos=pairs, sin=None), dict(g_txt, Q=Q4, K=K4, VT=V4, cos=pairs, sin=None))
+    else:
+        ops.gemm_qkv(X, W, bias, Q4, K4, V4, nq, nk, pairs, None, M=B * S, H=H, Spad=Spad, tok_off=0, rows_per_sample=S, vt_perm=True)
+    assert torch.equal(Q4, Q2) and torch.equal(K4, K2) and torch.equal(V4, V2)
+    with pytest.raises(ValueError):
+        ops.rope_pairs(cos + torch.arange(128, device=DEV) * 1e-3, sin)   # not an interleaved-pair table: refused
 
 
 def test_rope_table_matches_float64_reference(ops):

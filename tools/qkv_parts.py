@@ -36,8 +36,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
 
     def plain():
         ops.gemm(A, Wq, bq, out=C)
+    pairs = ops.rope_pairs(cos, sin)
+
+    def fpair():   # the pair-form RoPE table (x2i_qkv_desc.sin == NULL): what flux.py passes since round 6
+        ops.gemm_qkv(A, Wq, bq, Q, Kk, VT, nq, nk, pairs, None, M=M, H=H, Spad=Sj, tok_off=0, rows_per_sample=Sj, vt_perm=True)
     res = []
-    for fn in (f, plain):
+    for fn in (f, plain, fpair):
         for _ in range(5):
             fn()
         ts = []
@@ -50,7 +54,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
             torch.cuda.synchronize()
             ts.append(s.elapsed_time(e) / 10 * 1e3)
         res.append(sorted(ts)[2])
-    print("RESULT %.1f %.1f" % (res[0], res[1]))
+    print("RESULT %.1f %.1f %.1f" % (res[0], res[1], res[2]))
     sys.exit(0)
 
 rounds = 3
@@ -65,9 +69,10 @@ for r in range(rounds):
         if line:
             acc[v].append(tuple(float(x) for x in line[0].split()[1:]))
 print("fused-QKV launch M=18432 N=9216 K=3072 (B=4, span-permuted V^T); median of 5 x 10 launches per process, %d processes per library" % rounds)
-print("%-28s %10s %14s" % ("library", "fused us", "plain-bias us (same process: the box's state)"))
+print("%-28s %10s %14s %14s" % ("library", "fused us", "plain-bias us", "fused, pair-form table us"))
 for v, name in VARIANTS:
     if acc[v]:
         a = sorted(x[0] for x in acc[v])[len(acc[v]) // 2]
         b = sorted(x[1] for x in acc[v])[len(acc[v]) // 2]
-        print("%-28s %10.1f %14.1f   %s" % (name, a, b, " ".join("%.1f" % x[0] for x in acc[v])))
+        c = sorted(x[2] for x in acc[v])[len(acc[v]) // 2]
+        print("%-28s %10.1f %14.1f %14.1f   %s" % (name, a, b, c, " ".join("%.1f/%.1f" % (x[0], x[2]) for x in acc[v])))

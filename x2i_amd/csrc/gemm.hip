@@ -544,7 +544,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
 // fp8 (e4m3) operands: x2i_gemm_fp8.  One kernel family (256^2 tiles, gemm256_fp8.hip); shapes it does not serve are refused
 // with a message -- the host keeps those GEMMs on the bf16 path (there is no silent slow fallback).
 static int check_qkv_desc(const x2i_gemm_args* a, const x2i_qkv_desc* qd, const char* who) {
-  if (!qd->norm_q || !qd->norm_k || !qd->cos || !qd->sin || !qd->Q || !qd->K || !qd->VT)
+  if (!qd->norm_q || !qd->norm_k || !qd->cos || !qd->Q || !qd->K || !qd->VT)   // (sin == NULL: `cos` is the pair-form table, include/x2i.h)
     return x2i_set_error(X2I_ERR_ARG, "%s: null pointer in descriptor", who);
   if (qd->H <= 0 || a->N != 3 * qd->H * 128) return x2i_set_error(X2I_ERR_SHAPE, "%s: N=%d must be 3*H*128 (H=%d)", who, a->N, qd->H);
   if (qd->Spad % 128 || qd->rows_per_sample <= 0 || qd->tok_off < 0 || qd->tok_off + qd->rows_per_sample > qd->Spad)

@@ -173,9 +173,18 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
     __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sec ? p.q_K : p.q_Q), 0, 0x7ffffff0u, 0x00020000);
     __amdgpu_buffer_rsrc_t cos_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.q_cos, 0, 0x7ffffff0u, 0x00020000);
     __amdgpu_buffer_rsrc_t sin_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.q_sin, 0, 0x7ffffff0u, 0x00020000);
-    f32x4_t cs[2][4];   // per pass of a half chunk: cos[0..3], cos[4..7], sin[0..3], sin[4..7] of this lane's 8 dims
-    uint32_t qoff[2];   // ... and where the pass's 16 bytes of Q / K go
-    auto load_cs = [&](int half) {  // half = 2 passes (8 tokens) of the 16-token chunks
+    // pair-form RoPE table (x2i_qkv_desc: sin == NULL): f32 [S][64][2] = (cos, sin) per dim pair.  The two table forms are two instantiations of
+    // the body below (a register array indexed by a run-time set would live in scratch memory)
+    auto qk_body = [&](auto pairs_c) {
+    constexpr bool pairs = decltype(pairs_c)::value;
+    // Table rows of a half chunk (2 passes = 8 tokens), one register SET per half.  Pair form: 2 x 16 bytes per pass (a lane's four dim pairs),
+    // two sets, and the loads of half n + 2 are requested as soon as half n has been computed -- TWO halves ahead: one half (~0.4 us) did not
+    // cover a table load's latency behind the epilogue's own stores, and the q / k tiles spent most of their ~10 us waiting for it
+    // (tools/qkv_parts.py, profiles/r06b_*).  The separate cos / sin tables need twice the registers per half: one set, one half ahead.
+    f32x4_t cs[pairs ? 2 : 1][2][4];   // [set][pass][cos 0..3 | cos 4..7 | sin 0..3 | sin 4..7]  (pair form: [pairs 0, 1 | pairs 2, 3], entries 2, 3 unused)
+    uint32_t qoff[pairs ? 2 : 1][2];   // ... and where the pass's 16 bytes of Q / K go
+    auto load_cs = [&](int half, auto set_c) {
+      constexpr int set = decltype(set_c)::value;  // half = 2 passes (8 tokens) of the 16-token chunks
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) {
         const int dm = half * 8 + ps * 4 + rsub;
@@ -184,15 +193,18 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
         tok_of(tmap, valid ? dm : 0, b, st);
         const uint32_t co = (uint32_t)(st * 128 + c * 8) * 4u;
         if constexpr (qabl == 86) {
-          cs[ps][0] = cs[ps][1] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
-          cs[ps][2] = cs[ps][3] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          cs[set][ps][0] = cs[set][ps][1] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+          cs[set][ps][2] = cs[set][ps][3] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        } else if constexpr (pairs) {
+          cs[set][ps][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co, 0, 0));
+          cs[set][ps][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co + 16, 0, 0));
         } else {
-        cs[ps][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co, 0, 0));
-        cs[ps][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co + 16, 0, 0));
-        cs[ps][2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co, 0, 0));
-        cs[ps][3] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co + 16, 0, 0));
+          cs[set][ps][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co, 0, 0));
+          cs[set][ps][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(cos_rsrc, co + 16, 0, 0));
+          cs[set][ps][2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co, 0, 0));
+          cs[set][ps][3] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(sin_rsrc, co + 16, 0, 0));
         }
-        qoff[ps] = valid ? (uint32_t)(((b * p.q_H + head) * p.q_Spad + st) * 128 + c * 8) * 2u : 0x80000000u;
+        qoff[set][ps] = valid ? (uint32_t)(((b * p.q_H + head) * p.q_Spad + st) * 128 + c * 8) * 2u : 0x80000000u;
       }
     };
     auto park = [&](auto qc) {  // chunk q16 (16 tokens x 128 dims) as bf16(acc + bias) into staging buffer q16 & 1
@@ -217,7 +229,8 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
       });
     };
     asm volatile("" ::: "memory");
-    load_cs(0);
+    load_cs(0, std::integral_constant<int, 0>{});
+    if constexpr (pairs) load_cs(1, std::integral_constant<int, 1>{});
     park(std::integral_constant<int, 0>{});
     static_for<8>([&](auto qc) {
       constexpr int q16 = decltype(qc)::value;
@@ -237,6 +250,8 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
       __builtin_amdgcn_sched_barrier(0);
       static_for<2>([&](auto hfc) {
         constexpr int hf = decltype(hfc)::value;  // passes 2hf, 2hf + 1 of this chunk = half-chunk index 2 q16 + hf
+        constexpr int half = 2 * q16 + hf;
+        constexpr int set = pairs ? (half & 1) : 0;
         u32x4 outv[2];
         uint32_t so[2];
 #pragma unroll
@@ -250,16 +265,29 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
           for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // the 16 lanes of this token
           }
           const float r = rms_rsqrt128(ss, p.q_eps);
-          const float csv[8] = {cs[ps][0][0], cs[ps][0][1], cs[ps][0][2], cs[ps][0][3], cs[ps][1][0], cs[ps][1][1], cs[ps][1][2], cs[ps][1][3]};
-          const float snv[8] = {cs[ps][2][0], cs[ps][2][1], cs[ps][2][2], cs[ps][2][3], cs[ps][3][0], cs[ps][3][1], cs[ps][3][2], cs[ps][3][3]};
+          const f32x4_t t0 = cs[set][ps][0], t1 = cs[set][ps][1];
+          float csv[8], snv[8];
+          if constexpr (pairs) {
+            csv[0] = csv[1] = t0[0]; snv[0] = snv[1] = t0[1]; csv[2] = csv[3] = t0[2]; snv[2] = snv[3] = t0[3];
+            csv[4] = csv[5] = t1[0]; snv[4] = snv[5] = t1[1]; csv[6] = csv[7] = t1[2]; snv[6] = snv[7] = t1[3];
+          } else {
+            const f32x4_t t2 = cs[0][ps][2], t3 = cs[0][ps][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csv[j] = t0[j], csv[4 + j] = t1[j], snv[j] = t2[j], snv[4 + j] = t3[j];
+          }
           float o8[8];
           norm_rope8(x, r, w, csv, snv, o8);
 #pragma unroll
           for (int j = 0; j < 4; ++j) outv[ps][j] = pack_bf16x2(o8[2 * j], o8[2 * j + 1]);
-          so[ps] = qoff[ps];
+          so[ps] = qoff[set][ps];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (2 * q16 + hf + 1 < 16) load_cs(2 * q16 + hf + 1);  // in front of this half's stores (see the header comment)
+        // the next table rows in front of this half's stores (a load queued behind a store is only known to have returned once the store has)
+        if constexpr (pairs) {
+          if constexpr (half + 2 < 16) load_cs(half + 2, std::integral_constant<int, set>{});
+        } else {
+          if constexpr (half + 1 < 16) load_cs(half + 1, std::integral_constant<int, 0>{});
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (qabl != 88) {
 #pragma unroll
@@ -274,6 +302,9 @@ __device__ __forceinline__ void epilogue_qkv_chunked(const GemmP& p, f32x4_t (&a
       if constexpr (q16 + 1 < 8) park(std::integral_constant<int, q16 + 1>{});
       }
     });
+    };
+    if (p.q_sin == nullptr) qk_body(std::true_type{});
+    else qk_body(std::false_type{});
   } else {
     const int ch_lo = lane & 7, dp_lo = lane >> 3;
     const bool aligned = ((p.q_tok_off | p.q_rpb | p.q_row0 | p.M | p.q_Spad) & 7) == 0;
@@ -436,6 +467,13 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(GemmArg<PAIR> pp) {
   const int kby = khl * 64 + ((cphys ^ (3 * (wave & 1))) << 4);  // byte within the K-tile line; group parity = wave parity (4 pieces per row-group step)
   auto offsets = [&](int sel, int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8]) {  // (W is shared by the batch items: w_bs == 0)
     const GemmP& q = prob(pp, sel);
+#ifdef X2I_ABLATION
+    // measurement only (tools/gemm_fabric_price.py; wrong results by design): every workgroup READS the operand panels of a folded tile
+    // coordinate -- 75: tile (0, 0) for everybody (the panels stay in every XCD's L2: no fabric traffic), 76: a 4 x 8 tile patch (18.9 MB at
+    // K = 3072: out of L2, inside the Infinity Cache: fabric traffic as in the product, no HBM traffic) -- while the epilogue writes the real tile
+    if (p.act2 == 75) m0 = 0, n0 = 0;
+    if (p.act2 == 76) m0 &= 1023, n0 &= 2047;
+#endif
     const long long zoff = (long long)z * q.a_bs;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {

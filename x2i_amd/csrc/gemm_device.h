@@ -476,12 +476,20 @@ __device__ __forceinline__ void qkv_finish(const GemmP& p, int z, int m0, int n0
         const float r = rms_rsqrt128(ss, p.q_eps);
         int b, st;
         tok_of(tmap, row, b, st);
-        const float* cp = p.q_cos + (long long)st * 128 + c * 8;
-        const float* sp = p.q_sin + (long long)st * 128 + c * 8;
-        const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
-        const f32x4_t s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
-        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        float cs[8], sn[8];
+        if (p.q_sin) {
+          const float* cp = p.q_cos + (long long)st * 128 + c * 8;
+          const float* sp = p.q_sin + (long long)st * 128 + c * 8;
+          const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
+          const f32x4_t s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cs[j] = c0[j], cs[4 + j] = c1[j], sn[j] = s0[j], sn[4 + j] = s1[j];
+        } else {   // pair-form table (x2i_qkv_desc: sin == NULL): f32 [S][64][2] = (cos, sin) of dim pair k -- the same values, half the bytes
+          const float* pp = p.q_cos + (long long)st * 128 + c * 8;
+          const f32x4_t p0 = *(const f32x4_t*)pp, p1 = *(const f32x4_t*)(pp + 4);
+          cs[0] = cs[1] = p0[0]; sn[0] = sn[1] = p0[1]; cs[2] = cs[3] = p0[2]; sn[2] = sn[3] = p0[3];
+          cs[4] = cs[5] = p1[0]; sn[4] = sn[5] = p1[1]; cs[6] = cs[7] = p1[2]; sn[6] = sn[7] = p1[3];
+        }
         float o[8];
         norm_rope8(x, r, w, cs, sn, o);
         union { bf16x8_t v8; uint32_t uu[4]; } pk;

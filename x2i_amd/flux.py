@@ -85,6 +85,7 @@ class FluxTransformer2DModel(nn.Module):
         dev = torch.device(device)
         self._fused = {}
         self._views = []  # (param, fused name, index expression)
+        self.rope_pair_tables = os.environ.get("X2I_ROPE_PAIRS", "1") != "0"   # fused QKV epilogues read the pair-form RoPE table (denoise)
 
         def store(name, *shape):
             t = torch.empty(shape, device=dev, dtype=dtype)
@@ -327,6 +328,7 @@ class FluxTransformer2DModel(nn.Module):
         # RoPE tables: FluxPosEmbed semantics (float64 frequencies), once per prompt
         ids = torch.cat((txt_ids.to(self.device), img_ids.to(self.device)), dim=0)
         cos, sin = ops.rope_table(ids, cfg.axes_dims_rope)  # FluxPosEmbed, once per prompt (x2i_rope_table_f32)
+        pairs = ops.rope_pairs(cos, sin, check=False)                    # the same values as (cos, sin) per dim pair: what the fused QKV epilogues read
         # conditioning: text_embedder(pooled) [+ guidance_embedder(guidance*1000)]
         # per-state buffer (NOT the shared workspace): two prepared states of the same shape -- positive / negative prompts,
         # prepare A, prepare B, denoise A -- must not see each other's pooled / guidance conditioning
@@ -342,7 +344,7 @@ class FluxTransformer2DModel(nn.Module):
             gp = ops.timestep_sinusoid(g, 256, round_bf16=pooled_projections.dtype == torch.bfloat16)
             h1 = ops.skinny_linear(gp, f["tte.guidance_embedder.1.w"], f["tte.guidance_embedder.1.b"], out=ws["H1"], act_out=ACT_SILU)
             ops.skinny_linear(h1, f["tte.guidance_embedder.2.w"], f["tte.guidance_embedder.2.b"], out=cond, accumulate=True)
-        return dict(B=B, St=St, Si=Si, ctx=ctx, cos=cos, sin=sin, cond=cond, ws=ws,
+        return dict(B=B, St=St, Si=Si, ctx=ctx, cos=cos, sin=sin, rope_pairs=pairs, cond=cond, ws=ws,
                     round_bf16=pooled_projections.dtype == torch.bfloat16)
 
     MOD_GROUP = 4   # (t, sample) pairs per pass of the modulation table: x2i_skinny_linear stages its activations in LDS, and beyond four
@@ -409,6 +411,9 @@ class FluxTransformer2DModel(nn.Module):
             # ---- every AdaLN modulation vector of this step in one HBM-bound pass over 27% of the weights
             ops.skinny_linear(temb, f["mod.w"], f["mod.b"], out=MOD, act_in=ACT_SILU)
         cos, sin = state["cos"], state["sin"]
+        # what the FUSED QKV epilogues read: the pair-form table (half the bytes per token, fetched two half chunks ahead in the persistent
+        # kernel; X2I_ROPE_PAIRS=0: the separate tables, A/B -- same values, bit-identical results); x2i_qkv_split_bf16 keeps cos / sin
+        rc, rs = (state["rope_pairs"], None) if self.rope_pair_tables else (cos, sin)
         scale = 1.0 / math.sqrt(128.0)
 
         def mod(off):
@@ -444,11 +449,11 @@ class FluxTransformer2DModel(nn.Module):
                 ops.ln_modulate_fp8(X, None, ws["NRM8"], ws["RS"], B, Si, D, 0, None, None, mod(oi), mod(oi + D), Ntot,
                                     x_bs=S * D, x_offset=St * D, y8_bs=S * D, y8_offset=St * D)
                 wq, sq = fp8[p + ".qkv"]
-                ops.gemm_qkv_fp8(ws["NRM8"], wq, f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=Si, H=H,
+                ops.gemm_qkv_fp8(ws["NRM8"], wq, f[p + ".qkv.b"], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], rc, rs, M=Si, H=H,
                                  Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D, a_offset=St * D,
                                  a_scale=ws["RS"], a_scale_batch_stride=Si, w_scale=sq, q_scale=qs)
                 ops.gemm_qkv(NRM, f[p + ".cqkv.w"], f[p + ".cqkv.b"], Q, K, VT, f[p + ".norm_added_q"], f[p + ".norm_added_k"],
-                             cos, sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D, q_scale=qs)
+                             rc, rs, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B, a_batch_stride=S * D, lda=D, q_scale=qs)
             else:
                 ops.ln_modulate(X, NRM, B, S, D, St, mod(oc), mod(oc + D), mod(oi), mod(oi + D), Ntot)
             if fp8_all:
@@ -457,10 +462,10 @@ class FluxTransformer2DModel(nn.Module):
                 # q/k RMSNorm + RoPE + head split + V transpose ride in the QKV GEMM's epilogue (no [B*S, 3D] round trip)
                 # (image rows and text rows: two problems, ONE grouped launch -- the text tiles ride in the image launch's rounds)
                 g_img = dict(A=NRM, W=f[p + ".qkv.w"], bias=f[p + ".qkv.b"], Q=Q, K=K, VT=VT, norm_q=f[p + ".norm_q"], norm_k=f[p + ".norm_k"],
-                             cos=cos, sin=sin, M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
+                             cos=rc, sin=rs, M=Si, H=H, Spad=Spad, tok_off=St, rows_per_sample=Si, batch=B, a_batch_stride=S * D, lda=D,
                              a_offset=St * D, q_scale=qs, vt_perm=vp_d)
                 g_txt = dict(A=NRM, W=f[p + ".cqkv.w"], bias=f[p + ".cqkv.b"], Q=Q, K=K, VT=VT, norm_q=f[p + ".norm_added_q"],
-                             norm_k=f[p + ".norm_added_k"], cos=cos, sin=sin, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B,
+                             norm_k=f[p + ".norm_added_k"], cos=rc, sin=rs, M=St, H=H, Spad=Spad, tok_off=0, rows_per_sample=St, batch=B,
                              a_batch_stride=S * D, lda=D, q_scale=qs, vt_perm=vp_d)
                 if St > 0:
                     ops.gemm_qkv_pair(g_img, g_txt)
@@ -564,10 +569,10 @@ class FluxTransformer2DModel(nn.Module):
             w, bias = f[p + ".in.w"], f[p + ".in.b"]
             if fp8_all:
                 wq, sq = fp8[p + ".qkv"]
-                ops.gemm_qkv_fp8(ws["NRM8"], wq, bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
+                ops.gemm_qkv_fp8(ws["NRM8"], wq, bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], rc, rs, M=B * S, H=H,
                                  Spad=Spad, tok_off=0, rows_per_sample=S, a_scale=ws["RS"], w_scale=sq, q_scale=qs)
             elif fuse_qkv:
-                ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], cos, sin, M=B * S, H=H,
+                ops.gemm_qkv(NRM, w[:3 * D], bias[:3 * D], Q, K, VT, f[p + ".norm_q"], f[p + ".norm_k"], rc, rs, M=B * S, H=H,
                              Spad=Spad, tok_off=0, rows_per_sample=S, q_scale=qs, vt_perm=vp_s)
             else:
                 ops.gemm(NRM, w, bias, out=QKV, M=B * S, N=3 * D)

@@ -215,6 +215,16 @@ def gemm_pair(g0, g1):
     check(_lib.load().x2i_gemm_pair_bf16(C.byref(a0), C.byref(a1), _stream()), "gemm_pair")
 
 
+def rope_pairs(cos, sin, check=True):
+    """The interleaved-pair RoPE tables f32 [S,128] (cos[s][2k] == cos[s][2k+1]: FluxPosEmbed's repeat_interleave(2)) in PAIR form:
+    f32 [S,64,2] = (cos, sin) of dim pair k -- the same values in half the bytes.  Pass it as `cos` with sin=None to gemm_qkv / gemm_qkv_fp8
+    (include/x2i.h, x2i_qkv_desc: sin == NULL): the fused epilogues then fetch two 16-byte pieces per token and lane instead of four."""
+    # (check=False: tables that are pair-form by construction -- rope_table's -- inside a stream capture, where the comparison's sync is not allowed)
+    if check and not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
+        raise ValueError("rope_pairs: the tables are not in interleaved-pair form")
+    return torch.stack((cos[:, 0::2], sin[:, 0::2]), dim=-1).contiguous()
+
+
 def gemm_qkv_pair(g0, g1):
     """Two gemm_qkv() calls (dicts of its arguments) as one grouped launch (x2i_gemm_qkv_pair_bf16)."""
     (a0, q0), (a1, q1) = _gemm_qkv_args(**g0), _gemm_qkv_args(**g1)
@@ -248,7 +258,7 @@ def _gemm_qkv_args(A, W, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     a.act, a.out_f32 = ACT_NONE, 0
     _set_ws(a)
     q = QkvDesc()
-    q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), (sin.data_ptr() if sin is not None else None)   # sin=None: `cos` is the pair-form table (rope_pairs)
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
     q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
     q.vt_perm = 1 if vt_perm else 0
@@ -646,7 +656,7 @@ def gemm_qkv_fp8(A8, W8, bias, Q, K, VT, norm_q, norm_k, cos, sin, *, M, H, Spad
     f.w_scale = w_scale.data_ptr() if w_scale is not None else None
     f.alpha, f.out_fp8, f.out_inv_scale = float(alpha), 0, 1.0
     q = QkvDesc()
-    q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    q.norm_q, q.norm_k, q.cos, q.sin = norm_q.data_ptr(), norm_k.data_ptr(), cos.data_ptr(), (sin.data_ptr() if sin is not None else None)   # sin=None: `cos` is the pair-form table (rope_pairs)
     q.Q, q.K, q.VT = Q.data_ptr(), K.data_ptr(), VT.data_ptr()
     q.H, q.Spad, q.tok_off, q.rows_per_sample, q.eps, q.q_scale = H, Spad, tok_off, rows_per_sample, eps, q_scale
     q.vt_perm = 1 if vt_perm else 0
