@@ -69,19 +69,20 @@ const char* x2i_last_error(void);
  * "attn_w16" (1: x2i_attention_prefers_vt_perm may answer 1 -- the sampling path then uses the 16 x 16 x 32 attention kernel; 0: never; 2: at any size -- tests),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
- * "gemm_r2" (DEFAULT 0; 1: A/B -- plain bf16 launches with K % 256 == 0 take the "two residents" kernel, 256 x 128 tiles and two
- * workgroups per CU, bit-identical and measured slower: DESIGN.md section 4 round 5),
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
  * same values up to the summation order of the row statistics),
- * "conv256" (1), "attn_variant" (0 auto; 4 = 4-wave
- * kernel, 5..8 = 8-wave ping-pong forms, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale, 10 / 11 = A/B kernels on 16x16x32 MFMAs (compiler-scheduled), 12 = the hand-scheduled kernel on 16x16x32 MFMAs (11 / 12: V^T with the
- * 32-key-span permutation of attention16.hip -- tools and tests only)), "conv5_variant" (0),
+ * "conv256" (1), "conv_w4" (1: convolutions with >= 256 output channels take the persistent four-wave kernel with the hand-scheduled K-loop,
+ * csrc/gemm256c.hip; 0: the eight-wave one-tile form -- bit-identical), "attn_variant" (0 auto; 4 = 4-wave kernel, 8 = the 8-wave ping-pong
+ * kernel, 9 = the hand-scheduled one-wave-per-SIMD kernel for any scale, 12 = the hand-scheduled kernel on 16x16x32 MFMAs (V^T span-permuted by the
+ * caller -- tools and tests); the A/B forms 1..3, 5..7, 10, 11 exist only in the measurement library since round 6 and mean "automatic" here),
+ * "conv5_variant" (0),
  * "fp8" (0; 2 = x2i_ln_modulate_fp8 keeps its per-row kernel at D = 3072, bit-identical A/B); "last_gemm_tile" is a read-back for tests: the tile edge of the kernel the
  * last GEMM / conv launch took (256, 128, 0 = generic kernel; +1000 = a peeled 128^2 tail launch followed).  Unknown names
  * return X2I_ERR_ARG.  Every setting selects between
  * kernels with identical results (bit-identical where the tests say so); the measurement-only kernels ("wrong results by
  * design" ablations) are NOT in this library -- they are compiled only into libx2i_hip_ablate.so (-DX2I_ABLATION), where
- * x2i_is_ablation_build() returns 1 and the extra options "gemm_lform", "gemm_ablate", "attn_ablate" exist. */
+ * x2i_is_ablation_build() returns 1 and the extra options "gemm_lform", "gemm_ablate", "attn_ablate", "gemm_r2" (the "two residents" GEMM form,
+ * csrc/gemm_r2.hip: measured 1.6x slower) exist together with the A/B attention forms (csrc/attention16.hip, the ping-pong schedules 0 / 1). */
 int x2i_set_option(const char* name, int64_t value);
 int x2i_get_option(const char* name, int64_t* value);
 int x2i_is_ablation_build(void);

@@ -10,14 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ablation: A/B kernels that live only in the measurement library (round 6 prune) -- run on a GPU box with "
+                                       "X2I_LIB_VARIANT=ablate python -m pytest tests -m ablation; skipped everywhere else")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
 
     if torch.cuda.is_available():
+        if os.environ.get("X2I_LIB_VARIANT") != "ablate":
+            need = pytest.mark.skip(reason="A/B kernels of the measurement library: run with X2I_LIB_VARIANT=ablate")
+            for item in items:
+                if "ablation" in item.keywords:
+                    item.add_marker(need)
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:
-        if "gpu" in item.keywords:
+        if "gpu" in item.keywords or "ablation" in item.keywords:
             item.add_marker(skip)

@@ -184,13 +184,26 @@ def test_attention_forced_rescale_branch(ops):
     assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 8, 9, 10])
-@pytest.mark.parametrize("B,H,S,S0", [(1, 1, 64, 0), (2, 2, 136, 40), (1, 2, 1152, 128), (1, 3, 700, 100), (2, 1, 2000, 0)])
+_FORM_CASES = [(1, 1, 64, 0), (2, 2, 136, 40), (1, 2, 1152, 128), (1, 3, 700, 100), (2, 1, 2000, 0)]
+
+
+@pytest.mark.parametrize("variant", [4, 8, 9])
+@pytest.mark.parametrize("B,H,S,S0", _FORM_CASES)
 def test_attention_kernel_forms(ops, opt, variant, B, H, S, S0):
-    """attn_variant 4 = the 4-wave kernel, 5 / 6 = the 8-wave ping-pong kernel (attention_pp.hip) with / without defer-max, 9 = the
-    hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip: 1, 2, 3, 11, 18 and 32 key tiles, ragged last tiles), 10 = the A/B kernel on
-    16 x 16 x 32 MFMAs (attention16.hip), on
+    """attn_variant 4 = the 4-wave kernel, 8 = the 8-wave ping-pong kernel (attention_pp.hip, the product schedule), 9 = the
+    hand-scheduled one-wave-per-SIMD kernel (attention_w4.hip: 1, 2, 3, 11, 18 and 32 key tiles, ragged last tiles), on
     ragged sequence lengths (S % 64 != 0, S % 256 != 0, fewer rows than one 256-row workgroup) and with the forced-rescale spike."""
+    opt("attn_variant", variant)
+    assert _attention_case(ops, B, H, S, S0, 200 + S) < 1e-2
+    assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
+
+
+@pytest.mark.ablation
+@pytest.mark.parametrize("variant", [5, 6, 7, 10])
+@pytest.mark.parametrize("B,H,S,S0", _FORM_CASES)
+def test_attention_ab_forms_of_the_measurement_library(ops, opt, variant, B, H, S, S0):
+    """The A/B forms that live only in libx2i_hip_ablate.so since round 6: 5 / 6 = the ping-pong kernel's schedule 0 with / without defer-max,
+    7 = its schedule 1, 10 = the compiler-scheduled kernel on 16 x 16 x 32 MFMAs (attention16.hip)."""
     opt("attn_variant", variant)
     assert _attention_case(ops, B, H, S, S0, 200 + S) < 1e-2
     assert _attention_case(ops, 1, 1, 640, 64, 300, spike=True) < 1e-2
@@ -207,7 +220,7 @@ def test_attention_ping_pong_equals_four_wave_kernel_closely(ops, opt):
     K = torch.randn((B, H, Spad, 128), device=DEV, generator=gen).bfloat16()
     VT = torch.randn((B, H, 128, Spad), device=DEV, generator=gen).bfloat16()
     outs = []
-    for v in (4, 5):
+    for v in (4, 8):
         opt("attn_variant", v)
         O = torch.empty((B, S, H * 128), device=DEV, dtype=torch.bfloat16)
         ops.attention(Q, K, VT, O, B, H, S, Spad, H * 128, S * H * 128, 1 / math.sqrt(128))

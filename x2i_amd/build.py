@@ -16,7 +16,10 @@ LIB = os.path.join(HERE, "libx2i_hip.so")
 # measurement-only library for tools/ (ablation kernels that are "wrong results by design", the k-half-unit GEMM form):
 # same sources, the files below recompiled with -DX2I_ABLATION.  Never loaded by the product package.
 LIB_ABLATE = os.path.join(HERE, "libx2i_hip_ablate.so")
-ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm_r2.hip", "gemm256w.hip", "gemm256p.hip", "attention.hip", "c_api.hip")
+ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm_r2.hip", "gemm256w.hip", "gemm256p.hip", "attention.hip", "attention16.hip", "attention_pp.hip", "c_api.hip")
+# A/B kernels that no product path selects (round 6 prune): compiled and linked ONLY into the measurement library -- gemm_r2.hip (the "two
+# residents" GEMM, measured 1.6x slower), attention16.hip (compiler-scheduled 16 x 16 x 32 attention, superseded by the generated attention_w16.hip)
+ABLATE_ONLY_SRCS = ("gemm_r2.hip", "attention16.hip")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=fast"]
 
@@ -78,7 +81,7 @@ def build_ubench(force=False, verbose=True):
 def build(force=False, verbose=True, ablate=True):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    jobs = [(s, False) for s in srcs]
+    jobs = [(s, False) for s in srcs if os.path.basename(s) not in ABLATE_ONLY_SRCS]
     if ablate:
         jobs += [(s, True) for s in srcs if os.path.basename(s) in ABLATE_SRCS]
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
@@ -87,7 +90,7 @@ def build(force=False, verbose=True, ablate=True):
     abl = {os.path.basename(j[0]): r for j, r in zip(jobs, res) if j[1]}
     _link(LIB, [o for o, _ in prod.values()], any(c for _, c in prod.values()), verbose)
     if ablate:
-        objs = [(abl.get(n) or prod[n]) for n in prod]
+        objs = [(abl.get(n) or prod[n]) for n in prod] + [abl[n] for n in ABLATE_ONLY_SRCS if n in abl]
         _link(LIB_ABLATE, [o for o, _ in objs], any(c for _, c in objs), verbose)
     build_ubench(force, verbose)
     return LIB

@@ -337,10 +337,12 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
     const int rc = x2i_launch_attention_w16(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, unit ? 0 : 1, stream, lse);
     if (rc != X2I_ERR_STATE) return rc;
   }
+#ifdef X2I_ABLATION   // (measurement library only since round 6)
   if ((var == 10 || var == 11) && !out8) {   // (11: V^T arrives with the 32-key-span permutation of attention16.hip -- tools only)   // A/B: the 16 x 16 x 32 MFMA shape (attention16.hip; compare with variant 4, the same organisation on 32 x 32 x 16)
     const int rc = x2i_launch_attention_16(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, lse, var == 11);
     if (rc != X2I_ERR_STATE) return rc;
   }
+#endif
   // the 8-wave ping-pong kernel (attention_pp.hip)
   if ((var == 0 && (long long)((S + 255) / 256) * H * B >= 256) || var == 5 || var == 6 || var == 7 || var == 8) {
     const int rc = x2i_launch_attention_pp(Q, K, VT, O, B, H, S, Spad, ldo, o_bs, scale_log2, stream, out8, oinv, var == 6 ? 0 : 8, lse);
@@ -379,10 +381,13 @@ int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, 
   else if (abl == 32) X2I_ATTN_LAUNCH_ABL(32)
   else
 #endif
+#ifdef X2I_ABLATION   // (A/B forms 1 = eight lock-step waves, 2 = no defer-max, 3 = both: measurement library only since round 6)
   if (var == 1) X2I_ATTN_LAUNCH(8, 8)
   else if (var == 2) X2I_ATTN_LAUNCH(4, 0)
   else if (var == 3) X2I_ATTN_LAUNCH(8, 0)
-  else X2I_ATTN_LAUNCH(4, 8)
+  else
+#endif
+  X2I_ATTN_LAUNCH(4, 8)
 #undef X2I_ATTN_LAUNCH
   return x2i_check_launch("attention");
 }

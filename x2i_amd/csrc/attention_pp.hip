@@ -432,9 +432,15 @@ int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* 
   const int var = x2i_options().attn_variant;
   // schedule: 2 (four-deep rings, fragment prefetch in the vector phase; +2 % measured) for the bf16 / defer-max launches unless an
   // A/B variant asks otherwise (5 = schedule 0, 7 = schedule 1); the e4m3-output and THR = 0 instantiations stay on schedule 0
+#ifdef X2I_ABLATION
   const int sch = var == 7 ? 1 : (var == 8 || (var != 5 && var != 6 && !out8 && thr != 0)) ? 2 : 0;
+#else   // product: schedule 2 for bf16 outputs, schedule 0 for the e4m3-output instantiation (the A/B schedules live in the measurement library)
+  (void)var;
+  const int sch = out8 ? 0 : 2;
+#endif
   const size_t shm = (sch == 2 ? 4 : sch ? 3 : 2) * (KTILE + VTILE);
   dim3 grid(((S + 255) / 256) * H * B);
+#ifdef X2I_ABLATION
   if (sch == 1 && !out8) {
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 1>, (int)shm);
     if (rc_) return rc_;
@@ -442,6 +448,7 @@ int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* 
                        (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv, lse);
     return x2i_check_launch("attention");
   }
+#endif
   if (sch == 2 && !out8) {
     const int rc_ = x2i_ensure_dynamic_smem((const void*)attn_pp_kernel<8, false, 2>, (int)shm);
     if (rc_) return rc_;
@@ -457,8 +464,12 @@ int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* 
                        (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo, o_bs, scale_log2, B, oinv, lse);                          \
   }
   if (out8) X2I_PP(8, true)
+#ifdef X2I_ABLATION
   else if (thr == 0) X2I_PP(0, false)
   else X2I_PP(8, false)
+#else
+  else return X2I_ERR_STATE;   // (not reachable: bf16 outputs took schedule 2 above)
+#endif
 #undef X2I_PP
   return x2i_check_launch("attention");
 }

@@ -413,14 +413,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
     }
     if (frc) return frc;
   }
+#ifdef X2I_ABLATION   // (measurement library only since round 6: measured 1.57-1.62x slower than the persistent kernel)
   // A/B (option gemm_r2): the "two residents" form -- 256 x 128 tiles, two workgroups per CU, epilogues hidden behind the other
   // workgroup's K-loop; whole K-tiles in groups of four
   if (opt.gemm_r2 && !conv && !qd && fast && !f32 && a->K % (4 * BK) == 0 && a->M >= 256 && a->N >= 128 && !a->w_batch_stride) {
-#ifdef X2I_ABLATION
     const int var = opt.gemm_ablate;
-#else
-    const int var = 0;
-#endif
     if (kern_t kr = pick_gemm_r2(p.act, res, f32, c2, var)) {
       const int rc = x2i_ensure_dynamic_smem((const void*)kr, SMEM_R2_BYTES);
       if (rc) return rc;
@@ -432,6 +429,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       return x2i_check_launch("gemm (r2)");
     }
   }
+#endif
   if (force == 128) use256 = false;
   if (force == 256 && !conv) use256 = true;
   if (conv && !conv256) use256 = false;

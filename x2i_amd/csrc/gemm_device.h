@@ -568,7 +568,7 @@ kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);
 kern_t pick_gemm256p_fx();        // gated-residual epilogue, parallel split with fix-up (launches that cannot fill the chip with whole tiles)
 kern2_t pick_gemm256p_pair_fx();  // ... grouped form     // ... over the tiles of two problems (x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16)
 constexpr int SMEM2P_BYTES = 2 * TILE2_BYTES + 4 * 8192;     // 128 KiB operand ring + 4 x 8 KiB staging = all 160 KiB
-kern_t pick_gemm_r2(int act, bool res, bool f32, bool c2, int var);  // 256 x 128 tiles, two resident workgroups per CU (gemm_r2.hip); var: measurement builds
+kern_t pick_gemm_r2(int act, bool res, bool f32, bool c2, int var);  // (measurement library only)  // 256 x 128 tiles, two resident workgroups per CU (gemm_r2.hip); var: measurement builds
 constexpr int SMEM_R2_BYTES = 4 * 16384;                     // 4-stage W ring (reused as 4 x 9 KiB epilogue staging)
 kern_t pick_gemm256_fp8(int act, bool res, bool out8);
 kern_t pick_gemm256p_fp8(int act, bool res, bool out8, bool qkv);  // ... in the persistent four-wave form (gemm256p.hip, gen_gemm256f8.py)  // e4m3 operands, MX-scaled K = 128 MFMA (gemm256_fp8.hip)
