@@ -18,6 +18,9 @@ def pytest_collection_modifyitems(config, items):
     import torch
 
     if torch.cuda.is_available():
+        # the fp32 CPU oracle of the full-depth parity tests: torch's CPU GEMMs peak near half the physical cores on the 2-socket hosts of the pool
+        # (bench.py's cpu_baseline pins the same count); the default -- every hardware thread -- ran those tests 2x slower
+        torch.set_num_threads(max(1, min(64, (os.cpu_count() or 4) // 4)))
         if os.environ.get("X2I_LIB_VARIANT") != "ablate":
             need = pytest.mark.skip(reason="A/B kernels of the measurement library: run with X2I_LIB_VARIANT=ablate")
             for item in items:

@@ -18,20 +18,36 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
-def _both(fn):
-    """fn() under conv_w4 = 1 and 0 -> (new, old, tile read-backs)."""
+def _flat(o):
+    return [t.float().flatten() for t in (o if isinstance(o, tuple) else (o,))]
+
+
+def _both(fn, tile_new=5256):
+    """fn() under conv_w4 = 1 and 0 -> (new, old, tile read-backs).  The new kernels run in the OTHER kernels' K order here (conv_korder = 0: the
+    bit-identity claim); their product order (conv_korder = 1: a filter row's taps back to back, so their shifted re-reads hit L2) sums the same
+    products in another order and is checked against it with a tolerance: every output tensor of fn() within 2e-3 (rel-L2)."""
     from x2i_amd import _lib
     out = []
     tiles = []
     for v in (1, 0):
         _lib.set_option("conv_w4", v)
+        _lib.set_option("conv_korder", 0)
         _lib.set_option("gemm_min256", 1)    # (the 256^2 convolution kernels also for the few tiles of a test-sized image)
         try:
             out.append(fn())
             tiles.append(_lib.get_option("last_gemm_tile"))
         finally:
             _lib.set_option("conv_w4", 1)
+            _lib.set_option("conv_korder", 1)
             _lib.set_option("gemm_min256", 128)
+    _lib.set_option("gemm_min256", 1)
+    try:
+        prod = fn()                           # the product configuration: conv_w4 = 1, conv_korder = 1
+        assert _lib.get_option("last_gemm_tile") == tile_new
+    finally:
+        _lib.set_option("gemm_min256", 128)
+    for a, b in zip(_flat(prod), _flat(out[0])):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 2e-3
     return out[0], out[1], tiles
 
 
@@ -151,3 +167,68 @@ def test_conv_w4_batch_independence():
     finally:
         _lib.set_option("gemm_min256", 128)
     assert torch.equal(y3[1:2], y1)
+
+
+# ---- <= 128 output channels: the 512 x 128 tiles of csrc/gemm512c.hip (epilogue straight from registers) against the 128^2 kernel
+CASES128 = [
+    # Cin, Cout, KH, KW, stride, pad, H, W, B
+    (128, 128, 3, 3, 1, 1, 64, 64, 2),     # the VAE's last up block / ControlNeXt ResnetBlock
+    (256, 128, 3, 3, 1, 1, 48, 80, 2),     # M = 3840: 7.5 tiles of 512 (ragged last tile), rows of 80 pixels straddle the tiles
+    (128, 128, 5, 5, 2, 2, 128, 96, 2),    # the composed conv2 -> Downsample2D chain (25 taps, stride 2)
+    (128, 128, 3, 3, 2, 1, 128, 128, 1),   # Downsample2D
+    (256, 128, 1, 1, 1, 0, 64, 64, 2),     # conv_shortcut (1 x 1: K = 256, four K-tiles)
+    (64, 128, 3, 3, 1, 1, 72, 64, 2),      # ControlNeXt embedding conv (Cin = 64: the tap advances every K-tile)
+    (128, 96, 3, 3, 1, 1, 64, 48, 2),      # fewer than 128 output channels: the tile's last 32 columns are out of range
+]
+
+
+def _both128(fn):
+    return _both(fn, tile_new=5512)
+
+
+@pytest.mark.parametrize("Cin,Cout,KH,KW,s,p,H,W,B", CASES128)
+def test_conv512_bit_identical_to_the_128_tile_kernel(Cin, Cout, KH, KW, s, p, H, W, B):
+    from x2i_amd import ops
+    x = bf(seeded((B, Cin, H, W), 41))
+    w = bf(seeded((Cout, Cin, KH, KW), 42) / (KH * KW * Cin) ** 0.5)
+    b = bf(seeded((Cout,), 43))
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+    ref = F.conv2d(x.float(), w.float(), b.float(), stride=s, padding=p)
+    res = bf(seeded(tuple(ref.shape), 45)).permute(0, 2, 3, 1).contiguous().to(DEV)
+    b2 = seeded((B, Cout), 44)
+    for kw, want in ((dict(), ref), (dict(res=res), ref + res.float().permute(0, 3, 1, 2).cpu()),
+                     (dict(act=ops.ACT_RELU, bias2=b2.to(DEV)), torch.relu(ref + b2[:, :, None, None]))):
+        def run():
+            mom = torch.zeros((B, Cout, 2), device=DEV)
+            y = ops.conv2d_nhwc(xn, wp, b.to(DEV), H, W, Cin, Cout, KH, KW, s, p, moments=mom, **kw)
+            return y, mom
+        (yn, mn), (yo, mo), tiles = _both128(run)
+        assert tiles == [5512, 128], tiles
+        assert torch.equal(yn, yo)                               # same MFMA, same k order, same epilogue arithmetic
+        assert rel_l2(yn.permute(0, 3, 1, 2), want) < 1e-2
+        # moments: 128-row blocks here, 64-row blocks there -- the same sums up to the order of an f32 addition
+        assert rel_l2(mn, mo) < 1e-5 and float(mn[:, 1::4].abs().max()) == 0.0
+        q = yn.float().reshape(B, -1, Cout // 4, 4)
+        assert rel_l2(mn[:, 0::4, 0], q.sum((1, 3))) < 1e-4 and rel_l2(mn[:, 0::4, 1], (q * q).sum((1, 3))) < 1e-4
+
+
+def test_conv512_batch_independence_and_determinism():
+    from x2i_amd import _lib, ops
+    Cin, Cout, H, W = 128, 128, 64, 80
+    x = bf(seeded((3, H, W, Cin), 51)).to(DEV)
+    wp = bf(seeded((Cout, 9 * Cin), 52) / 34).to(DEV)
+    b = bf(seeded((Cout,), 53)).to(DEV)
+    _lib.set_option("gemm_min256", 1)
+    try:
+        mom = torch.zeros((3, Cout, 2), device=DEV)
+        y3 = ops.conv2d_nhwc(x, wp, b, H, W, Cin, Cout, 3, 3, 1, 1, moments=mom)
+        assert _lib.get_option("last_gemm_tile") == 5512
+        mom1 = torch.zeros((1, Cout, 2), device=DEV)
+        y1 = ops.conv2d_nhwc(x[1:2].contiguous(), wp, b, H, W, Cin, Cout, 3, 3, 1, 1, moments=mom1)
+        mom_b = torch.zeros((3, Cout, 2), device=DEV)
+        y3b = ops.conv2d_nhwc(x, wp, b, H, W, Cin, Cout, 3, 3, 1, 1, moments=mom_b)
+    finally:
+        _lib.set_option("gemm_min256", 128)
+    assert torch.equal(y3[1:2], y1) and torch.equal(mom[1:2], mom1)      # a sample's outputs and moments do not depend on its batch
+    assert torch.equal(y3, y3b) and torch.equal(mom, mom_b)              # run to run: bit-equal (fixed summation tree)

@@ -79,7 +79,9 @@ def test_conv256_kernel_vs_fp32_conv(opt, Cin, Cout, k, s, p, H, W, up):
         return ops.conv2d_nhwc(xn, wp, b.to(DEV), H, W, Cin, Cout, k, k, s, p, up=up, **kw)
 
     out = run()
-    assert _lib.get_option("last_gemm_tile") == 256, "the >= 256-channel convolution must take the 256^2 kernel"
+    # (5256: the persistent four-wave kernel, csrc/gemm256c.hip -- every gather that is affine in the tap; 256: the eight-wave kernel, which keeps
+    # the x2 upsampling fused into the gather)
+    assert _lib.get_option("last_gemm_tile") == (256 if up else 5256), "the >= 256-channel convolution must take a 256^2 kernel"
     assert out.shape == (B, OH, OW, Cout)
     assert rel_l2(out.permute(0, 3, 1, 2), ref) < 1e-2
     # epilogues the ControlNeXt / VAE graphs use on this kernel: per-sample bias2 (time embedding) + ReLU; residual add
@@ -115,7 +117,7 @@ def test_controlnext_at_1024_hint_vs_oracle():
     hint = bf(torch.rand((2, 3, 1024, 1024), generator=torch.Generator().manual_seed(5)) * 2 - 1)
     t = torch.tensor([752.0])
     o = m(hint.to(DEV), t.to(DEV))
-    assert _lib.get_option("last_gemm_tile") == 256  # mid_convs.1: 256 -> 3072, k2 s2 on the 128x128 map
+    assert _lib.get_option("last_gemm_tile") == 5256  # mid_convs.1: 256 -> 3072, k2 s2 on the 128x128 map, on the persistent four-wave conv kernel
     ref = OF.controlnext_forward(sdr, "", hint.float(), t)
     assert o["out"].shape == ref["out"].shape == (2, 3072, 64, 64) and o["scale"] == ref["scale"] == 1.0
     assert rel_l2(o["out"], ref["out"]) < 2e-2

@@ -57,3 +57,12 @@ if which == "conv":
         for _ in range(3):
             ops.conv2d_nhwc(x, wt, b, h, h, cin, cout, 3, 3, 1, 1, res=r, out=out)
         torch.cuda.synchronize()
+if which == "vaeconv":
+    # the VAE decoder's big convolutions (B = 4): <= 128 output channels at the image resolution (csrc/gemm512c.hip) and a 256-wide one (csrc/gemm256c.hip)
+    for (h, cin, cout) in [(1024, 256, 128), (1024, 128, 128), (512, 512, 256)]:
+        x, wt, b = rnd(B, h, h, cin), rnd(cout, 9 * cin, scale=0.02), rnd(cout)
+        out = torch.empty((B, h, h, cout), device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            ops.conv2d_nhwc(x, wt, b, h, h, cin, cout, 3, 3, 1, 1, out=out)
+        torch.cuda.synchronize()
+        del x, out

@@ -72,7 +72,7 @@ static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = a->out_f32;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0; p.cMom = nullptr; p.cMomBlocks = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = p.cKorder = 0; p.cMom = nullptr; p.cMomBlocks = 0;
   p.gm = 4;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
@@ -288,6 +288,38 @@ static int conv_moments_tail(const x2i_gemm_args* a, const x2i_conv_desc* cd, hi
   return x2i_check_launch("conv_moments_finish");
 }
 
+// One launch of a persistent convolution kernel (gemm256c.hip / gemm512c.hip) per CHUNK of batch items whose images fit the kernel's single 2 GB
+// input descriptor (a 1024^2 x 256-channel image is 512 MiB: four of them do not fit, two launches of two do); every chunk's tile list fills the
+// chip on its own.  Pointers of `pm` advance by whole batch items; the moments of a chunk's items are finished behind its launch.
+static int launch_conv_chunks(kern_t kc, int smem, const GemmP& p0, const x2i_gemm_args* a, const x2i_conv_desc* cd, hipStream_t stream, int mom_blocks) {
+  const long long img2 = (long long)cd->H * cd->W * cd->Cin * 2, bias_b = ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2;
+  const long long room = 0x7f000000LL - bias_b - img2;
+  if (room < 0) return X2I_ERR_STATE;
+  long long per = a->a_batch_stride > 0 ? room / (a->a_batch_stride * 2) + 1 : a->batch;
+  if (per > a->batch) per = a->batch;
+  const int cus = x2i_num_cus();
+  for (int z0 = 0; z0 < a->batch; z0 += (int)per) {
+    const int nb = (int)(a->batch - z0 < per ? a->batch - z0 : per);
+    GemmP pm = p0;
+    pm.nbatch = nb;
+    pm.A = p0.A + (long long)z0 * p0.a_bs;
+    pm.C = (void*)((bf16_t*)p0.C + (long long)z0 * p0.c_bs);
+    if (p0.res) pm.res = p0.res + (long long)z0 * p0.r_bs;
+    if (p0.bias2) pm.bias2 = p0.bias2 + (long long)z0 * p0.bias2_bs;
+    const long long tiles = (long long)pm.tilesM * pm.tilesN * nb;
+    hipLaunchKernelGGL(kc, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), smem, stream, pm);
+    if (cd->moments) {
+      x2i_gemm_args ac = *a;
+      x2i_conv_desc cc = *cd;
+      ac.batch = nb;
+      cc.moments = cd->moments + (long long)z0 * a->N * 2;
+      const int rc = conv_moments_tail(&ac, &cc, stream, mom_blocks);
+      if (rc) return rc;
+    }
+  }
+  return x2i_check_launch("conv");
+}
+
 static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, const x2i_qkv_desc* qd, hipStream_t stream) {
   if (!a || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm: null pointer");
   const bool conv = cd != nullptr;
@@ -369,11 +401,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   bool conv256 = false;
   if (conv && a->N >= 256 && a->N % 8 == 0 && tiles256 >= min256 && a->M >= 1024 && opt.conv256) conv256 = use256 = true;
   // ... on the persistent four-wave core (gemm256c.hip: the linear kernels' hand-scheduled K-loop with the gather as a scalar tap offset + a
-  // padding mask per piece row) when the gather is affine in the tap (no fused upsampling), the whole batch fits one 2 GB descriptor and the
-  // epilogue is one it instantiates; bit-identical to the eight-wave form (option conv_w4 = 0)
+  // padding mask per piece row) when the gather is affine in the tap (no fused upsampling), ONE image fits the 2 GB descriptor (batches that do not are launched in chunks)
+  // and the epilogue is one it instantiates; bit-identical to the eight-wave form (option conv_w4 = 0)
   if (conv256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
       (((uintptr_t)a->C) & 15) == 0 && (long long)a->M < (1LL << 24) &&
-      ((long long)(a->batch - 1) * a->a_batch_stride + (long long)cd->H * cd->W * cd->Cin) * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
+      (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
       (long long)a->M * a->ldc * 2 < 0x7f000000LL && (!cd->out_row_pitch || (long long)(a->M / p.cOW) * cd->out_row_pitch * 2 < 0x7f000000LL) &&
       (!res || ((a->ldr & 7) == 0 && (a->res_batch_stride & 7) == 0 && (((uintptr_t)a->res) & 15) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL))) {
     if (kern_t kc = pick_gemm256c(p.act, res)) {
@@ -382,13 +414,29 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
       GemmP pm = p;
       pm.tilesM = (a->M + BM2 - 1) / BM2; pm.tilesN = (a->N + BN2 - 1) / BN2;
       pm.gm = pick_gm(pm.tilesN, a->K);
-      pm.nbatch = a->batch;
       pm.cMomBlocks = pm.tilesM * 2;
-      const int cus = x2i_num_cus();
-      const long long tiles = (long long)pm.tilesM * pm.tilesN * a->batch;
-      hipLaunchKernelGGL(kc, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), SMEM2P_BYTES, stream, pm);
+      pm.cKorder = opt.conv_korder ? 1 : 0;
       opt.last_gemm_tile = 5256;   // (read-back for tests: the persistent four-wave convolution kernel)
-      return conv_moments_tail(a, cd, stream, pm.tilesM * 2);
+      return launch_conv_chunks(kc, SMEM2P_BYTES, pm, a, cd, stream, pm.tilesM * 2);
+    }
+  }
+  // ... and with at most 128 output channels (the VAE's last up block, ControlNeXt's 128-wide convolutions): 512 x 128 tiles on the same core
+  // (gemm512c.hip: the same wave tile and K-loop, epilogue straight from registers); outputs bit-identical to the 128^2 kernel's
+  if (conv && opt.conv_w4 && opt.gemm_tile == 0 && fast && cd->up == 0 && !cd->out_row_pitch && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && a->N > 64 && a->N <= 128 &&
+      (a->N & 7) == 0 && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 && (((uintptr_t)a->C) & 15) == 0 && a->M >= 2048 && (long long)a->M < (1LL << 24) &&
+      (long long)((a->M + 511) / 512) * a->batch >= opt.gemm_min256 &&
+      (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
+      (long long)a->M * a->ldc * 2 < 0x7f000000LL &&
+      (!res || ((a->ldr & 3) == 0 && (a->res_batch_stride & 3) == 0 && (((uintptr_t)a->res) & 7) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL))) {
+    if (kern_t kc = pick_gemm512c(p.act, res)) {
+      int rc = x2i_ensure_dynamic_smem((const void*)kc, SMEM5C_BYTES);
+      if (rc) return rc;
+      GemmP pm = p;
+      pm.tilesM = (a->M + 511) / 512; pm.tilesN = (a->N + 127) / 128;
+      pm.cMomBlocks = pm.tilesM * 4;     // (128-row wave tiles, four per 512-row tile)
+      pm.cKorder = opt.conv_korder ? 1 : 0;
+      opt.last_gemm_tile = 5512;   // (read-back for tests: the persistent 512 x 128 convolution kernel)
+      return launch_conv_chunks(kc, SMEM5C_BYTES, pm, a, cd, stream, pm.tilesM * 4);
     }
   }
   // small batches: a launch whose batch item has fewer 256^2 tiles than the chip has CUs, with a deep K, is cut along K over all CUs
@@ -599,7 +647,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   p.res = (const bf16_t*)a->res; p.r_bs = a->res_batch_stride; p.ldr = a->ldr;
   p.bias2 = a->bias2; p.bias2_bs = a->bias2_batch_stride;
   p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.out_f32 = 0;
-  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = 0; p.cMom = nullptr; p.cMomBlocks = 0;
+  p.cH = p.cW = p.cCin = p.cOW = p.cKW = p.cStride = p.cPad = p.cUp = p.cPadW = p.cRowPitch = p.cKorder = 0; p.cMom = nullptr; p.cMomBlocks = 0;
   p.q_on = 0; p.q_H = p.q_Spad = p.q_tok_off = p.q_rpb = p.q_row0 = p.q_vperm = 0; p.q_eps = 0.f; p.q_qs = 1.f;
   p.q_nq = p.q_nk = nullptr; p.q_cos = p.q_sin = nullptr; p.q_Q = p.q_K = p.q_VT = nullptr;
   if (qd) {

@@ -46,26 +46,39 @@ __global__ __launch_bounds__(256) void gemm256c_kernel(GemmP p) {
   };
   // ---- the gather's launch constants
   const int KW = p.cKW, KH = p.K / (p.cKW * p.cCin);
-  const int ccs = p.cCin / BK, rcs = KW * ccs;
-  const int rowjump = (p.cW - KW) * p.cCin * 2;
+  // K order of the launch (gen_gemm256w.py, ADV_LINES): two nested counters under the filter rows, with the increments of the image offset (A),
+  // the weight-row offset (W) and the tap shift (S = 31 - tap index) per level.  p.cKorder 1 (product): (ky, channel slice, kx) -- the taps of a
+  // filter row follow each other, so their shifted re-reads of the same image lines hit L2; 0: (ky, kx, channel slice), the weight layout's own
+  // order = the order of the other convolution kernels (bit-identical to them)
+  const int ccs = p.cCin / BK;
+  const int cin2 = p.cCin * 2;
+  // (integer arithmetic on ko = 0 / 1, not selects: a select between two constants is an i1 to the compiler, which it keeps in a VGPR -- no "s" operand)
+  const int ko = p.cKorder;   // 0 / 1 (launcher)
+  const int n0s = ccs + ko * (KW - ccs), n1s = KW + ko * (ccs - KW);
+  const int dA0 = 128 + ko * (cin2 - 128), dS0 = -ko;
+  const int dA1 = ko * (128 - KW * cin2), dS1 = ko * (KW + 1) - 1;
+  const int dA2 = (p.cW - KW) * cin2 + ko * (KW * cin2 - ccs * 128), dW2 = ko * (KW - 1) * cin2, dS2 = -ko * KW;
   const int bias_b = (p.cPad * p.cW + p.cPadW) * p.cCin * 2;   // pixel bases are made non-negative by this many bytes; the descriptor starts as far in front of A
   const float r_ow = 1.0f / (float)p.cOW;
   const uint32_t fullrow = KW >= 32 ? 0xffffffffu : ((1u << KW) - 1u);
+  uint32_t rep = 0;
+  for (int ky = 0; ky < KH; ++ky) rep |= 1u << (ky * KW);
   const int khl = lane >> 5, r8 = (lane >> 2) & 7, cphys = lane & 3;
   const int kby = khl * 64 + ((cphys ^ (3 * (wave & 1))) << 4);  // byte within the K-tile's 128-byte line (group parity = wave parity)
   auto offsets = [&](int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8], uint32_t (&mk)[8]) {
     const long long zoff = (long long)z * p.a_bs * 2 + bias_b + kby;
+    int oy = fast_div(m0 + wave * 8 + r8, p.cOW, r_ow), ox = m0 + wave * 8 + r8 - oy * p.cOW;   // piece 0's pixel; the next pieces are 32 pixels apart
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int row = (jj * 4 + wave) * 8 + r8;
       vw[jj] = (n0 + row < p.N) ? (uint32_t)((long long)(n0 + row) * p.ldw * 2 + kby) : 0x80000000u;
       const int m = m0 + row;
-      const int oy = fast_div(m, p.cOW, r_ow), ox = m - oy * p.cOW;
+      if (jj) {
+        ox += 32;
+        while (ox >= p.cOW) ox -= p.cOW, ++oy;
+      }
       const int iy0 = oy * p.cStride - p.cPad, ix0 = ox * p.cStride - p.cPadW;
-      uint32_t colbad = 0;
-      for (int kx = 0; kx < KW; ++kx) colbad |= ((unsigned)(ix0 + kx) >= (unsigned)p.cW ? 1u : 0u) << kx;
-      uint32_t mask = 0;
-      for (int ky = 0; ky < KH; ++ky) mask |= ((unsigned)(iy0 + ky) >= (unsigned)p.cH ? fullrow : colbad) << (ky * KW);
+      const uint32_t mask = conv_tap_mask(iy0, ix0, p.cH, p.cW, KH, KW, rep, fullrow);
       const bool live = m < p.M;
       va[jj] = live ? (uint32_t)(zoff + ((long long)iy0 * p.cW + ix0) * p.cCin * 2) : 0x80000000u;
       mk[jj] = live ? mask : 0xffffffffu;
@@ -97,14 +110,15 @@ __global__ __launch_bounds__(256) void gemm256c_kernel(GemmP p) {
   offsets(z, m0, n0, va, vw, mk);
   bf16x8_t fr[32];  // wa 0..7 | wb 8..15 | aa 16..23 | ab 24..31
   uint32_t s_koff, s_it, s_tmp;
-  uint32_t s_koffa, s_sh, s_cc, s_rc;   // gather state of the K-tile to fetch next; carried from statement to statement
+  uint32_t s_koffa, s_sh, s_c0, s_c1, s_msk;   // gather state of the K-tile to fetch next (with s_koff); carried from statement to statement
   const uint32_t c8 = 0x80000000u;
-  const int zero = 0;
+#define X2I_CONV_KORDER_OPS [n0s] "s"(n0s), [n1s] "s"(n1s), [dA0] "s"(dA0), [dS0] "s"(dS0), [dA1] "s"(dA1), \
+    [dS1] "s"(dS1), [dA2] "s"(dA2), [dW2] "s"(dW2), [dS2] "s"(dS2)
   asm volatile(X2I_GEMM256C_PRO
-               : X2I_GEMM256P_OPS_FRAG0_OUT(fr), X2I_GEMM256C_OPS_TMP(tv), [koff] "=&s"(s_koff), [koffa] "=&s"(s_koffa), [sh] "=&s"(s_sh), [cc] "=&s"(s_cc),
-                 [rc] "=&s"(s_rc), [tmp] "=&s"(s_tmp)
+               : X2I_GEMM256P_OPS_FRAG0_OUT(fr), X2I_GEMM256C_OPS_TMP(tv), [koff] "=&s"(s_koff), [koffa] "=&s"(s_koffa), [sh] "=&s"(s_sh), [kc0] "=&s"(s_c0),
+                 [kc1] "=&s"(s_c1), [tmp] "=&s"(s_tmp), [msk] "=&s"(s_msk)
                : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256C_OPS_MASK(mk, mk), [la] "v"(la), [lw] "v"(lw), [dma] "s"(dma), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc),
-                 [k0b] "s"(zero), [cmsb] "s"(c8), [ccs] "s"(ccs), [rcs] "s"(rcs), [rowjump] "s"(rowjump)
+                 [cmsb] "s"(c8), X2I_CONV_KORDER_OPS
                : "memory", "scc", "m0");
   for (int ui = 0;; ++ui) {
     const int nvb = w + (ui + 1) * G;
@@ -121,11 +135,10 @@ __global__ __launch_bounds__(256) void gemm256c_kernel(GemmP p) {
     const int zs = 1;   // every unit is a whole tile: the first K-tile takes C = 0
     asm volatile(X2I_GEMM256C_MAIN
                  : X2I_GEMM256P_OPS_ACC_OUT(acc), X2I_GEMM256P_OPS_FRAG0_IO(fr), X2I_GEMM256P_OPS_FRAG1(fr), X2I_GEMM256C_OPS_TMP(tv), [la] "+v"(la), [lw] "+v"(lw),
-                   [dma] "+s"(dma), [koff] "=&s"(s_koff), [it] "=&s"(s_it), [koffa] "+s"(s_koffa), [sh] "+s"(s_sh), [cc] "+s"(s_cc), [rc] "+s"(s_rc),
-                   [tmp] "=&s"(s_tmp)
+                   [dma] "+s"(dma), [koff] "+s"(s_koff), [it] "=&s"(s_it), [koffa] "+s"(s_koffa), [sh] "+s"(s_sh), [kc0] "+s"(s_c0), [kc1] "+s"(s_c1),
+                   [tmp] "=&s"(s_tmp), [msk] "=&s"(s_msk)
                  : X2I_GEMM256W_OPS_VOFF(va, vw), X2I_GEMM256P_OPS_NEXT(na, nw), X2I_GEMM256C_OPS_MASK(mk, nmk), [ra] "s"(a_rsrc), [rw] "s"(w_rsrc),
-                   [nra] "s"(a_rsrc), [nrw] "s"(w_rsrc), [nk] "s"(nk), [k0b] "s"(zero), [nk0b] "s"(zero), [zs] "s"(zs), [cmsb] "s"(c8), [ccs] "s"(ccs),
-                   [rcs] "s"(rcs), [rowjump] "s"(rowjump)
+                   [nk] "s"(nk), [zs] "s"(zs), [cmsb] "s"(c8), X2I_CONV_KORDER_OPS
                  : "memory", "scc", "m0");
     // ---- epilogue of (z, m0, n0): per-wave private staging, no workgroup barrier; the next unit's first two K-tiles are in flight
     const Deq<false> dq;

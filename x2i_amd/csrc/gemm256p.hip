@@ -410,7 +410,7 @@ __device__ __forceinline__ GemmP prob(const GemmP2& a, int sel) {
 #define X2I_F(f) q.f = sel ? y.f : x.f;
   X2I_F(A) X2I_F(a_bs) X2I_F(lda) X2I_F(W) X2I_F(ldw) X2I_F(w_bs) X2I_F(bias) X2I_F(C) X2I_F(c_bs) X2I_F(ldc) X2I_F(C2) X2I_F(act2)
   X2I_F(gate) X2I_F(gate_bs) X2I_F(res) X2I_F(r_bs) X2I_F(ldr) X2I_F(bias2) X2I_F(bias2_bs) X2I_F(M) X2I_F(N) X2I_F(K) X2I_F(act)
-  X2I_F(out_f32) X2I_F(tilesM) X2I_F(tilesN) X2I_F(cH) X2I_F(cW) X2I_F(cCin) X2I_F(cOW) X2I_F(cKW) X2I_F(cStride) X2I_F(cPad) X2I_F(cUp) X2I_F(cPadW) X2I_F(cRowPitch) X2I_F(cMom) X2I_F(cMomBlocks)
+  X2I_F(out_f32) X2I_F(tilesM) X2I_F(tilesN) X2I_F(cH) X2I_F(cW) X2I_F(cCin) X2I_F(cOW) X2I_F(cKW) X2I_F(cStride) X2I_F(cPad) X2I_F(cUp) X2I_F(cPadW) X2I_F(cRowPitch) X2I_F(cKorder) X2I_F(cMom) X2I_F(cMomBlocks)
   X2I_F(q_on) X2I_F(q_H) X2I_F(q_Spad) X2I_F(q_tok_off) X2I_F(q_rpb) X2I_F(q_row0) X2I_F(q_vperm) X2I_F(gm) X2I_F(q_eps) X2I_F(q_qs) X2I_F(q_nq) X2I_F(q_nk)
   X2I_F(q_cos) X2I_F(q_sin) X2I_F(q_Q) X2I_F(q_K) X2I_F(q_VT) X2I_F(f_sa) X2I_F(f_sa_bs) X2I_F(f_sw) X2I_F(f_alpha) X2I_F(f_oinv) X2I_F(f_out8)
   X2I_F(nbatch) X2I_F(sk_on) X2I_F(sk_slabs) X2I_F(sk_flags) X2I_F(fx_v0)

@@ -177,6 +177,27 @@ __device__ __forceinline__ int fast_div(int m, int d, float rd) {
   q -= (r < 0) ? 1 : 0;
   return q;
 }
+// Invalid-tap mask of one output pixel (bit ky * KW + kx = that tap lies outside the H x W image) in closed form: the out-of-image taps of a row / a
+// column are a prefix and a suffix of it.  rep = sum over ky of 1 << (ky * KW) replicates the column bits into every filter row; filter rows that are
+// outside themselves (top / bottom image rows only: a rarely taken loop) become all-ones.
+__device__ __forceinline__ uint32_t conv_tap_mask(int iy0, int ix0, int H, int W, int KH, int KW, uint32_t rep, uint32_t fullrow) {
+  auto edge = [](int i0, int n, int k) -> uint32_t {   // bits t < k with (unsigned)(i0 + t) >= n
+    const uint32_t all = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
+    const int lo = min(max(-i0, 0), k);            // taps below 0
+    const int hi = min(max(n - i0, 0), k);         // first tap at or behind n
+    const uint32_t below = lo >= 32 ? 0xffffffffu : ((1u << lo) - 1u);
+    const uint32_t upto = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u);
+    return (below | ~upto) & all;
+  };
+  uint32_t mask = edge(ix0, W, KW) * rep;
+  uint32_t rowbad = edge(iy0, H, KH);
+  while (rowbad) {
+    const int ky = __builtin_ctz(rowbad);
+    rowbad &= rowbad - 1;
+    mask |= fullrow << (ky * KW);
+  }
+  return mask;
+}
 template <int ACT, bool HASC2, bool RES, bool F8 = false, bool FXADD = false, bool CONV = false>
 __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&acc)[2][4][2][4], int z, int m_wave, int n_wave, int lane,
                                                       char* stage, const Deq<F8>& dq, int fx_slab0 = 0, int npre = 0, int tid = 0) {

@@ -26,6 +26,7 @@ struct GemmP {
   int cH, cW, cCin, cOW, cKW, cStride, cPad, cUp;  // cUp: nearest-neighbour x2 upsampling fused into the gather, bit 0 = along H, bit 1 = along W
   int cPadW;                                       // padding along W (cPad: along H)
   int cRowPitch;                                   // conv: elements between two output ROWS of C (0 = cOW * ldc, dense): x2i_conv_desc.out_row_pitch
+  int cKorder;                                     // conv, persistent four-wave kernels: 1 = K order (ky, channel slice, kx), 0 = (ky, kx, channel slice) (option conv_korder)
   float* cMom; int cMomBlocks;                     // conv: per-row-block channel-quad moments of the bf16 outputs, f32 [batch][cMomBlocks][N / 4][2] (nullptr: off)
   // fused q/k-norm + RoPE + head split + V transpose epilogue (x2i_gemm_qkv_bf16); q_on = 0: plain epilogue
   int q_on, q_H, q_Spad, q_tok_off, q_rpb, q_row0, q_vperm;   // q_vperm: V^T span-permuted (x2i_vt_pos)
@@ -563,6 +564,8 @@ kern_t pick_gemm256l(int act, bool res, bool f32, bool c2, bool conv);
 kern_t pick_gemm256w(int act, bool res, bool f32, bool c2);  // 4 waves, hand-scheduled K-loop (gemm256w.hip)
 kern_t pick_gemm256p(int act, bool res, bool f32, bool c2);  // the same K-loop, persistent over output tiles (gemm256p.hip)
 kern_t pick_gemm256c(int act, bool res);                     // implicit-GEMM convolutions on the same core (gemm256c.hip)
+kern_t pick_gemm512c(int act, bool res);                     // ... with <= 128 output channels: 512 x 128 tiles (gemm512c.hip)
+constexpr int SMEM5C_BYTES = 2 * 65536 + 2 * 16384;          // A buffers + W buffers = all 160 KiB
 kern_t pick_gemm256p_qkv();                                 // ... with the fused QKV epilogue (x2i_gemm_qkv_bf16)
 kern2_t pick_gemm256p_pair(int act, bool res, bool qkv, bool c2 = false);
 kern_t pick_gemm256p_fx();        // gated-residual epilogue, parallel split with fix-up (launches that cannot fill the chip with whole tiles)

@@ -98,26 +98,100 @@ def conv_slots():
         s[k] = [e for e in s[k] if e[0] != "CNT"]
     for jj, k in {0: 52, 1: 55, 2: 79, 3: 82, 4: 85, 5: 88, 6: 91, 7: 113}.items():
         s.setdefault(k, []).append(("VA", jj))
-    for n in range(10):
-        s.setdefault(117 + n // 2, []).append(("ADV", n))
-    s.setdefault(123, []).append(("CNT", 0))
-    s.setdefault(124, []).append(("CNT", 1))
+    for n in range(ADV_STEPS):
+        s.setdefault(116 + n, []).append(("ADV", n))
+    s.setdefault(124, []).append(("CNT", 0))
+    s.setdefault(126, []).append(("CNT", 1))
+    s[125] = [e for e in s[125] if e[0] != "LGK"]
+    s.setdefault(127, []).append(("LGK", "all"))
     return {k: v for k, v in s.items() if v}
 
 
-ADV_LINES = ["s_add_u32 %[koffa], %[koffa], 128",
-             "s_sub_u32 %[cc], %[cc], 1",
-             "s_cmp_eq_u32 %[cc], 0",
-             "s_cselect_b32 %[cc], %[ccs], %[cc]",
-             "s_cselect_b32 %[tmp], 1, 0",
-             "s_sub_u32 %[sh], %[sh], %[tmp]",
-             "s_sub_u32 %[rc], %[rc], 1",
-             "s_cmp_eq_u32 %[rc], 0",
-             "s_cselect_b32 %[rc], %[rcs], %[rc]",
-             "s_cselect_b32 %[tmp], %[rowjump], 0",
-             "s_add_u32 %[koffa], %[koffa], %[tmp]"]
-# (eleven instructions in ten steps: the last step carries two)
-CONV_STATE_INIT = ["s_mov_b32 %[koffa], 0", "s_mov_b32 %[sh], 31", "s_mov_b32 %[cc], %[ccs]", "s_mov_b32 %[rc], %[rcs]"]
+# Tile geometries of the persistent statements.  "256": the product tile (256 x 256: waves 2 x 2, 8 A + 8 W pieces per wave and K-tile, LDS buffers
+# 64 KiB apart, W image 32 KiB behind the A image).  "512": 512 x 128 for the convolutions with <= 128 output channels (gemm512c.hip) -- the SAME
+# 128 x 128 wave tile and MFMA / fragment stream, four waves stacked along M: 16 A pieces + 4 W pieces per wave, A buffers at 0 / 64 KiB, W buffers
+# at 128 / 144 KiB (their own DMA base `dmaw`, flip 16 KiB): all 160 KiB of LDS, no epilogue staging (that epilogue leaves straight from registers).
+GEOMS = {"256": dict(npa=8, npw=8, a_flip=0x10000, w_flip=0x10000, dmaw=False, w_buf1=65536 + 32768, w_buf0=32768),
+         "512": dict(npa=16, npw=4, a_flip=0x10000, w_flip=0x4000, dmaw=True, w_buf1=16384, w_buf0=0)}
+
+
+def conv512_slots():
+    """Schedule of the 512 x 128 convolution form: the fragment reads, waits and barriers where the product schedule has them; 4 W pieces behind
+    the first barrier, 16 A pieces (offset made in the gap in front of each: ("VA", jj) shares a gap with ("M0A", jj)) behind the second."""
+    s = {}
+
+    def put(k, *ev):
+        s.setdefault(k, []).extend(ev)
+    for j in range(8):
+        put(2 * j, ("R1W", j))
+    put(1, ("TL", 0)); put(3, ("TL", 1)); put(5, ("TL", 2))
+    put(15, ("XW",))
+    put(18, ("LGK", "W1")); put(19, ("BAR",))
+    for jj in range(4):
+        put(20 + 3 * jj, ("M0W", jj)); put(21 + 3 * jj, ("DW", jj))
+    for i, k in enumerate((22, 25, 28, 31, 33, 35, 37, 39)):
+        put(k, ("R1A", i))
+    put(41, ("XA",))
+    put(45, ("LGK", "A1")); put(46, ("BAR",))
+    k = 47
+    for jj in range(7):          # A pieces 0..6
+        put(k, ("VA", jj), ("M0A", jj)); put(k + 1, ("DA", jj))
+        k += 2
+    put(62, ("VM", "W")); put(63, ("BAR",))
+    for j in range(8):
+        put(64 + 2 * j, ("R0W", j))
+    for n, jj in enumerate(range(7, 11)):     # A pieces 7..10 in the odd gaps between the W fragment reads
+        put(65 + 4 * n, ("VA", jj), ("M0A", jj)); put(67 + 4 * n, ("DA", jj))
+    k = 80
+    for jj in range(11, 16):      # A pieces 11..15
+        put(k, ("VA", jj), ("M0A", jj)); put(k + 1, ("DA", jj))
+        k += 2
+    put(90, ("XD",))
+    for n, k in enumerate((91, 92, 93, 94, 95, 99, 101, 103)):
+        put(k, ("ADV", n))
+    put(96, ("VM", "A")); put(97, ("BAR",))
+    for i in range(8):
+        put(98 + 2 * i, ("R0A", i))
+    put(121, ("CNT", 0)); put(122, ("CNT", 1))
+    put(125, ("LGK", "all"))
+    return s
+
+
+# The gather state of the K-tile to fetch -- (koffa: byte offset of its tap + channel slice in the image, koff: byte offset of its 64 weights in a W row,
+# sh: 31 - tap index) -- advances through TWO nested counters with per-level increments, so that the K order is the launch's choice:
+#   order "kx inner" (the product order since round 6):  K-tile (ky, c, kx): the three taps of a filter row follow each other for one channel
+#       slice -- they read the SAME image lines shifted by a pixel, one K-tile apart: the re-read hits the XCD's L2 instead of the fabric (with
+#       [ky][kx][c] the same lines come back Cin / 64 K-tiles later, after 32 workgroups' worth of other lines: a miss; for <= 128 output
+#       channels that traffic -- 9 x the image at 128 FLOP per byte -- is what bounded the convolution at ~1.0 PFLOP/s);
+#   order "c inner": K-tile (ky, kx, c) = the weight layout's own order, every offset advances by 128 bytes (the order of the other kernels:
+#       bit-identical to them, option conv_korder = 0).
+# state: c0 / c1 = steps left in the inner / middle counter; constants n0s / n1s, dA0 dS0 (every step), dA1 dS1 (added when the inner
+# counter wraps), dA2 dW2 dS2 (added when the middle counter wraps as well).
+ADV_LINES = ["s_add_u32 %[koffa], %[koffa], %[dA0]",
+             "s_add_u32 %[koff], %[koff], %[dA0]",
+             "s_add_u32 %[sh], %[sh], %[dS0]",
+             "s_sub_u32 %[kc0], %[kc0], 1",
+             "s_cmp_eq_u32 %[kc0], 0",
+             "s_cselect_b32 %[kc0], %[n0s], %[kc0]",
+             "s_cselect_b32 %[msk], -1, 0",
+             "s_and_b32 %[tmp], %[msk], %[dA1]",
+             "s_add_u32 %[koffa], %[koffa], %[tmp]",
+             "s_add_u32 %[koff], %[koff], %[tmp]",
+             "s_and_b32 %[tmp], %[msk], %[dS1]",
+             "s_add_u32 %[sh], %[sh], %[tmp]",
+             "s_and_b32 %[tmp], %[msk], 1",
+             "s_sub_u32 %[kc1], %[kc1], %[tmp]",
+             "s_cmp_eq_u32 %[kc1], 0",
+             "s_cselect_b32 %[kc1], %[n1s], %[kc1]",
+             "s_cselect_b32 %[msk], -1, 0",
+             "s_and_b32 %[tmp], %[msk], %[dA2]",
+             "s_add_u32 %[koffa], %[koffa], %[tmp]",
+             "s_and_b32 %[tmp], %[msk], %[dW2]",
+             "s_add_u32 %[koff], %[koff], %[tmp]",
+             "s_and_b32 %[tmp], %[msk], %[dS2]",
+             "s_add_u32 %[sh], %[sh], %[tmp]"]
+ADV_STEPS = 8     # three instructions per step (the last one two); the W-row offset shares the image offset's first two increments (dW0 = dA0, dW1 = dA1 in both orders)
+CONV_STATE_INIT = ["s_mov_b32 %[koffa], 0", "s_mov_b32 %[koff], 0", "s_mov_b32 %[sh], 31", "s_mov_b32 %[kc0], %[n0s]", "s_mov_b32 %[kc1], %[n1s]"]
 
 
 def emit_event(ev, st):
@@ -133,10 +207,11 @@ def emit_event(ev, st):
         st["ds"].append(kind + str(n))
         off = n * 2048 + half
         return [f"ds_read_b128 {reg}, {addr}" + (f" offset:{off}" if off else "")]
+    geom = st.get("geom", GEOMS["256"])
     if kind == "XW":
-        return ["v_xor_b32 %[lw], 0x10000, %[lw]"]
+        return [f"v_xor_b32 %[lw], {hex(geom['w_flip'])}, %[lw]"]
     if kind == "XA":
-        return ["v_xor_b32 %[la], 0x10000, %[la]"]
+        return [f"v_xor_b32 %[la], {hex(geom['a_flip'])}, %[la]"]
     mode = st.get("mode", "W")
     conv = st.get("conv", False)
     if kind == "VA":
@@ -144,31 +219,36 @@ def emit_event(ev, st):
         m, v = ("nmk", "na") if mode in ("B1", "B2") else ("mk", "va")
         return [f"v_lshlrev_b32 %[tv{k}], %[sh], %[{m}{ev[1]}]", f"v_and_or_b32 %[tv{k}], %[tv{k}], %[cmsb], %[{v}{ev[1]}]"]
     if kind == "ADV":
-        return ADV_LINES[ev[1]:ev[1] + 1] if ev[1] < 9 else ADV_LINES[9:]
+        return ADV_LINES[3 * ev[1]:3 * ev[1] + 3]
     if kind == "TL" and conv and mode == "B1" and ev[1] == 0:
-        return ["s_mov_b32 %[koff], %[nk0b]"] + CONV_STATE_INIT   # the next unit starts at tap 0, channel slice 0
+        return list(CONV_STATE_INIT)   # the next unit starts at tap 0, channel slice 0
     if kind == "TL":
         if mode == "W":  # one-tile kernel: fetch tile min(t + 2, nk - 1)
             return [["s_add_u32 %[tl], %[tl], 1", "s_min_u32 %[tmp], %[tl], %[nkm1]", "s_lshl_b32 %[koff], %[tmp], 7"][ev[1]]]
         if mode in ("B1", "B2"):  # last two K-tiles of a unit: fetch the first two K-tiles of the NEXT unit (byte offset nk0b of its row)
+            if conv:
+                return []         # (the convolution forms carry koff in the gather state: reset in B1, advanced by ADV)
             return (["s_mov_b32 %[koff], %[nk0b]"] if mode == "B1" else ["s_add_u32 %[koff], %[nk0b], 128"]) if ev[1] == 0 else []
         return []  # mode "A": koff advances behind the last piece (XD)
     if kind == "M0W":
+        if geom["dmaw"]:
+            return [f"s_add_u32 m0, %[dmaw], {ev[1] * 4096}" if ev[1] else "s_mov_b32 m0, %[dmaw]"]
         return [f"s_add_u32 m0, %[dma], {32768 + ev[1] * 4096}"]
     if kind == "M0A":
         return [f"s_add_u32 m0, %[dma], {ev[1] * 4096}" if ev[1] else "s_mov_b32 m0, %[dma]"]
     if kind == "DW":
         st["vm"].append(("W", st["iter"], ev[1]))
-        v, r = ("nw", "nrw") if mode in ("B1", "B2") else ("vw", "rw")     # (the next unit may belong to another problem of a grouped launch)
+        v, r = ("nw", "rw" if conv else "nrw") if mode in ("B1", "B2") else ("vw", "rw")     # (the next unit may belong to another problem of a grouped launch; a convolution launch has one problem)
         return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[{r}], %[koff] offen" + st["aux_w"] + " lds"]
     if kind == "DA":
         st["vm"].append(("A", st["iter"], ev[1]))
-        v, r = ("na", "nra") if mode in ("B1", "B2") else ("va", "ra")
+        v, r = ("na", "ra" if conv else "nra") if mode in ("B1", "B2") else ("va", "ra")
         if conv:
             return [f"buffer_load_dwordx4 %[tv{ev[1] & 3}], %[{r}], %[koffa] offen" + st["aux_a"] + " lds"]
         return [f"buffer_load_dwordx4 %[{v}{ev[1]}], %[{r}], %[koff] offen" + st["aux_a"] + " lds"]
     if kind == "XD":
-        return ["s_xor_b32 %[dma], %[dma], 0x10000"] + (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" else [])
+        return ([f"s_xor_b32 %[dma], %[dma], {hex(geom['a_flip'])}"] + ([f"s_xor_b32 %[dmaw], %[dmaw], {hex(geom['w_flip'])}"] if geom["dmaw"] else []) +
+                (["s_add_u32 %[koff], %[koff], 128"] if mode == "A" and not conv else []))
     if kind == "BAR":
         return ["s_barrier"]
     if kind == "CNT":
@@ -205,14 +285,21 @@ def body(slots, st, zero=False):
     return lines
 
 
-def check(slots):
+def check(slots, geom=None):
     """Static hazards of the schedule (register reuse, buffer reuse, wait coverage)."""
+    geom = geom or GEOMS["256"]
+    npa, npw = geom["npa"], geom["npw"]
     pos = {}
     order = []
     for k in sorted(slots):
         for n, ev in enumerate(slots[k]):
             pos[ev] = (k, n)
             order.append(ev)
+    assert sorted(e[1] for e in pos if e[0] == "DW") == list(range(npw)) and sorted(e[1] for e in pos if e[0] == "DA") == list(range(npa))
+    for j in range(npw):
+        assert pos[("M0W", j)] < pos[("DW", j)] < pos[("XD",)]
+    for j in range(npa):
+        assert pos[("M0A", j)] < pos[("DA", j)] < pos[("XD",)]
     for j in range(8):
         # wa[j] is read by MFMAs 8i + j (i = 0..7, k-half 0): last use 56 + j;  aa[i] by 8i .. 8i+7
         assert pos[("R0W", j)][0] >= 56 + j, "wa[%d] overwritten before its last use" % j
@@ -222,16 +309,14 @@ def check(slots):
         assert pos[("R1A", j)] < pos[("LGK", "A1")] and pos[("LGK", "A1")][0] < 64
         assert pos[("R1W", j)] < pos[("XW",)] < pos[("R0W", j)]
         assert pos[("R1A", j)] < pos[("XA",)] < pos[("R0A", j)]
-        assert pos[("M0W", j)] < pos[("DW", j)] and pos[("M0A", j)] < pos[("DA", j)]
-        assert pos[("DW", j)] < pos[("XD",)] and pos[("DA", j)] < pos[("XD",)]
     bars = [pos[e] for e in order if e == ("BAR",)]
     # barrier after the W (A) k-half-1 reads have returned, before the first W (A) piece overwrites the current buffer
     barpos = sorted(p for e, p in pos.items() if e[0] == "BAR")
     # (BAR events are identical tuples: recover their positions from the slot table)
     barpos = sorted((k, n) for k in slots for n, ev in enumerate(slots[k]) if ev == ("BAR",))
     assert len(barpos) in (3, 4)
-    assert pos[("LGK", "W1")] < barpos[0] < min(pos[("DW", j)] for j in range(8))
-    assert pos[("LGK", "A1")] < barpos[1] < min(pos[("DA", j)] for j in range(8))
+    assert pos[("LGK", "W1")] < barpos[0] < min(pos[("DW", j)] for j in range(npw))
+    assert pos[("LGK", "A1")] < barpos[1] < min(pos[("DA", j)] for j in range(npa))
     if len(barpos) == 4:
         assert pos[("VM", "W")] < barpos[2] < min(pos[("R0W", j)] for j in range(8))
         assert pos[("VM", "A")] < barpos[3] < min(pos[("R0A", j)] for j in range(8))
@@ -244,10 +329,10 @@ def check(slots):
         assert p1[0] > p0[0], "M0 write and its piece must be separated by an MFMA"
     # SCC: the compare must be the last SCC-writing scalar instruction of the body
     assert all(pos[e] < pos[("CNT", 1)] for e in pos if e[0] in ("TL", "M0W", "M0A", "XD", "ADV") or e == ("CNT", 0))
-    for j in range(8):
+    for j in range(npa):
         if ("VA", j) in pos:   # convolution form: a piece's offset is made in an earlier gap, its temporary is free again (piece j - 4 issued)
             assert pos[("VA", j)][0] < pos[("DA", j)][0] and (j < 4 or pos[("DA", j - 4)][0] < pos[("VA", j)][0])
-            assert all(pos[("ADV", n)][0] > pos[("DA", 7)][0] for n in range(10))
+            assert all(pos[("ADV", n)][0] > pos[("DA", npa - 1)][0] for n in range(ADV_STEPS)) and all(pos[("ADV", n)] < pos[("ADV", n + 1)] for n in range(ADV_STEPS - 1))
     assert pos[("LGK", "all")] > max(pos[("R0A", j)] for j in range(8))
     del bars
 
@@ -297,33 +382,41 @@ def generate(aux_a="", aux_w="", variant=0):
     return L, st["vm_n"]
 
 
-def generate_persistent(aux_a="", aux_w="", conv=False):
+def generate_persistent(aux_a="", aux_w="", conv=False, geom_name="256"):
     """Seamless form for the persistent kernel: PRO (first output tile of a workgroup: K-tiles 0 and 1, first fragments), MAIN (the nk
     K-tiles of one output tile; the last two iterations fetch K-tiles 0 / 1 of the NEXT output tile through the `na` / `nw` offsets and
     leave its first fragments in wa / aa, so the next MAIN starts multiplying at once), DRAIN (after the last tile)."""
-    slots = conv_slots() if conv else default_slots()
-    check(slots)
-    st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A", conv=conv)
+    geom = GEOMS[geom_name]
+    npa, npw = geom["npa"], geom["npw"]
+    slots = (conv512_slots() if geom_name == "512" else conv_slots()) if conv else default_slots()
+    check(slots, geom)
+    st = dict(ds=[], vm=[], iter=-1, aux_a=aux_a, aux_w=aux_w, vm_n={}, mode="A", conv=conv, geom=geom)
+    wbase = "%[dmaw]" if geom["dmaw"] else "%[dma]"
+
+    def w_piece(jj, buf):
+        off = (geom["w_buf1"] if buf else geom["w_buf0"]) + jj * 4096
+        return [f"s_add_u32 m0, {wbase}, {off}" if off else f"s_mov_b32 m0, {wbase}", "s_nop 0",
+                f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
 
     def a_piece(jj, buf):   # prologue A piece: plain offset, or the convolution gather's masked offset + scalar tap offset
         m0 = [f"s_add_u32 m0, %[dma], {buf * 65536 + jj * 4096}"]
         if conv:   # (the two VALU instructions are the wait state between the M0 write and the piece)
-            return m0 + emit_event(("VA", jj), dict(mode="A")) + [f"buffer_load_dwordx4 %[tv{jj & 3}], %[ra], %[koffa] offen" + aux_a + " lds"]
+            return m0 + emit_event(("VA", jj), dict(mode="A", geom=geom)) + [f"buffer_load_dwordx4 %[tv{jj & 3}], %[ra], %[koffa] offen" + aux_a + " lds"]
         return m0 + ["s_nop 0", f"buffer_load_dwordx4 %[va{jj}], %[ra], %[koff] offen" + aux_a + " lds"]
-    P = ["s_nop 4", "s_mov_b32 %[koff], %[k0b]"] + (CONV_STATE_INIT if conv else [])
-    for jj in range(8):
+    P = ["s_nop 4"] + (list(CONV_STATE_INIT) if conv else ["s_mov_b32 %[koff], %[k0b]"])
+    for jj in range(npa):
         P += a_piece(jj, 0)
-    for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
-    P += ["s_add_u32 %[koff], %[k0b], 128"] + (ADV_LINES if conv else [])
-    for jj in range(8):
-        P += [f"s_add_u32 m0, %[dma], {65536 + 32768 + jj * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[vw{jj}], %[rw], %[koff] offen" + aux_w + " lds"]
+    for jj in range(npw):
+        P += w_piece(jj, 0)
+    P += list(ADV_LINES) if conv else ["s_add_u32 %[koff], %[k0b], 128"]
+    for jj in range(npw):
+        P += w_piece(jj, 1)
         st["vm"].append(("W", -1, jj))
-    for jj in range(8):
+    for jj in range(npa):
         P += a_piece(jj, 1)
         st["vm"].append(("A", -1, jj))
-    P += ADV_LINES if conv else []
-    P += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    P += list(ADV_LINES) if conv else []
+    P += [f"s_waitcnt vmcnt({npa + npw})", "s_barrier"]
     for j in range(8):
         P.append(f"ds_read_b128 %[wa{j}], %[lw]" + (f" offset:{j * 2048}" if j else ""))
     for i in range(8):
@@ -345,7 +438,7 @@ def generate_persistent(aux_a="", aux_w="", conv=False):
     # statements on the two sides of a C++ branch made hipcc spill the whole accumulator file at the join).
     st["iter"], st["ds"], st["mode"] = 5, [], "A"
     a0 = body(slots, st, zero=True)
-    MC = ["s_nop 4", "s_add_u32 %[koff], %[k0b], 256", "s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[zs], 0", "s_cbranch_scc1 5f",
+    MC = ["s_nop 4"] + ([] if conv else ["s_add_u32 %[koff], %[k0b], 256"]) + ["s_sub_u32 %[it], %[nk], 2", "s_cmp_lg_u32 %[zs], 0", "s_cbranch_scc1 5f",
           "s_cmp_lg_u32 %[it], 0", "s_cbranch_scc0 2f", "s_branch 1f", "5:"]
     MC += a0 + ["s_cbranch_scc0 2f", "1:"] + bodies["A"] + ["s_cbranch_scc1 1b", "2:"] + bodies["B1"] + bodies["B2"] + ["s_nop 7", "s_nop 7"]
     # The last body has requested the NEXT unit's first fragments (ds_read into the FRAG0 operands).  They must have landed when the
@@ -413,8 +506,8 @@ def main():
     P, MC, MZ, D, vmc = generate_persistent(conv=True)
     txt.append("// implicit-GEMM convolution form (gemm256c.hip) -- additional operands: mk0..7 / nmk0..7 \"v\" = invalid-tap masks of this / the next unit's")
     txt.append("// piece rows (bit t = filter tap t lies outside the image), tv0..3 \"=&v\" scratch, c8 \"s\" = 0x80000000, koffa / sh / cc / rc \"+s\" = the gather")
-    txt.append("// state of the K-tile to fetch (byte offset of its tap + channel slice, 31 - tap, channel slices / K-tiles left in the tap / filter row),")
-    txt.append("// ccs / rcs / rowjump \"s\" = Cin / 64, KW * Cin / 64, (W - KW) * Cin * 2; tmp \"=&s\" scratch.  A unit is a whole tile (k0b = nk0b = 0).")
+    txt.append("// state of the K-tile to fetch; koff (the W row offset) is part of that state here: \"+s\"; c0 / c1 \"+s\" = steps left in the inner / middle counter;")
+    txt.append("// n0s / n1s / dA0..2 / dW0..2 / dS0..2 \"s\" = the launch's K order (see ADV_LINES in the generator); msk / tmp \"=&s\" scratch.  A unit is a whole tile.")
     for name, L in (("X2I_GEMM256C_PRO", P), ("X2I_GEMM256C_MAIN", MC)):
         txt.append(f"// {name}: {len(L)} lines" + (f"; vmcnt W / A: {vmc['W']} / {vmc['A']}" if "MAIN" in name else ""))
         txt.append(f"#define {name} \\")
@@ -425,6 +518,24 @@ def main():
     txt.append(f"#define X2I_GEMM256C_OPS_MASK(mk, nmk) {mk}")
     tv = ", ".join(f'[tv{n}] "=&v"(tv[{n}])' for n in range(4))
     txt.append(f"#define X2I_GEMM256C_OPS_TMP(tv) {tv}")
+    # 512 x 128 convolution form (gemm512c.hip): the same statements on the "512" geometry
+    P, MC, MZ, D, vm5 = generate_persistent(conv=True, geom_name="512")
+    txt.append("// 512 x 128 implicit-GEMM convolution form (gemm512c.hip: <= 128 output channels; four waves stacked along M, the SAME 128 x 128 wave tile and")
+    txt.append("// MFMA / fragment stream) -- operands as the 256 x 256 convolution form with 16 A pieces (va / na / mk / nmk 0..15) and 4 W pieces (vw / nw 0..3)")
+    txt.append("// per wave, and dmaw \"+s\" = LDS byte address of this wave's first W piece in buffer 0 (W buffers at 128 / 144 KiB).")
+    for name, L in (("X2I_GEMM512C_PRO", P), ("X2I_GEMM512C_MAIN", MC)):
+        txt.append(f"// {name}: {len(L)} lines" + (f"; vmcnt W / A: {vm5['W']} / {vm5['A']}" if "MAIN" in name else ""))
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{l}\\n" \\' for l in L[:-1]]
+        txt.append(f'  "{L[-1]}\\n"')
+        txt.append("")
+    g5 = GEOMS["512"]
+    vo5 = ", ".join(f'[va{n}] "v"(va[{n}])' for n in range(g5["npa"])) + ", " + ", ".join(f'[vw{n}] "v"(vw[{n}])' for n in range(g5["npw"]))
+    txt.append(f"#define X2I_GEMM512C_OPS_VOFF(va, vw) {vo5}")
+    nx5 = ", ".join(f'[na{n}] "v"(na[{n}])' for n in range(g5["npa"])) + ", " + ", ".join(f'[nw{n}] "v"(nw[{n}])' for n in range(g5["npw"]))
+    txt.append(f"#define X2I_GEMM512C_OPS_NEXT(na, nw) {nx5}")
+    mk5 = ", ".join(f'[mk{n}] "v"(mk[{n}])' for n in range(g5["npa"])) + ", " + ", ".join(f'[nmk{n}] "v"(nmk[{n}])' for n in range(g5["npa"]))
+    txt.append(f"#define X2I_GEMM512C_OPS_MASK(mk, nmk) {mk5}")
     # operand lists (the asm statement itself is written out in gemm256w.hip)
     accs = ", ".join(f'[c{i * NF + j}] "+a"(acc[{j >> 2}][{i}][{j & 3}])' for i in range(NF) for j in range(NF))
     txt.append("// acc[h][i][jj]: rows 16i.., columns 64h + 16jj.. of the 128 x 128 wave tile (two halves in the layout the shared epilogues take)")

@@ -47,6 +47,8 @@ struct X2IOptions {
   int conv256;            // 1 = >= 256-channel convolutions use the 256^2 kernel (default)                X2I_CONV256
   int conv_w4;            // 1 = those convolutions take the persistent four-wave kernel with the hand-scheduled K-loop (gemm256c.hip, default); 0 = the
                           // eight-wave one-tile form (gemm256.hip); bit-identical results                   X2I_CONV_W4
+  int conv_korder;        // persistent conv kernels: 1 = K runs (filter row, channel slice, kx): a filter row's taps back to back, their shifted re-reads hit
+                          // L2 (default); 0 = (filter row, kx, channel slice), the other kernels' order: bit-identical to them              X2I_CONV_KORDER
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
   int attn_w16;           // 1 = x2i_attention_prefers_vt_perm may say yes (sampling path on attention_w16.hip; default); 0 = never; 2 = at any size   X2I_ATTN_W16
   int conv5_variant;      // matrix-core projector conv: 0 = automatic form choice; 1 = plain stages, 2 = pipelined, 3 = two row blocks   X2I_CONV5_VARIANT
