@@ -243,14 +243,17 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
       }
     }
   });
-  // residual: descriptor of this batch item, per-lane offsets of the (i = 0 / 1, j = 0) block of the chunk at (c = 0, h = 0); a
-  // chunk's eight 8-byte loads differ by the 16-row step (i), a 32-byte immediate (j) and the scalar chunk offset
+  // residual: descriptor of this batch item, per-lane offsets of the (i = 0 / 1) row blocks of the chunk at (c = 0, h = 0).  Round 6: the residual
+  // comes as FOUR 16-byte loads per chunk instead of eight 8-byte ones -- a lane fetches eight consecutive columns (of column block 2 jp + (ng & 1),
+  // half (ng >> 1): a row's four lanes cover 64 contiguous bytes) and v_permlane16_swap turns two such registers into the accumulator layout of the
+  // blocks 2 jp and 2 jp + 1 (the exchange of gemm512c.hip's direct epilogue, run backwards; it is its own inverse).  Half the memory instructions
+  // of what was the most expensive epilogue of the step (14.5 us per tile against 5.5 us for the plain one, tools/gemm_unit_timeline.py)
   __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
   uint32_t roff[2] = {0, 0};
   if constexpr (RES) {
     r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)z * p.r_bs), 0, (uint32_t)(((long long)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) roff[i] = (uint32_t)(((long long)(m_wave + i * 16 + mlane) * p.ldr + n_wave + ng * 4) * 2);
+    for (int i = 0; i < 2; ++i) roff[i] = (uint32_t)(((long long)(m_wave + i * 16 + mlane) * p.ldr + n_wave + 16 * (ng & 1) + 8 * (ng >> 1)) * 2);
   }
   // fix-up partials: window of two chunks, rp[q & 1][i][j] = sum over the predecessors' slabs of accumulator tile (2c + i, 4h + j)
   f32x4_t rp[FXADD ? 2 : 1][2][4];
@@ -279,7 +282,11 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rres[q % 3][i][j] = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, roff[i] + j * 32, soff, 0);
+        for (int jp = 0; jp < 2; ++jp) {
+          const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, roff[i] + jp * 64, soff, 0);
+          rres[q % 3][i][2 * jp] = (u32x2){l[0], l[1]};          // (exchanged into the accumulator layout where the pair is first used: stage_a)
+          rres[q % 3][i][2 * jp + 1] = (u32x2){l[2], l[3]};
+        }
     }
   };
   // output descriptors of this batch item: rows at or behind M are out of range (dropped by the hardware)
@@ -307,6 +314,15 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
     constexpr int j = decltype(jc)::value;
     constexpr int h = q >> 2, c = q & 3;
     char* buf = stage + which * 4096;
+    if constexpr (RES && (j & 1) == 0) {   // the residual of column blocks j, j + 1: loaded layout -> accumulator layout (both 16-row blocks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const auto a = __builtin_amdgcn_permlane16_swap(rres[q % 3][i][j][0], rres[q % 3][i][j + 1][0], false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(rres[q % 3][i][j][1], rres[q % 3][i][j + 1][1], false, false);
+        rres[q % 3][i][j] = (u32x2){a[0], b[0]};
+        rres[q % 3][i][j + 1] = (u32x2){a[1], b[1]};
+      }
+    }
     float x[8];   // (the quarter's eight accumulators first, then eight independent chains; GELU breadth first: see the e4m3 form)
     static_for<2>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
