@@ -46,7 +46,11 @@ X2I_VAE_EPI_MOMENTS=0 X2I_VAE_UP_PHASES=0 python tools/vae_bench.py > "$OUT/${TA
 python tools/conv_probe.py > "$OUT/${TAG}_conv_probe.log" 2>&1
 timeout 600 python tools/train_bench.py 1 2 > "$OUT/${TAG}_train_bench.log" 2>&1
 python tools/fx_bench.py > "$OUT/${TAG}_fx_bench.log" 2>&1
-python tools/gemm_r2_probe.py --quick > "$OUT/${TAG}_gemm_r2_probe.log" 2>&1
+X2I_LIB_VARIANT=ablate python tools/gemm_r2_probe.py --quick > "$OUT/${TAG}_gemm_r2_probe.log" 2>&1   # (measurement library since round 6)
+python tools/vendor_probe.py 4 > "$OUT/${TAG}_vendor_probe.log" 2>&1
+python tools/gemm_fabric_price.py > "$OUT/${TAG}_gemm_fabric_price.log" 2>&1
+X2I_CONV_W4=0 python tools/conv_probe.py > "$OUT/${TAG}_conv_probe_conv_w4_0.log" 2>&1
+X2I_CONV_W4=0 python tools/vae_bench.py > "$OUT/${TAG}_vae_bench_conv_w4_0.log" 2>&1
 bash tools/attn_clock_pmc.sh "$OUT/attn_clock" > /dev/null 2>&1; cp "$OUT/attn_clock/attn_clock.json" "$OUT/${TAG}_attn_clock_alone_vs_in_sequence.json" 2>/dev/null; rm -rf "$OUT/attn_clock/alone" "$OUT/attn_clock/seq"
 [ -x tools/ubench/bin/mfma_power ] && bash tools/clock_watch.sh "$OUT/${TAG}_mfma_power_clock.log" -- tools/ubench/bin/mfma_power 1 8 > "$OUT/${TAG}_mfma_power.log" 2>&1
 cd /tmp
