@@ -91,7 +91,15 @@ def test_conv256_kernel_vs_fp32_conv(opt, Cin, Cout, k, s, p, H, W, up):
     res = bf(seeded((B, OH, OW, Cout), 5))
     out_res = run(res=res.to(DEV))
     assert rel_l2(out_res.permute(0, 3, 1, 2), ref + res.float().permute(0, 3, 1, 2)) < 1e-2
-    # the 128^2 implicit-GEMM kernel accumulates in the same order: bit-identical results
+    # the 128^2 implicit-GEMM kernel accumulates in the weight layout's K order; so does the 256^2 kernel with conv_korder = 0: bit-identical results
+    # (its product order -- a filter row's taps back to back -- is the same sum in another order: within 2e-3)
+    if not up:
+        opt("conv_korder", 0)
+        out_k0, out_b2_k0, out_res_k0 = run(), run(act=ops.ACT_RELU, bias2=b2.to(DEV)), run(res=res.to(DEV))
+        assert _lib.get_option("last_gemm_tile") == 5256
+        for a_, b_ in ((out, out_k0), (out_b2, out_b2_k0), (out_res, out_res_k0)):
+            assert rel_l2(a_, b_) < 2e-3
+        out, out_b2, out_res = out_k0, out_b2_k0, out_res_k0
     opt("conv256", 0)
     out128 = run()
     assert _lib.get_option("last_gemm_tile") == 128

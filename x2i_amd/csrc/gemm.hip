@@ -403,7 +403,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // ... on the persistent four-wave core (gemm256c.hip: the linear kernels' hand-scheduled K-loop with the gather as a scalar tap offset + a
   // padding mask per piece row) when the gather is affine in the tap (no fused upsampling), ONE image fits the 2 GB descriptor (batches that do not are launched in chunks)
   // and the epilogue is one it instantiates; bit-identical to the eight-wave form (option conv_w4 = 0)
-  if (conv256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
+  // The choice of THESE kernels depends on the batch ITEM's shape only (not on the tile count of the whole batch, which gates the eight-wave
+  // form above): in their product K order they sum in another order than the other convolution kernels, and a sample's bits must not depend on
+  // the batch it rides in (tests/test_fullscale_parity_gpu.py: batch independence of the LightControl step)
+  const bool conv_item256 = conv && a->N >= 256 && a->N % 8 == 0 && a->M >= 1024 && opt.conv256;
+  if (conv_item256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
       (((uintptr_t)a->C) & 15) == 0 && (long long)a->M < (1LL << 24) &&
       (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
       (long long)a->M * a->ldc * 2 < 0x7f000000LL && (!cd->out_row_pitch || (long long)(a->M / p.cOW) * cd->out_row_pitch * 2 < 0x7f000000LL) &&
@@ -424,7 +428,6 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // (gemm512c.hip: the same wave tile and K-loop, epilogue straight from registers); outputs bit-identical to the 128^2 kernel's
   if (conv && opt.conv_w4 && opt.gemm_tile == 0 && fast && cd->up == 0 && !cd->out_row_pitch && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && a->N > 64 && a->N <= 128 &&
       (a->N & 7) == 0 && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 && (((uintptr_t)a->C) & 15) == 0 && a->M >= 2048 && (long long)a->M < (1LL << 24) &&
-      (long long)((a->M + 511) / 512) * a->batch >= opt.gemm_min256 &&
       (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
       (long long)a->M * a->ldc * 2 < 0x7f000000LL &&
       (!res || ((a->ldr & 3) == 0 && (a->res_batch_stride & 3) == 0 && (((uintptr_t)a->res) & 7) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL))) {
