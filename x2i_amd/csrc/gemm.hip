@@ -406,7 +406,11 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // The choice of THESE kernels depends on the batch ITEM's shape only (not on the tile count of the whole batch, which gates the eight-wave
   // form above): in their product K order they sum in another order than the other convolution kernels, and a sample's bits must not depend on
   // the batch it rides in (tests/test_fullscale_parity_gpu.py: batch independence of the LightControl step)
-  const bool conv_item256 = conv && a->N >= 256 && a->N % 8 == 0 && a->M >= 1024 && opt.conv256;
+  // ... and only for items with at least 64 tiles (a quarter of the chip per item: the VAE's and ControlNeXt's convolutions at 1024^2); smaller
+  // images keep the older kernels, whose smaller tiles fill the chip better there (tests lower the threshold through gemm_min256)
+  const long long conv_item_thr = opt.gemm_min256 < 64 ? opt.gemm_min256 : 64;
+  const bool conv_item256 = conv && a->N >= 256 && a->N % 8 == 0 && a->M >= 1024 && opt.conv256 &&
+                            (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) >= conv_item_thr;
   if (conv_item256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
       (((uintptr_t)a->C) & 15) == 0 && (long long)a->M < (1LL << 24) &&
       (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
@@ -428,6 +432,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // (gemm512c.hip: the same wave tile and K-loop, epilogue straight from registers); outputs bit-identical to the 128^2 kernel's
   if (conv && opt.conv_w4 && opt.gemm_tile == 0 && fast && cd->up == 0 && !cd->out_row_pitch && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && a->N > 64 && a->N <= 128 &&
       (a->N & 7) == 0 && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 && (((uintptr_t)a->C) & 15) == 0 && a->M >= 2048 && (long long)a->M < (1LL << 24) &&
+      (long long)((a->M + 511) / 512) >= conv_item_thr &&
       (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
       (long long)a->M * a->ldc * 2 < 0x7f000000LL &&
       (!res || ((a->ldr & 3) == 0 && (a->res_batch_stride & 3) == 0 && (((uintptr_t)a->res) & 7) == 0 && (long long)a->M * a->ldr * 2 < 0x7f000000LL))) {
