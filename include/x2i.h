@@ -20,7 +20,7 @@
  *     mutex-protected: the option table below, a per-kernel "dynamic LDS size already raised" cache, and ONE HIP object set per
  *     device that holds no memory -- a side stream with two events, created on the first x2i_attention_bwd_bf16 call that runs
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
- *   - ABI version 3 (x2i_abi_version).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
+ *   - ABI version 4 (x2i_abi_version; 4 appends `w_group` to x2i_gemm_args, 0 = what version 3 did, and adds the *_grouped entry points).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
  *     zero-initialised descriptor means what it meant in version 1), appends `out_w`, `out_h`, `out_row_pitch` (0 = computed / dense) and the `moments` fields (NULL = off) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
  *     library (x2i_amd/_lib.py checks).
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define X2I_ABI_VERSION 3
+#define X2I_ABI_VERSION 4
 
 #define X2I_OK 0
 #define X2I_ERR_ARG (-1)
@@ -112,7 +112,14 @@ typedef struct x2i_gemm_args {
   int32_t act; int32_t out_f32;
   void* workspace;                                   /* optional caller-owned stream-K workspace (below); NULL: none */
   int64_t workspace_bytes;
+  int32_t w_group;                                   /* > 0 (needs w_batch_stride != 0): GROUPED weights, see below; 0: off */
+  int32_t reserved1;
 } x2i_gemm_args;
+/* Grouped weights (w_group > 0): w_group consecutive batch items share one W and one bias,
+ *     W[z] = W + (z / w_group) * w_batch_stride,   bias[z] = bias + (z / w_group) * N.
+ * The 19 ControlNeXt models of a LightControl step (lightcontrol_flux.py:504-507: control_nets[i] behind block i) x B samples ride in one launch
+ * this way (x2i_amd/lightcontrol.py: ControlNeXtBank).  Served by x2i_gemm_bf16 and x2i_conv2d_nhwc_bf16 with bf16 outputs (no C2 / f32 output;
+ * the fused-QKV and fp8 entry points refuse it).  An item's results are bit-identical to those of a launch of that item alone with its W and bias. */
 int x2i_gemm_bf16(const x2i_gemm_args* args, x2i_stream_t stream);
 
 /* Stream-K workspace of the persistent GEMM kernel (csrc/gemm256p.hip).  A launch whose last round of 256 x 256 output tiles is
@@ -236,6 +243,16 @@ int x2i_groupnorm_nhwc_from_moments_bf16(const void* x, void* y, int32_t B, int6
                                          const void* bias, float eps, int32_t act, const float* moments, const float* pre_add,
                                          const void* post_add, float* partial, x2i_stream_t stream);
 
+/* GROUPED affine parameters: weight / bias are [ceil(B / w_group)][C] and item b uses row b / w_group (w_group = 0: one [C] pair for all items =
+ * the two entry points above).  The batch of a ControlNeXt bank is (model, sample)-major: the 19 models of a step (lightcontrol_flux.py:504-507)
+ * normalise in one launch, each with its own nn.GroupNorm parameters.  Everything else as above; an item's results do not depend on the batch. */
+int x2i_groupnorm_nhwc_grouped_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight, const void* bias,
+                                    int32_t w_group, float eps, int32_t act, const float* pre_add, const void* post_add, float* partial,
+                                    x2i_stream_t stream);
+int x2i_groupnorm_nhwc_from_moments_grouped_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight,
+                                                 const void* bias, int32_t w_group, float eps, int32_t act, const float* moments,
+                                                 const float* pre_add, const void* post_add, float* partial, x2i_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * F.scaled_dot_product_attention(q, k, v, dropout_p=0, is_causal=False) for head_dim 128 (diffusers
  * FluxAttnProcessor2_0; reference call sites lightcontrol_flux.py:92-95,173-177).
@@ -333,6 +350,11 @@ int x2i_ln_affine_bf16(const void* X, void* Y, int64_t rows, int32_t D, const vo
 int x2i_skinny_linear(const void* X, int32_t x_is_bf16, const void* W, const void* bias, float* Y, int32_t ldy,
                       int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out, int32_t accumulate,
                       x2i_stream_t stream);
+/* `groups` independent skinny linears in one launch (the time embeddings of a ControlNeXt bank): group g has W[g] [N][K] and bias[g] [N]
+ * (contiguous), reads X + g * x_group_stride elements (0: one X [B][K] for every group) and writes rows g*B .. g*B + B-1 of Y.  B <= 8. */
+int x2i_skinny_linear_grouped(const void* X, int32_t x_is_bf16, int64_t x_group_stride, const void* W, const void* bias, float* Y, int32_t ldy,
+                              int32_t groups, int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out, int32_t accumulate,
+                              x2i_stream_t stream);
 
 /* diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(t f_k) | sin(t f_k)] */
 int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, int32_t round_bf16, x2i_stream_t stream);

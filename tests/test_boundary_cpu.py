@@ -45,7 +45,7 @@ def markdown_struct(name):
 def test_gemm_args_header_binding_and_integration_doc_agree():
     from x2i_amd import _lib
     want = header_struct("x2i_gemm_args")
-    assert len(want) == 27 and want[0] == ("A", "c_void_p") and want[-1] == ("workspace_bytes", "c_int64")
+    assert len(want) == 29 and want[0] == ("A", "c_void_p") and want[-2] == ("w_group", "c_int32")
     assert ctypes_struct(_lib.GemmArgs) == want
     assert [(n, t) for n, t in markdown_struct("GemmArgs")] == want, "INTEGRATION.md's raw-binding struct is out of date"
 

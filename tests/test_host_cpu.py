@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
                                     "x2i_streamk_workspace_bytes", "x2i_groupnorm_moments_scratch_floats", "x2i_conv_moments_scratch_floats"}
     assert declared == bound, (declared ^ bound)
     ver = int(re.search(r"#define X2I_ABI_VERSION (\d+)", hdr).group(1))
-    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 3   # header, library and binding move together
+    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 4   # header, library and binding move together
     assert lib.x2i_streamk_workspace_bytes() == 4096 + 512 * 256 * 1024   # the caller-owned workspace: flags + 512 slabs of 256 KiB (round 5: the K split double-buffers)
 
 

@@ -210,3 +210,132 @@ def test_lightcontrol_sampler_vs_oracle():
     got2 = sampler(pe.to(DEV), pooled.to(DEV), hint.to(DEV), num_inference_steps=3, height=128, width=192, latents=noise.to(DEV),
                    use_graph=True)
     assert torch.equal(got2, got)
+
+
+# ---------------------------------------------------------------------------------------------------- grouped weights / ControlNeXtBank
+def _opt(**kw):
+    import contextlib
+    from x2i_amd import _lib
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: _lib.get_option(k) for k in kw}
+        for k, v in kw.items():
+            _lib.set_option(k, v)
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                _lib.set_option(k, v)
+    return cm()
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,p,H,W,res,min256", [
+    (128, 128, 3, 1, 1, 64, 64, True, 1),      # 512 x 128 persistent kernel (8 tiles per item)
+    (128, 256, 3, 1, 1, 64, 48, False, 1),     # 256^2 persistent kernel
+    (256, 256, 5, 2, 2, 64, 64, True, 1),      # ... stride 2, residual
+    (128, 128, 3, 2, 1, 32, 48, True, 256),    # 128^2 kernel
+    (128, 128, 1, 1, 0, 8, 8, False, 256),     # a handful of pixels per item (the corrections' shape class)
+])
+def test_grouped_conv_equals_the_groups_launched_one_by_one(Cin, Cout, k, s, p, H, W, res, min256):
+    """x2i_gemm_args.w_group: batch item b takes W[b // w_group], bias[b // w_group]; bit-identical to one launch per group."""
+    from x2i_amd import _lib, ops
+    G, B = 3, 2
+    torch.manual_seed(11)
+    with _opt(gemm_min256=min256):
+        x = bf(torch.randn(G * B, H, W, Cin)).to(DEV)
+        wt = bf(torch.randn(G, Cout, k * k * Cin) * 0.05).to(DEV)
+        b = bf(torch.randn(G, Cout)).to(DEV)
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        r = bf(torch.randn(G * B, OH, OW, Cout)).to(DEV) if res else None
+        y = ops.conv2d_nhwc(x, wt, b, H, W, Cin, Cout, k, k, s, p, res=r, w_group=B)
+        tile = _lib.get_option("last_gemm_tile")
+        for g in range(G):
+            yg = ops.conv2d_nhwc(x[g * B:(g + 1) * B], wt[g], b[g], H, W, Cin, Cout, k, k, s, p, res=None if r is None else r[g * B:(g + 1) * B])
+            assert _lib.get_option("last_gemm_tile") == tile
+            assert torch.equal(y[g * B:(g + 1) * B], yg), (g, tile)
+    print("tile", tile)
+
+
+def test_grouped_conv_in_chunks_of_whole_groups_and_of_group_parts():
+    """Batches beyond the persistent kernels' one 2 GB input descriptor are launched in chunks: of whole groups, or of parts of one group."""
+    from x2i_amd import _lib, ops
+    H = W = 512
+    Cin, Cout = 256, 128           # 128 MiB per item
+    for G, B in ((6, 4), (2, 16)):   # 15 items fit one descriptor: (6, 4) -> chunks of 12 = 3 whole groups; (2, 16) -> chunks of 8 = half a group
+        torch.manual_seed(5)
+        if True:
+            x = bf(torch.randn(G * B, H, W, Cin)).to(DEV)
+            wt = bf(torch.randn(G, Cout, 9 * Cin) * 0.03).to(DEV)
+            b = bf(torch.randn(G, Cout)).to(DEV)
+            y = ops.conv2d_nhwc(x, wt, b, H, W, Cin, Cout, 3, 3, 1, 1, w_group=B)
+            assert _lib.get_option("last_gemm_tile") == 5512
+            for g in (0, G - 1):
+                yg = ops.conv2d_nhwc(x[g * B:(g + 1) * B], wt[g], b[g], H, W, Cin, Cout, 3, 3, 1, 1)
+                assert torch.equal(y[g * B:(g + 1) * B], yg), (G, B, g)
+    del x, y
+    torch.cuda.empty_cache()
+
+
+def test_grouped_gemm_groupnorm_and_skinny_linear():
+    from x2i_amd import _lib, ops
+    G, B = 3, 2
+    torch.manual_seed(3)
+    if True:
+        a = bf(torch.randn(G * B, 40, 128)).to(DEV)
+        wt = bf(torch.randn(G, 192, 128) * 0.1).to(DEV)
+        b = bf(torch.randn(G, 192)).to(DEV)
+        y = ops.gemm(a, wt, b, M=40, batch=G * B, a_batch_stride=40 * 128, lda=128, w_batch_stride=192 * 128, w_group=B)
+        for g in range(G):
+            yg = ops.gemm(a[g * B:(g + 1) * B], wt[g], b[g], M=40, batch=B, a_batch_stride=40 * 128, lda=128)
+            assert torch.equal(y[g * B:(g + 1) * B], yg)
+        x = bf(torch.randn(G * B, 20, 12, 128)).to(DEV)
+        gw, gb = bf(torch.randn(G, 128)).to(DEV), bf(torch.randn(G, 128)).to(DEV)
+        pre = torch.randn(G * B, 128).to(DEV)
+        post = bf(torch.randn(G * B, 20, 12, 128)).to(DEV)
+        mom = ops.groupnorm_moments(x)
+        y = ops.groupnorm_nhwc(x, gw, gb, 4, 1e-6, act=ops.ACT_SILU, pre_add=pre, post_add=post, w_group=B)
+        ym = ops.groupnorm_nhwc_from_moments(x, mom, gw, gb, 4, 1e-6, act=ops.ACT_SILU, pre_add=pre, w_group=B)
+        for g in range(G):
+            sl = slice(g * B, (g + 1) * B)
+            assert torch.equal(y[sl], ops.groupnorm_nhwc(x[sl], gw[g], gb[g], 4, 1e-6, act=ops.ACT_SILU, pre_add=pre[sl], post_add=post[sl]))
+            assert torch.equal(ym[sl], ops.groupnorm_nhwc_from_moments(x[sl], mom[sl], gw[g], gb[g], 4, 1e-6, act=ops.ACT_SILU, pre_add=pre[sl]))
+        xs = torch.randn(G * B, 256).to(DEV)
+        ws, bs = bf(torch.randn(G, 320, 256) * 0.1).to(DEV), bf(torch.randn(G, 320)).to(DEV)
+        y = ops.skinny_linear_grouped(xs, ws, bs, rows=B, act_in=ops.ACT_SILU)
+        y1 = ops.skinny_linear_grouped(xs[:B].contiguous(), ws, bs, rows=B, act_out=ops.ACT_SILU)     # one input for every group
+        for g in range(G):
+            sl = slice(g * B, (g + 1) * B)
+            assert torch.equal(y[sl], ops.skinny_linear(xs[sl], ws[g], bs[g], act_in=ops.ACT_SILU))
+            assert torch.equal(y1[sl], ops.skinny_linear(xs[:B], ws[g], bs[g], act_out=ops.ACT_SILU))
+    with pytest.raises(_lib.X2IError):
+        ops.gemm(a, wt, b, M=40, batch=G * B, a_batch_stride=40 * 128, lda=128, w_group=B)      # w_group without w_batch_stride
+
+
+@pytest.mark.parametrize("H,W,min256", [(64, 96, 256), (256, 256, 1)])
+def test_controlnext_bank_is_bit_identical_to_the_nets_one_by_one(H, W, min256, monkeypatch):
+    """ControlNeXtBank (all nets' trunks as one (net, sample)-major batch with grouped weights) against forward_nhwc net by net: the same kernels
+    on the same items -- bitwise.  (256, 256, gemm_min256 = 1: the persistent convolution kernels serve the trunk, as at 1024^2.)"""
+    from x2i_amd.lightcontrol import ControlNeXtBank, make_control_fn
+    nets = [_load_cnext(40 + i, 256)[0] for i in range(3)]
+    g = torch.Generator().manual_seed(8)
+    hint = bf(torch.rand((2, 3, H, W), generator=g) * 2 - 1).to(DEV)
+    assert ControlNeXtBank.eligible(nets)
+    S, St, D = (H // 16) * (W // 16) + 8, 8, 256
+    outs = {}
+    with _opt(gemm_min256=min256):
+        for bank in ("1", "0"):
+            monkeypatch.setenv("X2I_CONTROL_BANK", bank)
+            fn = make_control_fn(nets, hint)
+            res = []
+            for tv in (0.3, 0.8):
+                X = torch.zeros((2, S, D), device=DEV, dtype=torch.bfloat16)
+                t1000 = torch.tensor([tv * 1000, tv * 1000], device=DEV)
+                for i in range(len(nets)):
+                    assert fn(i, t1000, X, St, S, D)
+                assert not fn(len(nets), t1000, X, St, S, D)
+                res.append(X.clone())
+            outs[bank] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert float(a.float().abs().max()) > 0 and torch.equal(a, b)
+    assert torch.equal(outs["1"][0][:, :St], torch.zeros_like(outs["1"][0][:, :St]))   # text rows untouched

@@ -14,7 +14,7 @@ _VARIANT = os.environ.get("X2I_LIB_VARIANT", "")
 LIB_PATH = os.path.join(_HERE, "libx2i_hip_%s.so" % _VARIANT if _VARIANT else "libx2i_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
-ABI_VERSION = 3  # include/x2i.h: X2I_ABI_VERSION
+ABI_VERSION = 4  # include/x2i.h: X2I_ABI_VERSION
 
 
 class X2IError(RuntimeError):
@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("act", C.c_int32), ("out_f32", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("w_group", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -83,6 +84,9 @@ SIGNATURES = {
     "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],
     "x2i_ln_modulate_bf16": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp],
     "x2i_ln_affine_bf16": [_vp, _vp, _i64, _i32, _vp, _vp, _f32, _vp],
+    "x2i_groupnorm_nhwc_grouped_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp],
+    "x2i_groupnorm_nhwc_from_moments_grouped_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "x2i_skinny_linear_grouped": [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "x2i_skinny_linear": [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "x2i_timestep_sinusoid": [_vp, _vp, _i32, _i32, _i32, _vp],
     "x2i_rope_table_f32": [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],

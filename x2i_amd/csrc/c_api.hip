@@ -272,6 +272,18 @@ int x2i_groupnorm_nhwc_from_moments_bf16(const void* x, void* y, int32_t B, int6
   return x2i_launch_groupnorm_from_moments(x, y, B, HW, C, G, weight, bias, eps, act, moments, pre_add, post_add, partial, (hipStream_t)stream);
 }
 
+int x2i_groupnorm_nhwc_grouped_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight, const void* bias,
+                                    int32_t w_group, float eps, int32_t act, const float* pre_add, const void* post_add, float* partial,
+                                    x2i_stream_t stream) {
+  return x2i_launch_groupnorm(x, y, B, HW, C, G, weight, bias, eps, act, pre_add, post_add, partial, (hipStream_t)stream, w_group);
+}
+int x2i_groupnorm_nhwc_from_moments_grouped_bf16(const void* x, void* y, int32_t B, int64_t HW, int32_t C, int32_t G, const void* weight,
+                                                 const void* bias, int32_t w_group, float eps, int32_t act, const float* moments,
+                                                 const float* pre_add, const void* post_add, float* partial, x2i_stream_t stream) {
+  return x2i_launch_groupnorm_from_moments(x, y, B, HW, C, G, weight, bias, eps, act, moments, pre_add, post_add, partial, (hipStream_t)stream,
+                                           w_group);
+}
+
 int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
                        int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
   return x2i_launch_attention(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, (hipStream_t)stream);
@@ -329,6 +341,13 @@ int x2i_ln_affine_bf16(const void* X, void* Y, int64_t rows, int32_t D, const vo
 int x2i_skinny_linear(const void* X, int32_t x_is_bf16, const void* W, const void* bias, float* Y, int32_t ldy, int32_t B,
                       int32_t N, int32_t K, int32_t act_in, int32_t act_out, int32_t accumulate, x2i_stream_t stream) {
   return x2i_launch_skinny_linear(X, x_is_bf16, W, bias, Y, ldy, B, N, K, act_in, act_out, accumulate, (hipStream_t)stream);
+}
+
+int x2i_skinny_linear_grouped(const void* X, int32_t x_is_bf16, int64_t x_group_stride, const void* W, const void* bias, float* Y, int32_t ldy,
+                              int32_t groups, int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out, int32_t accumulate,
+                              x2i_stream_t stream) {
+  return x2i_launch_skinny_linear_grouped(X, x_is_bf16, x_group_stride, W, bias, Y, ldy, groups, B, N, K, act_in, act_out, accumulate,
+                                          (hipStream_t)stream);
 }
 
 int x2i_timestep_sinusoid(const float* t, float* out, int32_t B, int32_t dim, int32_t round_bf16, x2i_stream_t stream) {

@@ -251,8 +251,10 @@ __global__ __launch_bounds__(256) void gn_finish_moments_kernel(const float* __r
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long HW, int C, int G,
                                                        const bf16_t* __restrict__ w, const bf16_t* __restrict__ bias,
                                                        int act, const float* __restrict__ pre_add,
-                                                       const bf16_t* __restrict__ post_add, const float* __restrict__ partial) {
+                                                       const bf16_t* __restrict__ post_add, const float* __restrict__ partial, int wdiv) {
   const int b = blockIdx.y;
+  w += (long long)(b / wdiv) * C;      // grouped affine parameters (x2i_groupnorm_*_grouped_bf16): wdiv consecutive items share one [C] pair
+  bias += (long long)(b / wdiv) * C;
   const int cpp = C / 8, cpg = C / G;
   const long long total = HW * cpp;
   const int chunk = threadIdx.x % cpp, c0 = chunk * 8;
@@ -373,7 +375,8 @@ int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void*
 long long x2i_groupnorm_scratch(int B, int G) { return (long long)B * G * 2 * (GN_SLABS + 1); }
 
 int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
-                         const float* pre_add, const void* post_add, float* partial, hipStream_t stream) {
+                         const float* pre_add, const void* post_add, float* partial, hipStream_t stream, int w_group) {
+  if (w_group < 0) return x2i_set_error(X2I_ERR_ARG, "groupnorm: w_group < 0");
   if (!x || !y || !w || !b || !partial) return x2i_set_error(X2I_ERR_ARG, "groupnorm: null pointer");
   if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || G <= 0 || G > 32 || C % G || !((C / G) % 8 == 0 || (C / G) == 4))
     return x2i_set_error(X2I_ERR_SHAPE, "groupnorm: unsupported C=%d G=%d (need C/8 | 256 and C/G == 4 or a multiple of 8)", C, G);
@@ -388,7 +391,7 @@ int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int
   const long long cap = 8192 / B > 256 ? 8192 / B : 256;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,
-                     (const bf16_t*)w, (const bf16_t*)b, act, pre_add, (const bf16_t*)post_add, partial);
+                     (const bf16_t*)w, (const bf16_t*)b, act, pre_add, (const bf16_t*)post_add, partial, w_group > 0 ? w_group : B);
   return x2i_check_launch("groupnorm_apply");
 }
 
@@ -405,7 +408,8 @@ int x2i_launch_groupnorm_moments(const void* x, int B, long long HW, int C, floa
 }
 
 int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
-                                      const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream) {
+                                      const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream, int w_group) {
+  if (w_group < 0) return x2i_set_error(X2I_ERR_ARG, "groupnorm_from_moments: w_group < 0");
   if (!x || !y || !w || !b || !partial || !moments) return x2i_set_error(X2I_ERR_ARG, "groupnorm_from_moments: null pointer");
   if (B <= 0 || HW <= 0 || C % 8 || 256 % (C / 8) || C > 2048 || G <= 0 || G > 32 || C % G || !((C / G) % 8 == 0 || (C / G) == 4))
     return x2i_set_error(X2I_ERR_SHAPE, "groupnorm_from_moments: unsupported C=%d G=%d", C, G);
@@ -417,7 +421,7 @@ int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long H
   const long long cap = 8192 / B > 256 ? 8192 / B : 256;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, HW, C, G,
-                     (const bf16_t*)w, (const bf16_t*)b, act, pre_add, (const bf16_t*)post_add, partial);
+                     (const bf16_t*)w, (const bf16_t*)b, act, pre_add, (const bf16_t*)post_add, partial, w_group > 0 ? w_group : B);
   return x2i_check_launch("groupnorm_apply");
 }
 

@@ -236,8 +236,16 @@ constexpr int SK_MAXB = 8;
 template <int NB>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const void* __restrict__ Xv, int x_is_bf16, const bf16_t* __restrict__ W,
                                                             const bf16_t* __restrict__ bias, float* __restrict__ Y, int ldy, int N,
-                                                            int K, int act_in, int act_out, int accumulate, int rpw) {
+                                                            int K, int act_in, int act_out, int accumulate, int rpw, long long x_gs, int rows_g) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // grouped form (x2i_skinny_linear_grouped): blockIdx.y = group g with its own W [N][K], bias [N], rows_g output rows and input rows x_gs elements apart
+  if (blockIdx.y) {
+    const long long g = blockIdx.y;
+    Xv = (const char*)Xv + g * x_gs * (x_is_bf16 ? 2 : 4);
+    W += g * N * K;
+    if (bias) bias += g * N;
+    Y += g * rows_g * ldy;
+  }
   // [K][NBP]: the NB samples' values of one k side by side; the row stride is rounded up to an EVEN count so that every sample pair
   // read below (8-byte vector) is 8-byte aligned also for odd NB (the pad column is never read)
   constexpr int NBP = NB == 1 ? 1 : (NB + 1) & ~1;
@@ -457,7 +465,16 @@ int x2i_launch_qkv_split(const void* qkv0, const void* qkv1, int ld0, int ld1, i
 
 int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const void* bias, float* Y, int ldy, int B, int N, int K,
                              int act_in, int act_out, int accumulate, hipStream_t stream) {
+  return x2i_launch_skinny_linear_grouped(X, x_is_bf16, 0, W, bias, Y, ldy, 1, B, N, K, act_in, act_out, accumulate, stream);
+}
+
+// G independent skinny linears in one launch: group g has W[g] [N][K], bias[g] [N], input rows X + g * x_gs (x_gs = 0: one input for all groups) and
+// output rows g * B .. g * B + B - 1 of Y
+int x2i_launch_skinny_linear_grouped(const void* X, int x_is_bf16, long long x_gs, const void* W, const void* bias, float* Y, int ldy, int G, int B,
+                                     int N, int K, int act_in, int act_out, int accumulate, hipStream_t stream) {
   if (!X || !W || !Y) return x2i_set_error(X2I_ERR_ARG, "skinny_linear: null pointer");
+  if (G <= 0 || G > 65535 || x_gs < 0) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: bad group count / stride (G=%d)", G);
+  if (G > 1 && B > SK_MAXB) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear_grouped: at most %d rows per group (B=%d)", SK_MAXB, B);
   if (B <= 0 || N <= 0 || K <= 0 || K % 8) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: K=%d must be a multiple of 8", K);
   if (!al16(W)) return x2i_set_error(X2I_ERR_ALIGN, "skinny_linear: W must be 16-byte aligned");
   const int esz = x_is_bf16 ? 2 : 4;
@@ -467,7 +484,7 @@ int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const 
     float* yp = Y + (long long)b0 * ldy;
     // many rows per block when N is huge (the 1M-row AdaLN modulation table) so the activations are staged once
     const int rpw = N >= 65536 ? 16 : 4;
-    const dim3 grid((N + 4 * rpw - 1) / (4 * rpw)), block(256);
+    const dim3 grid((N + 4 * rpw - 1) / (4 * rpw), G), block(256);
     const size_t shm = (size_t)(nb == 1 ? 1 : (nb + 1) & ~1) * K * 4;   // (row stride padded to an even sample count)
     if (shm > 160 * 1024) return x2i_set_error(X2I_ERR_SHAPE, "skinny_linear: B*K too large for LDS");
 #define SK_CASE(NB)                                                                                                   \
@@ -476,7 +493,7 @@ int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const 
                                        (int)shm);                                                                     \
     if (e != hipSuccess) return x2i_set_error(X2I_ERR_HIP, "skinny_linear: %s", hipGetErrorString(e));                \
     hipLaunchKernelGGL(skinny_linear_kernel<NB>, grid, block, shm, stream, xp, x_is_bf16, (const bf16_t*)W,           \
-                       (const bf16_t*)bias, yp, ldy, N, K, act_in, act_out, accumulate, rpw);                         \
+                       (const bf16_t*)bias, yp, ldy, N, K, act_in, act_out, accumulate, rpw, x_gs, B);               \
   } break;
     switch (nb) {
       SK_CASE(1) SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7) SK_CASE(8)

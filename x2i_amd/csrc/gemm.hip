@@ -24,10 +24,10 @@ __global__ void gemm_naive_kernel(GemmP p, int batch) {
   const int z = (int)(mz / p.M), m = (int)(mz % p.M);
   if (n >= p.N || z >= batch) return;
   const bf16_t* a = p.A + (long long)z * p.a_bs + (long long)m * p.lda;
-  const bf16_t* w = p.W + (long long)z * p.w_bs + (long long)n * p.ldw;
+  const bf16_t* w = p.W + (long long)(z / p.wdiv) * p.w_bs + (long long)n * p.ldw;
   float acc = 0.f;
   for (int k = 0; k < p.K; ++k) acc = fmaf(bf16_to_f32(a[k]), bf16_to_f32(w[k]), acc);
-  float v = acc + (p.bias ? bf16_to_f32(p.bias[n]) : 0.f) + (p.bias2 ? p.bias2[(long long)z * p.bias2_bs + n] : 0.f);
+  float v = acc + (p.bias ? bf16_to_f32(p.bias[(long long)(z / p.wdiv) * p.bias_gs + n]) : 0.f) + (p.bias2 ? p.bias2[(long long)z * p.bias2_bs + n] : 0.f);
   v = apply_act(v, p.act);
   if (p.res) {
     const float g = p.gate ? p.gate[(long long)z * p.gate_bs + n] : 1.f;
@@ -65,6 +65,7 @@ int x2i_launch_gemm_qkv(const x2i_gemm_args* a, const x2i_qkv_desc* qd, hipStrea
 static void fill_gemm_p(const x2i_gemm_args* a, const x2i_qkv_desc* qd, GemmP& p) {
   p.A = (const bf16_t*)a->A; p.a_bs = a->a_batch_stride; p.lda = a->lda;
   p.W = (const bf16_t*)a->W; p.ldw = a->ldw; p.w_bs = a->w_batch_stride;
+  p.wdiv = a->w_group > 0 ? a->w_group : 1; p.bias_gs = a->w_group > 0 ? a->N : 0;
   p.bias = (const bf16_t*)a->bias;
   p.C = a->C; p.c_bs = a->c_batch_stride; p.ldc = a->ldc;
   p.C2 = (bf16_t*)a->C2; p.act2 = a->act2;
@@ -297,6 +298,12 @@ static int launch_conv_chunks(kern_t kc, int smem, const GemmP& p0, const x2i_ge
   if (room < 0) return X2I_ERR_STATE;
   long long per = a->a_batch_stride > 0 ? room / (a->a_batch_stride * 2) + 1 : a->batch;
   if (per > a->batch) per = a->batch;
+  // grouped weights: a chunk holds whole groups, or (when a group does not fit) a part of ONE group
+  const int wg = p0.wdiv > 1 ? p0.wdiv : 0;
+  if (wg && per < a->batch) {
+    if (per >= wg) per -= per % wg;
+    else while (wg % per) --per;
+  }
   const int cus = x2i_num_cus();
   for (int z0 = 0; z0 < a->batch; z0 += (int)per) {
     const int nb = (int)(a->batch - z0 < per ? a->batch - z0 : per);
@@ -306,6 +313,11 @@ static int launch_conv_chunks(kern_t kc, int smem, const GemmP& p0, const x2i_ge
     pm.C = (void*)((bf16_t*)p0.C + (long long)z0 * p0.c_bs);
     if (p0.res) pm.res = p0.res + (long long)z0 * p0.r_bs;
     if (p0.bias2) pm.bias2 = p0.bias2 + (long long)z0 * p0.bias2_bs;
+    if (wg) {
+      pm.W = p0.W + (long long)(z0 / wg) * p0.w_bs;
+      if (p0.bias) pm.bias = p0.bias + (long long)(z0 / wg) * p0.bias_gs;
+      if (per < wg) pm.wdiv = nb;   // (all items of this chunk belong to one group)
+    }
     const long long tiles = (long long)pm.tilesM * pm.tilesN * nb;
     hipLaunchKernelGGL(kc, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(256), smem, stream, pm);
     if (cd->moments) {
@@ -325,6 +337,8 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   const bool conv = cd != nullptr;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm: gate without residual");
+  if (a->w_group < 0 || (a->w_group > 0 && (!a->w_batch_stride || qd || a->C2 || a->out_f32)))
+    return x2i_set_error(X2I_ERR_ARG, "gemm: w_group=%d needs w_batch_stride != 0 and goes with the plain bf16 outputs only (no fused QKV / C2 / f32 output)", a->w_group);
   GemmP p;
   fill_gemm_p(a, qd, p);
   if (conv) {
@@ -408,10 +422,13 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   // the batch it rides in (tests/test_fullscale_parity_gpu.py: batch independence of the LightControl step)
   // ... and only for items with at least 64 tiles (a quarter of the chip per item: the VAE's and ControlNeXt's convolutions at 1024^2); smaller
   // images keep the older kernels, whose smaller tiles fill the chip better there (tests lower the threshold through gemm_min256)
+  // grouped weights ride the persistent kernels when all groups' weights fit ONE descriptor (the kernels address them through a per-item offset)
+  const bool wgrp_ok = !a->w_batch_stride || (a->w_group > 0 && (a->w_batch_stride & 7) == 0 &&
+                                              ((long long)((a->batch - 1) / a->w_group) * a->w_batch_stride + (long long)a->N * a->ldw) * 2 < 0x7f000000LL);
   const long long conv_item_thr = opt.gemm_min256 < 64 ? opt.gemm_min256 : 64;
   const bool conv_item256 = conv && a->N >= 256 && a->N % 8 == 0 && a->M >= 1024 && opt.conv256 &&
                             (long long)((a->M + BM2 - 1) / BM2) * ((a->N + BN2 - 1) / BN2) >= conv_item_thr;
-  if (conv_item256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
+  if (conv_item256 && opt.conv_w4 && fast && cd->up == 0 && !f32 && !c2 && wgrp_ok && a->K >= 3 * BK && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 &&
       (((uintptr_t)a->C) & 15) == 0 && (long long)a->M < (1LL << 24) &&
       (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
       (long long)a->M * a->ldc * 2 < 0x7f000000LL && (!cd->out_row_pitch || (long long)(a->M / p.cOW) * cd->out_row_pitch * 2 < 0x7f000000LL) &&
@@ -430,7 +447,7 @@ static int launch_gemm_impl(const x2i_gemm_args* a, const x2i_conv_desc* cd, con
   }
   // ... and with at most 128 output channels (the VAE's last up block, ControlNeXt's 128-wide convolutions): 512 x 128 tiles on the same core
   // (gemm512c.hip: the same wave tile and K-loop, epilogue straight from registers); outputs bit-identical to the 128^2 kernel's
-  if (conv && opt.conv_w4 && opt.gemm_tile == 0 && fast && cd->up == 0 && !cd->out_row_pitch && !f32 && !c2 && !a->w_batch_stride && a->K >= 3 * BK && a->N > 64 && a->N <= 128 &&
+  if (conv && opt.conv_w4 && opt.gemm_tile == 0 && fast && cd->up == 0 && !cd->out_row_pitch && !f32 && !c2 && wgrp_ok && a->K >= 3 * BK && a->N > 64 && a->N <= 128 &&
       (a->N & 7) == 0 && (a->ldc & 7) == 0 && (a->c_batch_stride & 7) == 0 && (((uintptr_t)a->C) & 15) == 0 && a->M >= 2048 && (long long)a->M < (1LL << 24) &&
       (long long)((a->M + 511) / 512) >= conv_item_thr &&
       (long long)cd->H * cd->W * cd->Cin * 2 + ((long long)cd->pad * cd->W + pad_w_of(cd)) * cd->Cin * 2 < 0x7f000000LL &&
@@ -633,7 +650,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   if (!a || !f || !a->A || !a->W || (!a->C && !qd)) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: null pointer");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return x2i_set_error(X2I_ERR_SHAPE, "gemm_fp8: bad shape M=%d N=%d K=%d batch=%d", a->M, a->N, a->K, a->batch);
   if (a->gate && !a->res) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: gate without residual");
-  if (a->C2 || a->out_f32 || a->w_batch_stride) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: C2 / f32 output / per-batch W are not supported");
+  if (a->C2 || a->out_f32 || a->w_batch_stride || a->w_group) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: C2 / f32 output / per-batch W are not supported");
   if (a->K % 128 || a->lda % 16 || a->ldw % 16 || (a->a_batch_stride & 15) || (((uintptr_t)a->A | (uintptr_t)a->W) & 15))
     return x2i_set_error(X2I_ERR_ALIGN, "gemm_fp8: needs K %% 128 == 0 (K=%d), lda / ldw / a_batch_stride %% 16 == 0, 16-byte aligned A / W", a->K);
   if ((long long)a->M * a->lda >= 0x7f000000LL || (long long)a->N * a->ldw >= 0x7f000000LL)
@@ -647,7 +664,7 @@ static int launch_gemm_fp8_impl(const x2i_gemm_args* a, const x2i_fp8_desc* f, c
   if (!kern) return x2i_set_error(X2I_ERR_ARG, "gemm_fp8: epilogue (act=%d%s%s) is not instantiated", a->act, res ? ", residual" : "", out8 ? ", e4m3 out" : "");
   GemmP p;
   p.A = (const bf16_t*)a->A; p.a_bs = a->a_batch_stride; p.lda = a->lda;
-  p.W = (const bf16_t*)a->W; p.ldw = a->ldw; p.w_bs = 0;
+  p.W = (const bf16_t*)a->W; p.ldw = a->ldw; p.w_bs = 0; p.wdiv = 1; p.bias_gs = 0;
   p.bias = (const bf16_t*)a->bias;
   p.C = a->C; p.c_bs = a->c_batch_stride; p.ldc = a->ldc;
   p.C2 = nullptr; p.act2 = 0;

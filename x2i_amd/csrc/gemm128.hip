@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
                                 : (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)z * p.w_bs), 0, w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)(z / p.wdiv) * p.w_bs), 0, w_bytes, 0x00020000);
 
   // per-thread source offsets of its 4 chunks per operand tile (row r, physical chunk c holds logical chunk c^swz)
   uint32_t a_voff[4], w_voff[4];

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void gemm256l_bf16_kernel(GemmP p) {
   const uint32_t a_bytes = CONV ? (uint32_t)((long long)p.cH * p.cW * p.cCin * 2) : (uint32_t)(((long long)(p.M - 1) * p.lda + p.K) * 2);
   const uint32_t w_bytes = (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2);
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Az, 0, a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)z * p.w_bs), 0, w_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (long long)(z / p.wdiv) * p.w_bs), 0, w_bytes, 0x00020000);
 
   // piece q = jj*8 + wave (jj = 0..3) covers row group q (rows 8q..8q+7); lane -> (k-half, row in group, physical chunk)
   uint32_t a_voff[4], w_voff[4];

@@ -67,11 +67,12 @@ __global__ __launch_bounds__(256) void gemm256c_kernel(GemmP p) {
   const int kby = khl * 64 + ((cphys ^ (3 * (wave & 1))) << 4);  // byte within the K-tile's 128-byte line (group parity = wave parity)
   auto offsets = [&](int z, int m0, int n0, uint32_t (&va)[8], uint32_t (&vw)[8], uint32_t (&mk)[8]) {
     const long long zoff = (long long)z * p.a_bs * 2 + bias_b + kby;
+    const long long wz = (long long)(z / p.wdiv) * p.w_bs * 2;   // grouped weights (x2i_gemm_args.w_group): this item's W inside the one descriptor over all groups
     int oy = fast_div(m0 + wave * 8 + r8, p.cOW, r_ow), ox = m0 + wave * 8 + r8 - oy * p.cOW;   // piece 0's pixel; the next pieces are 32 pixels apart
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int row = (jj * 4 + wave) * 8 + r8;
-      vw[jj] = (n0 + row < p.N) ? (uint32_t)((long long)(n0 + row) * p.ldw * 2 + kby) : 0x80000000u;
+      vw[jj] = (n0 + row < p.N) ? (uint32_t)(wz + (long long)(n0 + row) * p.ldw * 2 + kby) : 0x80000000u;
       const int m = m0 + row;
       if (jj) {
         ox += 32;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm256c_kernel(GemmP p) {
   };
   // one descriptor over all batch items (< 2 GB: launcher), starting bias_b bytes in front of A: every in-image tap of every pixel lies inside it
   const __amdgpu_buffer_rsrc_t a_rsrc = mk_rsrc(p.A, bias_b, (uint32_t)(((long long)(p.nbatch - 1) * p.a_bs + (long long)p.cH * p.cW * p.cCin) * 2 + bias_b));
-  const __amdgpu_buffer_rsrc_t w_rsrc = mk_rsrc(p.W, 0, (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2));
+  const __amdgpu_buffer_rsrc_t w_rsrc = mk_rsrc(p.W, 0, (uint32_t)(((long long)((p.nbatch - 1) / p.wdiv) * p.w_bs + (long long)(p.N - 1) * p.ldw + p.K) * 2));
 
   // ---- this workgroup's units: whole tiles vb = w, w + G, ...
   const int n_units = (TT - w + G - 1) / G;

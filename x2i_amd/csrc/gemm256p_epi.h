@@ -227,7 +227,9 @@ __device__ __forceinline__ void epilogue_chunked_pipe(const GemmP& p, f32x4_t (&
     }
     if (n + 3 < p.N) {
       if (p.bias) {
-        const uint2 bb = *(const uint2*)(p.bias + n);
+        const bf16_t* biasz = p.bias;
+        if constexpr (CONV) biasz += (long long)(z / p.wdiv) * p.bias_gs;   // (grouped weights: x2i_gemm_args.w_group)
+        const uint2 bb = *(const uint2*)(biasz + n);
         bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
         bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
       }

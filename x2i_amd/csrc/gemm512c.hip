@@ -36,7 +36,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmP& p, f32x4_t (&acc)[2
     for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
     if (n + 3 < p.N) {
       if (p.bias) {
-        const uint2 bb = *(const uint2*)(p.bias + n);
+        const uint2 bb = *(const uint2*)(p.bias + (long long)(z / p.wdiv) * p.bias_gs + n);   // (grouped weights: x2i_gemm_args.w_group)
         bv[j][0] = __uint_as_float(bb.x << 16); bv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
         bv[j][2] = __uint_as_float(bb.y << 16); bv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
       }
@@ -154,10 +154,11 @@ __global__ __launch_bounds__(256) void gemm512c_kernel(GemmP p) {
   const int kby = khl * 64 + ((cphys ^ (3 * (wave & 1))) << 4);
   auto offsets = [&](int z, int m0, int n0, uint32_t (&va)[16], uint32_t (&vw)[4], uint32_t (&mk)[16]) {
     const long long zoff = (long long)z * p.a_bs * 2 + bias_b + kby;
+    const long long wz = (long long)(z / p.wdiv) * p.w_bs * 2;   // grouped weights (x2i_gemm_args.w_group): this item's W inside the one descriptor over all groups
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int row = (jj * 4 + wave) * 8 + r8;
-      vw[jj] = (n0 + row < p.N) ? (uint32_t)((long long)(n0 + row) * p.ldw * 2 + kby) : 0x80000000u;
+      vw[jj] = (n0 + row < p.N) ? (uint32_t)(wz + (long long)(n0 + row) * p.ldw * 2 + kby) : 0x80000000u;
     }
     int oy = fast_div(m0 + wave * 8 + r8, p.cOW, r_ow), ox = m0 + wave * 8 + r8 - oy * p.cOW;   // piece 0's pixel; the next pieces are 32 pixels apart
 #pragma unroll
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm512c_kernel(GemmP p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)au, 0, (uint32_t)uni((int)bytes), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t a_rsrc = mk_rsrc(p.A, bias_b, (uint32_t)(((long long)(p.nbatch - 1) * p.a_bs + (long long)p.cH * p.cW * p.cCin) * 2 + bias_b));
-  const __amdgpu_buffer_rsrc_t w_rsrc = mk_rsrc(p.W, 0, (uint32_t)(((long long)(p.N - 1) * p.ldw + p.K) * 2));
+  const __amdgpu_buffer_rsrc_t w_rsrc = mk_rsrc(p.W, 0, (uint32_t)(((long long)((p.nbatch - 1) / p.wdiv) * p.w_bs + (long long)(p.N - 1) * p.ldw + p.K) * 2));
 
   const int n_units = (TT - w + G - 1) / G;
   if (n_units <= 0) return;  // (workgroup-uniform)

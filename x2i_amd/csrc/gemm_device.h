@@ -13,6 +13,7 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 struct GemmP {
   const bf16_t* A; long long a_bs; int lda;
   const bf16_t* W; int ldw; long long w_bs;
+  int wdiv, bias_gs;                       // grouped weights (x2i_gemm_args.w_group): batch item z reads W + (z / wdiv) * w_bs and bias + (z / wdiv) * bias_gs; off: 1, 0
   const bf16_t* bias;
   void* C; long long c_bs; int ldc;
   bf16_t* C2; int act2;
@@ -117,6 +118,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
   // ---- epilogue: lane owns m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4 + 0..3
   const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
   const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const bf16_t* biasz = p.bias ? p.bias + (long long)(z / p.wdiv) * p.bias_gs : nullptr;   // (grouped weights: x2i_gemm_args.w_group)
   const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!RES || (p.ldr & 3) == 0);
   static_for<NT>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -126,8 +128,8 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
       float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
       const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
       if (full) {
-        if (p.bias) {
-          const uint2 b2 = *(const uint2*)(p.bias + n);
+        if (biasz) {
+          const uint2 b2 = *(const uint2*)(biasz + n);
           bv[0] = __uint_as_float(b2.x << 16); bv[1] = __uint_as_float(b2.x & 0xffff0000u);
           bv[2] = __uint_as_float(b2.y << 16); bv[3] = __uint_as_float(b2.y & 0xffff0000u);
         }
@@ -143,7 +145,7 @@ __device__ __forceinline__ void epilogue_store(const GemmP& p, f32x4_t (&acc)[MT
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (n + r < p.N) {
-            if (p.bias) bv[r] = bf16_to_f32(p.bias[n + r]);
+            if (biasz) bv[r] = bf16_to_f32(biasz[n + r]);
             if (gz) gv[r] = gz[n + r];
             if (b2) bv[r] += b2[n + r];
           }
@@ -234,6 +236,7 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
   const int mlane = lane & 15, ng = lane >> 4;
   const float* gz = (RES && p.gate) ? p.gate + (long long)z * p.gate_bs : nullptr;
   const bf16_t* rz = RES ? p.res + (long long)z * p.r_bs : nullptr;
+  const bf16_t* biasz = p.bias ? p.bias + (long long)(z / p.wdiv) * p.bias_gs : nullptr;   // (grouped weights: x2i_gemm_args.w_group)
   const float* b2 = p.bias2 ? p.bias2 + (long long)z * p.bias2_bs : nullptr;
   bf16_t* Cz = (bf16_t*)p.C + (long long)z * p.c_bs;
   bf16_t* C2z = HASC2 ? p.C2 + (long long)z * p.c_bs : nullptr;
@@ -263,8 +266,8 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
 #pragma unroll
         for (int r = 0; r < 4; ++r) bvv[j][r] = 0.f, gvv[MOM ? 0 : j][r] = 1.f;
         if (n + 3 < p.N) {
-          if (p.bias) {
-            const uint2 bb = *(const uint2*)(p.bias + n);
+          if (biasz) {
+            const uint2 bb = *(const uint2*)(biasz + n);
             bvv[j][0] = __uint_as_float(bb.x << 16); bvv[j][1] = __uint_as_float(bb.x & 0xffff0000u);
             bvv[j][2] = __uint_as_float(bb.y << 16); bvv[j][3] = __uint_as_float(bb.y & 0xffff0000u);
           }
@@ -328,8 +331,8 @@ __device__ __forceinline__ void epilogue_store_lds(const GemmP& p, f32x4_t (&acc
       const int n = n_wave + j * 16 + ng * 4;
       float bv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
       if (n + 3 < p.N) {
-        if (p.bias) {
-          const uint2 bb = *(const uint2*)(p.bias + n);
+        if (biasz) {
+          const uint2 bb = *(const uint2*)(biasz + n);
           bv[0] = __uint_as_float(bb.x << 16); bv[1] = __uint_as_float(bb.x & 0xffff0000u);
           bv[2] = __uint_as_float(bb.y << 16); bv[3] = __uint_as_float(bb.y & 0xffff0000u);
         }

@@ -20,11 +20,12 @@ int x2i_launch_conv_stem(const void* x, const float* w, const float* bias, void*
                          hipStream_t stream);
 long long x2i_groupnorm_scratch(int B, int G);
 int x2i_launch_groupnorm(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps,
-                         int act, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
+                         int act, const float* pre_add, const void* post_add, float* partial, hipStream_t stream, int w_group = 0);
 long long x2i_groupnorm_moments_scratch(int B, int C);
 int x2i_launch_groupnorm_moments(const void* x, int B, long long HW, int C, float* moments, float* scratch, hipStream_t stream);
 int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long HW, int C, int G, const void* w, const void* b, float eps, int act,
-                                      const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream);
+                                      const float* moments, const float* pre_add, const void* post_add, float* partial, hipStream_t stream,
+                                      int w_group = 0);
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                          long long o_bs, float scale, hipStream_t stream, int out8 = 0, float oinv = 1.f, float* lse = nullptr);
 int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
@@ -46,6 +47,8 @@ int x2i_launch_ln_affine(const void* X, void* Y, long long rows, int D, const vo
                          hipStream_t stream);
 int x2i_launch_skinny_linear(const void* X, int x_is_bf16, const void* W, const void* bias, float* Y, int ldy, int B,
                              int N, int K, int act_in, int act_out, int accumulate, hipStream_t stream);
+int x2i_launch_skinny_linear_grouped(const void* X, int x_is_bf16, long long x_gs, const void* W, const void* bias, float* Y, int ldy, int G, int B,
+                                     int N, int K, int act_in, int act_out, int accumulate, hipStream_t stream);
 int x2i_launch_timestep_sinusoid(const float* t, float* out, int B, int dim, int round_bf16, hipStream_t stream);
 int x2i_launch_rope_table(const float* ids, int S, int d0, int d1, int d2, float theta, float* cosp, float* sinp, hipStream_t stream);
 int x2i_launch_gated_residual(void* X, long long x_bs, int ldx, const void* T, long long t_bs, int ldt, const float* gate, long long g_bs,

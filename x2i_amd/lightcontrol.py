@@ -103,22 +103,29 @@ class _Composed:
     def apply(self, n, h, w, base, out=None):
         """[down o conv2](n) + base on the (h/2, w/2) grid; n bf16 [B, h, w, ci]; base bf16 [B or 1, h/2, w/2, co] (everything else that
         `down` sees: bias map, shortcut / identity path)."""
-        B = n.shape[0]
-        oh, ow, ci, co = h // 2, w // 2, self.ci, self.co
-        bs = 0 if base.shape[0] == 1 else oh * ow * co
-        d = ops.conv2d_nhwc(n, self.w5, None, h, w, ci, co, 5, 5, 2, 2, res=base, res_batch_stride=bs, out=out)
-        # first output row: a 1 x 5 stride-2 convolution over input row 0, added in place (negated weights)
-        ops.conv2d_nhwc(n, self.w_top, None, 1, w, ci, co, 1, 5, 2, 0, pad_w=2, B=B, a_batch_stride=h * w * ci, out=d, c_batch_stride=oh * ow * co,
-                        res=d, res_batch_stride=oh * ow * co)
-        # first output column: a 5 x 1 stride-2 convolution over input column 0 (gathered: the conv reads contiguous NHWC), written with
-        # the output grid's row pitch so that result oy lands on pixel (oy, 0)
-        col = n[:, :, 0:1, :].contiguous()
-        ops.conv2d_nhwc(col, self.w_left, None, h, 1, ci, co, 5, 1, 2, 2, pad_w=0, out=d, c_batch_stride=oh * ow * co, ldc=ow * co, res=d,
-                        res_batch_stride=oh * ow * co, ldr=ow * co)
-        # first pixel: the (0, 0) tap was taken back by both corrections
-        ops.gemm(n, self.w_corner, None, out=d, M=1, batch=B, a_batch_stride=h * w * ci, lda=ci, c_batch_stride=oh * ow * co, ldc=co, res=d,
-                 res_batch_stride=oh * ow * co, ldr=co)
-        return d
+        return _composed_apply(self.w5, self.w_top, self.w_left, self.w_corner, self.ci, self.co, n, h, w, base, out=out)
+
+
+def _composed_apply(w5, w_top, w_left, w_corner, ci, co, n, h, w, base, out=None, w_group=0):
+    """_Composed.apply on explicit weights; with w_group > 0 they carry a leading group dimension (ControlNeXtBank: [nets, co, K]) and batch item b
+    of `n` uses group b // w_group."""
+    B = n.shape[0]
+    oh, ow = h // 2, w // 2
+    bs = 0 if base.shape[0] == 1 else oh * ow * co
+    g = dict(w_group=w_group)
+    d = ops.conv2d_nhwc(n, w5, None, h, w, ci, co, 5, 5, 2, 2, res=base, res_batch_stride=bs, out=out, **g)
+    # first output row: a 1 x 5 stride-2 convolution over input row 0, added in place (negated weights)
+    ops.conv2d_nhwc(n, w_top, None, 1, w, ci, co, 1, 5, 2, 0, pad_w=2, B=B, a_batch_stride=h * w * ci, out=d, c_batch_stride=oh * ow * co,
+                    res=d, res_batch_stride=oh * ow * co, **g)
+    # first output column: a 5 x 1 stride-2 convolution over input column 0 (gathered: the conv reads contiguous NHWC), written with
+    # the output grid's row pitch so that result oy lands on pixel (oy, 0)
+    col = n[:, :, 0:1, :].contiguous()
+    ops.conv2d_nhwc(col, w_left, None, h, 1, ci, co, 5, 1, 2, 2, pad_w=0, out=d, c_batch_stride=oh * ow * co, ldc=ow * co, res=d,
+                    res_batch_stride=oh * ow * co, ldr=ow * co, **g)
+    # first pixel: the (0, 0) tap was taken back by both corrections
+    ops.gemm(n, w_corner, None, out=d, M=1, batch=B, a_batch_stride=h * w * ci, lda=ci, c_batch_stride=oh * ow * co, ldc=co, res=d,
+             res_batch_stride=oh * ow * co, ldr=co, w_batch_stride=co * ci if w_group else 0, w_group=w_group)
+    return d
 
 
 class _Affine(nn.Module):
@@ -267,42 +274,32 @@ class ControlNeXtModel(nn.Module):
         B, h, w = prep["B"], prep["h"], prep["w"]
         if tp is None:
             tp = self.timestep_features(prep, timestep)
+        if self.compose and "d0" in prep:
+            x, h, w = _trunk(_trunk_tensors([self], h, w), prep, tp, self.groups, 0)
+            return self._final(x, h, w, add_into, add_offset, add_batch_stride, add_ld)
         te = self.time_embedding
         e1 = ops.skinny_linear(tp, te.linear_1.weight, te.linear_1.bias, act_out=ACT_SILU)
         emb = ops.skinny_linear(e1, te.linear_2.weight, te.linear_2.bias)  # [B,256] f32
-        if self.compose and "d0" in prep:
-            ca, cb = self._composed(h, w)
-            r = self.down_res[0]
-            tproj = ops.skinny_linear(emb, r.time_emb_proj.weight, r.time_emb_proj.bias, act_in=ACT_SILU)
-            n = ops.groupnorm_nhwc_from_moments(prep["h1"], prep["h1_moments"], r.norm2.weight, r.norm2.bias, self.groups[0], 1e-6, act=ACT_SILU,
-                                                pre_add=tproj)
-            x = ca.apply(n, h, w, prep["d0"])                      # = down_sample[0](conv2(n) + x0): [B, h/2, w/2, 128]
-            h, w = h // 2, w // 2
-            r = self.down_res[1]
-            n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
-            h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
-            tproj = ops.skinny_linear(emb, r.time_emb_proj.weight, r.time_emb_proj.bias, act_in=ACT_SILU)
-            n = ops.groupnorm_nhwc(h1, r.norm2.weight, r.norm2.bias, self.groups[1], 1e-6, act=ACT_SILU, pre_add=tproj)
-            t1 = ops.conv2d_nhwc(x, cb.wsc, None, h, w, 128, 256, 3, 3, 2, 1, res=cb.bias_map, res_batch_stride=0)   # down o shortcut + biases
-            x = cb.apply(n, h, w, t1)                               # = down_sample[1](conv2(n) + conv_shortcut(x)): [B, h/2, w/2, 256]
-            h, w = h // 2, w // 2
-        else:
-            x = self._resblock_tail(self.down_res[0], prep["x0"], prep["h1"], emb, self.groups[0], h, w, 128, 128, h1_moments=prep.get("h1_moments"))
-            d = self.down_sample[0].conv
-            x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 128, 128, 3, 3, 2, 1)
-            h, w = h // 2, w // 2
-            r = self.down_res[1]
-            n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
-            h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
-            x = self._resblock_tail(r, x, h1, emb, self.groups[1], h, w, 128, 256)
-            d = self.down_sample[1].conv
-            x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 256, 256, 3, 3, 2, 1)
-            h, w = h // 2, w // 2
+        x = self._resblock_tail(self.down_res[0], prep["x0"], prep["h1"], emb, self.groups[0], h, w, 128, 128, h1_moments=prep.get("h1_moments"))
+        d = self.down_sample[0].conv
+        x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 128, 128, 3, 3, 2, 1)
+        h, w = h // 2, w // 2
+        r = self.down_res[1]
+        n = ops.groupnorm_nhwc(x, r.norm1.weight, r.norm1.bias, self.groups[1], 1e-6, act=ACT_SILU)
+        h1 = ops.conv2d_nhwc(n, r.conv1.packed(), r.conv1.bias, h, w, 128, 256, 3, 3, 1, 1)
+        x = self._resblock_tail(r, x, h1, emb, self.groups[1], h, w, 128, 256)
+        d = self.down_sample[1].conv
+        x = ops.conv2d_nhwc(x, d.packed(), d.bias, h, w, 256, 256, 3, 3, 2, 1)
+        h, w = h // 2, w // 2
         m = self.mid_convs[0]
         y = ops.conv2d_nhwc(x, m[0].packed(), m[0].bias, h, w, 256, 256, 3, 3, 1, 1, act=ACT_RELU)
         y = ops.groupnorm_nhwc(y, m[2].weight, m[2].bias, 8, 1e-5)
         y = ops.conv2d_nhwc(y, m[3].packed(), m[3].bias, h, w, 256, 256, 3, 3, 1, 1)
         x = ops.groupnorm_nhwc(y, m[4].weight, m[4].bias, 8, 1e-5, post_add=x)  # mid_convs[0](x) + x (:744)
+        return self._final(x, h, w, add_into, add_offset, add_batch_stride, add_ld)
+
+    def _final(self, x, h, w, add_into=None, add_offset=0, add_batch_stride=None, add_ld=None):
+        """mid_convs[1] (the 2x2 stride-2 projection to the transformer width, :661-668,745) on the trunk's output x [B, h, w, 256]."""
         f = self.mid_convs[1]
         cout = f.weight.shape[0]
         if add_into is not None:
@@ -319,13 +316,115 @@ class ControlNeXtModel(nn.Module):
         return {"out": out.permute(0, 3, 1, 2), "scale": self.scale}  # NCHW view like the reference
 
 
+def _trunk_tensors(nets, h, w):
+    """The parameters the timestep-dependent trunk reads (composed form), as a dict: of ONE net as they are, of several nets stacked along a new
+    leading dimension ([nets, ...], contiguous) for the grouped launches of a bank."""
+    per = []
+    for net in nets:
+        ca, cb = net._composed(h, w)
+        te, r0, r1, m = net.time_embedding, net.down_res[0], net.down_res[1], net.mid_convs[0]
+        per.append(dict(
+            l1w=te.linear_1.weight, l1b=te.linear_1.bias, l2w=te.linear_2.weight, l2b=te.linear_2.bias,
+            t0w=r0.time_emb_proj.weight, t0b=r0.time_emb_proj.bias, n02w=r0.norm2.weight, n02b=r0.norm2.bias,
+            a5=ca.w5, atop=ca.w_top, aleft=ca.w_left, acorner=ca.w_corner,
+            n11w=r1.norm1.weight, n11b=r1.norm1.bias, c1w=r1.conv1.packed(), c1b=r1.conv1.bias,
+            t1w=r1.time_emb_proj.weight, t1b=r1.time_emb_proj.bias, n12w=r1.norm2.weight, n12b=r1.norm2.bias,
+            bsc=cb.wsc, bmap=cb.bias_map, b5=cb.w5, btop=cb.w_top, bleft=cb.w_left, bcorner=cb.w_corner,
+            m0w=m[0].packed(), m0b=m[0].bias, g2w=m[2].weight, g2b=m[2].bias, m3w=m[3].packed(), m3b=m[3].bias, g4w=m[4].weight, g4b=m[4].bias))
+    if len(nets) == 1:
+        return per[0]
+    return {k: torch.stack([d[k] for d in per]).contiguous() for k in per[0]}
+
+
+def _trunk(T, prep, tp, groups, wg):
+    """Timestep-dependent trunk of ControlNeXtModel.forward up to (not including) mid_convs[1], composed form (module docstring).  T:
+    _trunk_tensors of one net (wg = 0) or of a bank's nets (wg = samples per net: the batch of `prep` is (net, sample)-major and every launch
+    takes the nets' parameters as grouped weights).  prep: prepare_hint's dict; tp: timestep_features.  Returns (x [B, h, w, 256], h, w)."""
+    B, h, w = prep["B"], prep["h"], prep["w"]
+    g = dict(w_group=wg)
+
+    def lin(x, wt, b, **kw):
+        return ops.skinny_linear_grouped(x, wt, b, rows=B, **kw) if wg else ops.skinny_linear(x, wt, b, **kw)
+
+    e1 = lin(tp, T["l1w"], T["l1b"], act_out=ACT_SILU)
+    emb = lin(e1, T["l2w"], T["l2b"])                                   # [nets * B, 256] f32
+    tproj = lin(emb, T["t0w"], T["t0b"], act_in=ACT_SILU)
+    n = ops.groupnorm_nhwc_from_moments(prep["h1"], prep["h1_moments"], T["n02w"], T["n02b"], groups[0], 1e-6, act=ACT_SILU, pre_add=tproj, **g)
+    x = _composed_apply(T["a5"], T["atop"], T["aleft"], T["acorner"], 128, 128, n, h, w, prep["d0"], w_group=wg)   # = down_sample[0](conv2(n) + x0)
+    h, w = h // 2, w // 2
+    n = ops.groupnorm_nhwc(x, T["n11w"], T["n11b"], groups[1], 1e-6, act=ACT_SILU, **g)
+    h1 = ops.conv2d_nhwc(n, T["c1w"], T["c1b"], h, w, 128, 256, 3, 3, 1, 1, **g)
+    tproj = lin(emb, T["t1w"], T["t1b"], act_in=ACT_SILU)
+    n = ops.groupnorm_nhwc(h1, T["n12w"], T["n12b"], groups[1], 1e-6, act=ACT_SILU, pre_add=tproj, **g)
+    bmap = prep["bmap"] if wg else T["bmap"]                              # bank: the nets' bias maps, one copy per sample
+    t1 = ops.conv2d_nhwc(x, T["bsc"], None, h, w, 128, 256, 3, 3, 2, 1, res=bmap, res_batch_stride=(h // 2) * (w // 2) * 256 if wg else 0, **g)
+    x = _composed_apply(T["b5"], T["btop"], T["bleft"], T["bcorner"], 256, 256, n, h, w, t1, w_group=wg)       # = down_sample[1](conv2(n) + conv_shortcut(x))
+    h, w = h // 2, w // 2
+    y = ops.conv2d_nhwc(x, T["m0w"], T["m0b"], h, w, 256, 256, 3, 3, 1, 1, act=ACT_RELU, **g)
+    y = ops.groupnorm_nhwc(y, T["g2w"], T["g2b"], 8, 1e-5, **g)
+    y = ops.conv2d_nhwc(y, T["m3w"], T["m3b"], h, w, 256, 256, 3, 3, 1, 1, **g)
+    x = ops.groupnorm_nhwc(y, T["g4w"], T["g4b"], 8, 1e-5, post_add=x, **g)   # mid_convs[0](x) + x (:744)
+    return x, h, w
+
+
+class ControlNeXtBank:
+    """The control nets of a LightControl step (lightcontrol_flux.py:504-507: control_nets[i] behind double block i, every one fed the same
+    guided_hint and timestep) evaluated as ONE batch: their trunks do not depend on the transformer's state, only their last convolution adds
+    into it.  The batch is (net, sample)-major and each launch takes the nets' parameters as grouped weights (include/x2i.h:
+    x2i_gemm_args.w_group, x2i_groupnorm_*_grouped_bf16, x2i_skinny_linear_grouped): 19 x fewer launches, and the persistent convolution
+    kernels get tile lists of many rounds instead of exactly one.  A sample's results are bit-identical to ControlNeXtModel.forward_nhwc's
+    (the same kernels on the same items; tests/test_lightcontrol_gpu.py)."""
+
+    @staticmethod
+    def eligible(nets):
+        import os
+        return (len(nets) > 1 and os.environ.get("X2I_CONTROL_BANK", "1") != "0" and all(isinstance(n, ControlNeXtModel) and n.compose for n in nets)
+                and len({n.groups for n in nets}) == 1 and len({n.time_embedding.linear_1.weight.device for n in nets}) == 1)
+
+    @torch.no_grad()
+    def __init__(self, nets, guided_hint):
+        self.nets = list(nets)
+        preps = [n.prepare_hint(guided_hint) for n in self.nets]
+        p0 = preps[0]
+        self.B, h, w = p0["B"], p0["h"], p0["w"]
+        self.T = _trunk_tensors(self.nets, h, w)
+        self.prep = dict(h=h, w=w, B=self.B, round_bf16=p0["round_bf16"], x0=p0["x0"][:0],
+                         h1=torch.cat([p["h1"] for p in preps]), h1_moments=torch.cat([p["h1_moments"] for p in preps]),
+                         d0=torch.cat([p["d0"] for p in preps]), bmap=self.T["bmap"].repeat_interleave(self.B, dim=0).flatten(0, 1).contiguous())
+        self.groups = self.nets[0].groups
+
+    @torch.no_grad()
+    def trunk(self, tp):
+        """x bf16 [nets * B, H/16 * 2, W/16 * 2, 256]: net i's trunk output for sample b at row i * B + b."""
+        return _trunk(self.T, self.prep, tp, self.groups, self.B)
+
+
 def make_control_fn(control_nets, guided_hint):
     """Callable(i, timestep_x1000, X, St, S, D) used by FluxTransformer2DModel.denoise: adds control net i's output into the
-    image rows of the joint residual buffer.  The t-independent prefix of every net is computed once per hint."""
+    image rows of the joint residual buffer.  The t-independent prefix of every net is computed once per hint; the timestep-dependent trunks of
+    all nets run as one batch at the first call of a step (ControlNeXtBank; X2I_CONTROL_BANK=0: net by net, A/B)."""
     nets = list(control_nets)
-    preps = [n.prepare_hint(guided_hint) for n in nets]
+    shared = {"t": None, "tp": None, "x": None}   # the sinusoidal timestep features are the same for all nets of a step: one evaluation per step
 
-    shared = {"t": None, "tp": None}   # the sinusoidal timestep features are the same for all nets of a step: one evaluation per step
+    if ControlNeXtBank.eligible(nets):
+        bank = ControlNeXtBank(nets, guided_hint)
+        B = bank.B
+
+        def fn(i, t1000, X, St, S, D):
+            if i >= len(nets):
+                return False
+            if shared["t"] is not t1000:
+                shared["t"] = t1000
+                shared["x"] = bank.trunk(ControlNeXtModel.timestep_features(bank.prep, t1000))
+            x, h, w = shared["x"]
+            nets[i]._final(x[i * B:(i + 1) * B], h, w, add_into=X, add_offset=St * D, add_batch_stride=S * D, add_ld=D)
+            if i == len(nets) - 1:
+                shared["x"] = shared["t"] = None    # (the step's trunk outputs are not kept alive beyond their last reader)
+            return True
+
+        return fn
+
+    preps = [n.prepare_hint(guided_hint) for n in nets]
 
     def fn(i, t1000, X, St, S, D):
         if i >= len(nets):

@@ -159,7 +159,7 @@ def pad128(n):
 
 def _gemm_args(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, lda=None, c_batch_stride=0, ldc=None,
          act=ACT_NONE, gate=None, gate_batch_stride=0, res=None, res_batch_stride=0, ldr=None, out2=None, act2=ACT_NONE,
-         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None, bias2=None, bias2_batch_stride=0, w_batch_stride=0):
+         out_f32=False, a_offset=0, c_offset=0, res_offset=0, N=None, K=None, bias2=None, bias2_batch_stride=0, w_batch_stride=0, w_group=0):
     _req(A, torch.bfloat16, "A")
     _req(W, torch.bfloat16, "W")
     N = W.shape[-2] if N is None else N
@@ -193,6 +193,7 @@ def _gemm_args(A, W, bias=None, out=None, *, M=None, batch=1, a_batch_stride=0, 
     a.bias2 = bias2.data_ptr() if bias2 is not None else None
     a.bias2_batch_stride = bias2_batch_stride
     a.w_batch_stride = w_batch_stride
+    a.w_group = w_group   # > 0: grouped weights, W [groups, N, K] / bias [groups, N], w_group consecutive batch items per group (include/x2i.h)
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.act = act
     a.out_f32 = 1 if out_f32 else 0
@@ -325,6 +326,26 @@ def skinny_linear(X, W, bias=None, out=None, act_in=ACT_NONE, act_out=ACT_NONE, 
     return out
 
 
+def skinny_linear_grouped(X, W, bias=None, *, rows, out=None, act_in=ACT_NONE, act_out=ACT_NONE):
+    """`G` independent skinny linears in one launch (x2i_skinny_linear_grouped): W bf16 [G, N, K], bias bf16 [G, N]; X f32 / bf16 [G * rows, K] (group
+    g reads rows g * rows ..) or [rows, K] (one input for every group); returns f32 [G * rows, N]."""
+    lib = _lib.load()
+    _req(W, torch.bfloat16, "W")
+    G, N, K = W.shape
+    if not W.is_contiguous() or (bias is not None and not bias.is_contiguous()) or not X.is_contiguous():
+        raise _lib.X2IError("skinny_linear_grouped: X, W and bias must be contiguous")
+    if X.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.X2IError("skinny_linear_grouped: X must be f32 or bf16")
+    if X.shape[0] not in (rows, G * rows) or X.shape[1] != K:
+        raise _lib.X2IError("skinny_linear_grouped: X must be [rows, K] or [G * rows, K]")
+    x_gs = rows * K if X.shape[0] == G * rows and G > 1 else 0
+    if out is None:
+        out = torch.empty((G * rows, N), device=X.device, dtype=torch.float32)
+    check(lib.x2i_skinny_linear_grouped(_p(X), 1 if X.dtype == torch.bfloat16 else 0, x_gs, _p(W), _p(bias), _p(out), out.stride(0), G, rows, N, K,
+                                        act_in, act_out, 0, _stream()), "skinny_linear_grouped")
+    return out
+
+
 def timestep_sinusoid(t, dim, round_bf16=False):
     lib = _lib.load()
     _req(t, torch.float32, "t")
@@ -429,8 +450,10 @@ from ._lib import ACT_RELU, ConvDesc  # noqa: E402
 
 def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=None, act=ACT_NONE, bias2=None, res=None,
                 c_offset=0, c_batch_stride=None, ldc=None, res_offset=0, res_batch_stride=None, ldr=None, up=False, pad_w=None, B=None,
-                a_batch_stride=None, a_offset=0, out_w=None, out_h=None, out_row_pitch=0, moments=None, moments_accumulate=False):
+                a_batch_stride=None, a_offset=0, out_w=None, out_h=None, out_row_pitch=0, moments=None, moments_accumulate=False, w_group=0):
     """x: bf16 NHWC [B,H,W,Cin]; w_packed: bf16 [Cout, KH*KW*Cin] (ky,kx,ci order).  Returns NHWC [B,OH,OW,Cout].
+    w_group > 0: GROUPED weights -- w_packed [groups, Cout, KH*KW*Cin], bias [groups, Cout], batch item b uses group b // w_group (the models of a
+    ControlNeXt bank in one launch; include/x2i.h: x2i_gemm_args.w_group).
     pad_w: padding along W when it differs from `pad` (along H).  B / a_batch_stride / a_offset: the input is a window of `H` rows of a
     larger NHWC tensor (elements between two images / in front of the window).  up: True / 1 = nearest x2 upsampling in front of the conv,
     2 = along H only; out_w / out_h: number of output columns / rows when the right-hand / bottom padding differs from pad_w / pad;
@@ -468,7 +491,8 @@ def conv2d_nhwc(x, w_packed, bias, H, W, Cin, Cout, KH, KW, stride, pad, out=Non
     a.M, a.N, a.K, a.batch = OH * OW, Cout, KH * KW * Cin, B
     a.act = act
     a.out_f32 = 0
-    a.w_batch_stride = 0
+    a.w_batch_stride = Cout * KH * KW * Cin if w_group else 0
+    a.w_group = w_group
     d = ConvDesc(H, W, Cin, KH, KW, stride, pad, up, 0 if pad_w is None else pad_w + 1, 0 if out_w is None else out_w,
                  0 if out_h is None else out_h, out_row_pitch)
     if moments is not None:
@@ -509,8 +533,9 @@ def conv_stem(x_nhwc, w, bias, Cout):
 _gn_scratch = {}
 
 
-def groupnorm_nhwc(x, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add=None, out=None):
-    """GroupNorm on NHWC bf16 [B, ..., C] with fused pre-add (f32 [B,C]), activation and post-add (bf16 like x)."""
+def groupnorm_nhwc(x, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add=None, out=None, w_group=0):
+    """GroupNorm on NHWC bf16 [B, ..., C] with fused pre-add (f32 [B,C]), activation and post-add (bf16 like x).
+    w_group > 0: weight / bias are [groups, C] and item b uses row b // w_group (x2i_groupnorm_nhwc_grouped_bf16)."""
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")
     B, Cc = x.shape[0], x.shape[-1]
@@ -520,8 +545,8 @@ def groupnorm_nhwc(x, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add
     key = (x.device, n)
     if key not in _gn_scratch:
         _gn_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
-    check(lib.x2i_groupnorm_nhwc_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), eps, act, _p(pre_add), _p(post_add),
-                                      _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc")
+    check(lib.x2i_groupnorm_nhwc_grouped_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), w_group, eps, act, _p(pre_add), _p(post_add),
+                                              _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc")
     return out
 
 
@@ -538,7 +563,7 @@ def groupnorm_moments(x):
     return mom
 
 
-def groupnorm_nhwc_from_moments(x, moments, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add=None, out=None):
+def groupnorm_nhwc_from_moments(x, moments, weight, bias, G, eps, act=ACT_NONE, pre_add=None, post_add=None, out=None, w_group=0):
     """groupnorm_nhwc(x, ..., pre_add=...) with the statistics derived from groupnorm_moments(x) instead of a pass over x."""
     lib = _lib.load()
     _req(x, torch.bfloat16, "x")
@@ -550,8 +575,8 @@ def groupnorm_nhwc_from_moments(x, moments, weight, bias, G, eps, act=ACT_NONE, 
     key = (x.device, n)
     if key not in _gn_scratch:
         _gn_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
-    check(lib.x2i_groupnorm_nhwc_from_moments_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), eps, act, _p(moments), _p(pre_add),
-                                                   _p(post_add), _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc_from_moments")
+    check(lib.x2i_groupnorm_nhwc_from_moments_grouped_bf16(_p(x), _p(out), B, HW, Cc, G, _p(weight), _p(bias), w_group, eps, act, _p(moments),
+                                                           _p(pre_add), _p(post_add), _p(_gn_scratch[key]), _stream()), "groupnorm_nhwc_from_moments")
     return out
 
 
