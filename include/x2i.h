@@ -69,6 +69,7 @@ const char* x2i_last_error(void);
  * "attn_w16" (1: x2i_attention_prefers_vt_perm may answer 1 -- the sampling path then uses the 16 x 16 x 32 attention kernel; 0: never; 2: at any size -- tests),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
+ * "attn_bwd_pipe" (1: the dK / dV pass runs software-pipelined -- element-wise section under the MFMAs; 0: phase after phase; bit-identical),
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
  * same values up to the summation order of the row statistics),
  * "conv256" (1), "conv_w4" (1: convolutions with >= 256 output channels take the persistent four-wave kernel with the hand-scheduled K-loop,

@@ -479,6 +479,15 @@ def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     finally:
         _lib.set_option("attn_bwd_dq64", old)
     assert torch.equal(dQ3, dQ2) and torch.equal(dK3, dK2) and torch.equal(dV3, dV2)
+    # the software-pipelined dK / dV pass (default) against the phase-after-phase kernel: the same MFMA order per accumulator and the same
+    # element-wise operations, bit for bit
+    old = _lib.set_option("attn_bwd_pipe", 0)
+    try:
+        dQ4, dK4, dV4 = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
+        ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ4, dK4, dV4, B, H, S, Spad, scale, have_lse=True)
+    finally:
+        _lib.set_option("attn_bwd_pipe", old)
+    assert torch.equal(dQ4, dQ2) and torch.equal(dK4, dK2) and torch.equal(dV4, dV2)
 
 
 def test_full_width_distillation_gradient_vs_oracle_autograd():

@@ -70,6 +70,15 @@ def backward_bench():
     t = timeit(lambda: ops.attention_bwd(Q, K_, V, QT, KT, dOh, dOT, L, Dv, dQ, dK, dV, B, H, S, Spad, 1 / math.sqrt(128)))
     fl = (1 + 3 + 4) * 2 * B * H * S * S * 128
     print(f"attention backward (3 passes, 8 MFMA groups) B={B}: {t*1e3:8.3f} ms  {fl/t/1e12:8.1f} TFLOP/s")
+    # without the statistics pass (the training step hands over the forward kernel's statistics), per option set; passes one after the other
+    # (attn_bwd_overlap = 0) so that each pass's own time shows
+    fl7 = (3 + 4) * 2 * B * H * S * S * 128
+    for opts in ({}, {"attn_bwd_pipe": 0}, {"attn_bwd_overlap": 0}, {"attn_bwd_overlap": 0, "attn_bwd_pipe": 0}, {}):
+        old = {k: _lib.set_option(k, v) for k, v in opts.items()}
+        t = timeit(lambda: ops.attention_bwd(Q, K_, V, QT, KT, dOh, dOT, L, Dv, dQ, dK, dV, B, H, S, Spad, 1 / math.sqrt(128), have_lse=True))
+        for k, v in old.items():
+            _lib.set_option(k, v)
+        print(f"attention backward (dQ + dK/dV passes, 7 MFMA groups) B={B} {opts}: {t*1e3:8.3f} ms  {fl7/t/1e12:8.1f} TFLOP/s")
 
 
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "bwd":

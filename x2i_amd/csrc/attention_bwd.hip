@@ -515,6 +515,203 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __r
   for (int qb = 0; qb < 2; ++qb) store_rows(dQ + hoff + (long long)r0[qb] * 128, oacc[qb], scale, G.hi, r0[qb] < S);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// dK / dV pass, SOFTWARE-PIPELINED over the two 32-row halves u of a streamed tile (round 6).  attn_bwd_kernel<1> runs a tile as
+// [S, dP: 32 MFMAs] [element-wise section: ~330 VALU instructions with the matrix pipe idle] [dV, dK: 32 MFMAs]; with one wave per SIMD nothing
+// else fills the middle, the per-row statistics come as 16 global loads per tile that sit BEHIND the next tile's DMA in the vmcnt queue (so
+// their wait is a wait for the whole DMA), and the 16 DMA pieces issue in one burst.  Here a tile is 64 slots, one MFMA each, in four phases
+//     A: S(u0), dP(u0)                    + the next tile's 17 DMA pieces, one per slot
+//     B: S(u1), dP(u1)                    + the element-wise values of half u0, one per slot
+//     C: dV(u0), dK(u0)                   + the element-wise values of half u1
+//     D: dV(u1), dK(u1)
+// with every slot closed by a scheduling fence, so the order written here is the order issued: the fragment of slot m + LEAD is requested in
+// slot m (a ring of eight), L2 / D rows of the tile come through LDS with the tile (one 256-byte DMA piece each, read back as broadcasts).
+// Same MFMA order per accumulator and the same element-wise operations as attn_bwd_kernel<1>: bit-identical results (tested).
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (N > 0) {
+    sfor<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff_bytes, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff_bytes, 0, 0, 0);
+}
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int KV_STAGE = 4 * TILE + 512;   // Q rows | dO rows | dO^T | Q^T | L2[64] | D[64]
+constexpr int KV_LEAD = 4;
+
+struct KvState {
+  f32x16_t sacc[2], dacc[2];
+  bf16x8_t fr[8];
+  u32x4_t pf[2][2], dsf[2][2];          // P^T / dS^T fragments [u][kt] as packed bf16 pairs
+  f32x4_t Lr[2][4], Dr[2][4];           // statistics of the lane's 16 rows per half: [u][a * 2 + half of eight]
+};
+
+template <int M>
+__device__ __forceinline__ bf16x8_t kv_frag(const char* cur, const Geo& G) {
+  constexpr int ph = M >> 4, i = M & 15, u = ph & 1;
+  if constexpr (ph < 2) {
+    constexpr int ds = i >> 1, which = i & 1;
+    return row_frag(cur + which * TILE, G, ds >> 1, u + 2 * (ds & 1));
+  } else {
+    constexpr int kt = i >> 3, db = (i >> 1) & 3, which = i & 1;
+    return col_frag(cur + (2 + which) * TILE, G, u * 2 + kt, db);
+  }
+}
+
+template <int U, int R>
+__device__ __forceinline__ void kv_ew(KvState& st, float scale_log2) {
+  const float L = st.Lr[U][R >> 2][R & 3], D = st.Dr[U][R >> 2][R & 3];
+  const float p = __builtin_amdgcn_exp2f(st.sacc[U][R] * scale_log2 - L);
+  const float d = p * (st.dacc[U][R] - D);
+  st.sacc[U][R] = p;   // (the score registers are free: the values wait there for their pair partner)
+  st.dacc[U][R] = d;
+  if constexpr ((R & 1) == 1) {
+    st.pf[U][R >> 3][(R & 7) >> 1] = pack_bf16x2(st.sacc[U][R - 1], p);
+    st.dsf[U][R >> 3][(R & 7) >> 1] = pack_bf16x2(st.dacc[U][R - 1], d);
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, const Rsrc4& R,
+                                        __amdgpu_buffer_rsrc_t rL, __amdgpu_buffer_rsrc_t rD, const int (&row_src)[4], const int (&col_src)[4],
+                                        int wave, int lane, const Geo& G, const bf16x8_t (&pa)[8], const bf16x8_t (&pb)[8], float scale_log2,
+                                        f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4], KvState& st) {
+  constexpr int ph = M >> 4, i = M & 15, u = ph & 1;
+  if constexpr (M + KV_LEAD < 64) st.fr[(M + KV_LEAD) & 7] = kv_frag<M + KV_LEAD>(cur, G);
+  if constexpr (ph == 0) {   // the next tile: pieces j = i >> 2 of tile i & 3 (unconditional: behind the last tile they are never read)
+    constexpr int j = i >> 2, tl = i & 3;
+    char* dst = nxt + tl * TILE + (j * 256 + wave * 64) * 16;
+    if constexpr (tl == 0) dma16(R.a, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
+    if constexpr (tl == 1) dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
+    if constexpr (tl == 2) dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
+    if constexpr (tl == 3) dma16(R.d, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
+    if constexpr (i == 15) {
+      if (wave == 0) dma4(rL, (uint32_t)((s_next + lane) * 4), nxt + 4 * TILE);
+      if (wave == 1) dma4(rD, (uint32_t)((s_next + lane) * 4), nxt + 4 * TILE + 256);
+    }
+    // statistics of half u0 (needed from slot 18 on), half u1 in phase B
+    if constexpr (i >= 8) {
+      constexpr int q = i - 8, a = (q >> 1) & 1, h8 = q & 1;
+      const char* base = cur + 4 * TILE + (q >> 2) * 256 + (16 * a + 8 * G.hi) * 4 + h8 * 16;
+      if constexpr (q < 4) st.Lr[0][a * 2 + h8] = *(const f32x4_t*)base;
+      else st.Dr[0][a * 2 + h8] = *(const f32x4_t*)base;
+    }
+  }
+  if constexpr (ph == 1 && i >= 8) {
+    constexpr int q = i - 8, a = (q >> 1) & 1, h8 = q & 1;
+    const char* base = cur + 4 * TILE + (q >> 2) * 256 + (32 + 16 * a + 8 * G.hi) * 4 + h8 * 16;
+    if constexpr (q < 4) st.Lr[1][a * 2 + h8] = *(const f32x4_t*)base;
+    else st.Dr[1][a * 2 + h8] = *(const f32x4_t*)base;
+  }
+  if constexpr (ph < 2) {
+    constexpr int ds = i >> 1, which = i & 1;
+    if constexpr (which == 0) st.sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], pa[ds], st.sacc[u], 0, 0, 0);
+    else st.dacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], pb[ds], st.dacc[u], 0, 0, 0);
+  } else {
+    constexpr int kt = i >> 3, db = (i >> 1) & 3, which = i & 1;
+    if constexpr (which == 0) oacc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], __builtin_bit_cast(bf16x8_t, st.pf[u][kt]), oacc0[db], 0, 0, 0);
+    else oacc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], __builtin_bit_cast(bf16x8_t, st.dsf[u][kt]), oacc1[db], 0, 0, 0);
+  }
+  // element-wise values: half u0 in slots 18 .. 33, half u1 in slots 34 .. 49 (two slots behind the MFMAs that finish their scores)
+  if constexpr (M >= 18 && M < 34) kv_ew<0, M - 18>(st, scale_log2);
+  if constexpr (M >= 34 && M < 50) kv_ew<1, M - 34>(st, scale_log2);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void dkdv_tile(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, const Rsrc4& R, __amdgpu_buffer_rsrc_t rL,
+                                          __amdgpu_buffer_rsrc_t rD, const int (&row_src)[4], const int (&col_src)[4], int wave, int lane,
+                                          const Geo& G, const bf16x8_t (&pa)[8], const bf16x8_t (&pb)[8], float scale_log2,
+                                          f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4]) {
+  KvState st;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st.sacc[u][r] = 0.f; st.dacc[u][r] = 0.f; }
+  sfor<KV_LEAD>([&](auto mc) { st.fr[decltype(mc)::value & 7] = kv_frag<decltype(mc)::value>(cur, G); });
+  __builtin_amdgcn_sched_barrier(0);
+  sfor<64>([&](auto mc) {
+    kv_slot<decltype(mc)::value>(cur, nxt, s_next, R, rL, rD, row_src, col_src, wave, lane, G, pa, pb, scale_log2, oacc0, oacc1, st);
+  });
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ Q,
+                                                              const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
+                                                              const bf16_t* __restrict__ QT, const float* __restrict__ L2, const float* __restrict__ Dv,
+                                                              bf16_t* __restrict__ dV, bf16_t* __restrict__ dK, int H, int S, int Spad, float scale,
+                                                              float scale_log2, int nbatch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Geo G;
+  G.hi = lane >> 5; G.li = lane & 31;
+  {
+    const int kvm = (G.li & 0x13) | ((G.li & 4) << 1) | ((G.li & 8) >> 1);
+    G.k_row_off = kvm * 256; G.k_swz = kvm & 15; G.v_row_off = G.li * 128; G.v_swz = (G.li >> 1) & 7;
+  }
+  const int nblk = Spad / 128;
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int blk = bid % nblk, h = (bid / nblk) % H, b = bid / (nblk * H);
+  const long long bh = (long long)b * H + h;
+  const long long hoff = bh * Spad * 128;
+  const int r0 = blk * 128 + wave * 32 + G.li;   // this lane's persistent key
+  bf16x8_t pa[8], pb[8];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) {
+    pa[ds] = *(const bf16x8_t*)(K + hoff + (long long)r0 * 128 + ds * 16 + G.hi * 8);
+    pb[ds] = *(const bf16x8_t*)(V + hoff + (long long)r0 * 128 + ds * 16 + G.hi * 8);
+  }
+  int row_src[4], col_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + tid;
+    { const int row = p >> 4, c = p & 15; row_src[j] = row * 128 + ((c ^ (row & 15)) << 3); }
+    { const int row = p >> 3, c = p & 7; col_src[j] = row * Spad + ((c ^ ((row >> 1) & 7)) << 3); }
+  }
+  Rsrc4 R;
+  const uint32_t bytes = (uint32_t)Spad * 256u;
+  R.a = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + hoff), 0, bytes, 0x00020000);
+  R.b = __builtin_amdgcn_make_buffer_rsrc((void*)(dO + hoff), 0, bytes, 0x00020000);
+  R.c = __builtin_amdgcn_make_buffer_rsrc((void*)(dOT + hoff), 0, bytes, 0x00020000);
+  R.d = __builtin_amdgcn_make_buffer_rsrc((void*)(QT + hoff), 0, bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void*)(L2 + bh * Spad), 0, (uint32_t)Spad * 4u, 0x00020000);
+  __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(Dv + bh * Spad), 0, (uint32_t)Spad * 4u, 0x00020000);
+  f32x16_t oacc0[4], oacc1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc0[i][r] = 0.f; oacc1[i][r] = 0.f; }
+  const int nt = (S + KVB - 1) / KVB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {   // tile 0
+    char* dst = smem + (j * 256 + wave * 64) * 16;
+    dma16(R.a, (uint32_t)(row_src[j] * 2), dst);
+    dma16(R.b, (uint32_t)(row_src[j] * 2), dst + TILE);
+    dma16(R.c, (uint32_t)(col_src[j] * 2), dst + 2 * TILE);
+    dma16(R.d, (uint32_t)(col_src[j] * 2), dst + 3 * TILE);
+  }
+  if (wave == 0) dma4(rL, (uint32_t)(lane * 4), smem + 4 * TILE);
+  if (wave == 1) dma4(rD, (uint32_t)(lane * 4), smem + 4 * TILE + 256);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    dkdv_tile(smem + buf * KV_STAGE, smem + (buf ^ 1) * KV_STAGE, (t + 1) * KVB, R, rL, rD, row_src, col_src, wave, lane, G, pa, pb, scale_log2, oacc0,
+              oacc1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const bool live = r0 < S;
+  store_rows(dV + hoff + (long long)r0 * 128, oacc0, 1.f, G.hi, live);
+  store_rows(dK + hoff + (long long)r0 * 128, oacc1, scale, G.hi, live);
+}
+
 // D[b][h][s] = sum_d dO[b][s][h*128 + d] * O[b][s][h*128 + d] for s < S, 0 for the padding rows; 16 lanes x 8 elements per (token, head)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, long long do_bs, int lddo, const bf16_t* __restrict__ O,
                                                             long long o_bs, int ldo, float* __restrict__ Dv, int H, int S, int Spad) {
@@ -574,7 +771,13 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        (const bf16_t*)KT, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)dQ, (bf16_t*)nullptr, H, S, Spad, scale, scale_log2, B);
   }
   if (overlap) (void)hipEventRecord(ev_join, side);
-  {
+  if (x2i_options().attn_bwd_pipe) {   // dK / dV: software-pipelined (attn_bwd_dkdv_kernel); option 0 = attn_bwd_kernel<1> (A/B, bit-identical)
+    const int shm = 2 * KV_STAGE;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dkdv_kernel, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), shm, stream, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Q, (const bf16_t*)dOh,
+                       (const bf16_t*)dOT, (const bf16_t*)QT, (const float*)L2, Dv, (bf16_t*)dV, (bf16_t*)dK, H, S, Spad, scale, scale_log2, B);
+  } else {
     const int shm = 2 * 4 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<1>, shm);
     if (rc) return rc;

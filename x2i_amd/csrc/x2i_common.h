@@ -30,6 +30,8 @@ struct X2IOptions {
   int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
   int attn_bwd_overlap;   // 1 = the dQ pass runs on a side stream beside the dK / dV pass (their partly filled last rounds fill each other)
   int attn_bwd_dq64;      // 1 = the dQ pass of the attention backward keeps 64 query rows per wave (0: 32, A/B; bit-identical)
+  int attn_bwd_pipe;      // 1 = the dK / dV pass runs the software-pipelined kernel (attn_bwd_dkdv_kernel: element-wise section under the MFMAs; default);
+                          // 0 = attn_bwd_kernel<1> (A/B; bit-identical)                                          X2I_ATTN_BWD_PIPE
   int train_rows_wg;      // 1 = ln_mod_bwd / gate_bwd of the training step run a workgroup per row group, a thread per eight columns (default);
                           // 0 = the wave-per-row forms (A/B; same values up to the summation order of the row statistics)    X2I_TRAIN_ROWS_WG
   int gemm_pair;          // 1 = x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 issue ONE grouped persistent launch when they can (0: always two launches)
