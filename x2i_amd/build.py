@@ -22,6 +22,9 @@ ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm_r2.hip", "gemm256w.hip", "ge
 ABLATE_ONLY_SRCS = ("gemm_r2.hip", "attention16.hip")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=fast"]
+# per-file extras.  attention_bwd.hip: the SLP vectoriser pairs the element-wise values of two pipeline slots into v_pk_add_f32 / v_pk_mul_f32, which
+# moves the even value's work into the odd slot and costs more beside an MFMA than two plain instructions (MI355X_MICROARCH.md, filler price list)
+FILE_FLAGS = {"attention_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -38,9 +41,9 @@ def _newest_header():
 
 def _compile(src, force, ablate=False):
     obj = os.path.join(OBJ, os.path.basename(src) + (".abl.o" if ablate else ".o"))
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header()):
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header(), os.path.getmtime(os.path.abspath(__file__))):
         return obj, False
-    cmd = [_hipcc()] + FLAGS + (["-DX2I_ABLATION"] if ablate else []) + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + (["-DX2I_ABLATION"] if ablate else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

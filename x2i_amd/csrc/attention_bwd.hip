@@ -712,6 +712,186 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __r
   store_rows(dK + hoff + (long long)r0 * 128, oacc1, scale, G.hi, live);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// dQ pass, software-pipelined the same way (64 persistent query rows per wave = two 32-row blocks qb, so a streamed fragment feeds two
+// MFMAs): a tile is 96 one-MFMA slots
+//     A (0..31):  S(u0), dP(u0) for qb 0, 1         + the next tile's 12 DMA pieces
+//     B (32..63): S(u1), dP(u1)                     + the 32 element-wise values of half u0 (slots 34..65)
+//     C (64..95): dQ^T += K^T dS^T, groups (u0,kt0) (u0,kt1) (u1,kt0) (u1,kt1)   + the values of half u1: rows r < 8 of both blocks by slot 79,
+//                                                     rows r >= 8 by slot 87 (two values per slot there: the groups that need them follow)
+// Same MFMA order per accumulator and element-wise operations as attn_bwd_dq64_kernel: bit-identical (tested).  MASKED: the last tile of a
+// sequence with S % 64 != 0 (keys at or behind S get p = 0); every other tile runs without the compare / select per value.
+struct DqState {
+  f32x16_t sacc[2][2], dacc[2][2];   // [qb][u]
+  bf16x8_t fr[8];
+  u32x4_t dsf[2][2][2];              // dS^T fragments [qb][u][kt]
+};
+
+template <int F>   // fragment F (0..47) of a tile: one per two slots
+__device__ __forceinline__ bf16x8_t dq_frag(const char* cur, const Geo& G) {
+  if constexpr (F < 32) {
+    constexpr int u = F >> 4, i = F & 15, ds = i >> 1, which = i & 1;   // which: 0 = K rows (S), 1 = V rows (dP)
+    return row_frag(cur + which * TILE, G, ds >> 1, u + 2 * (ds & 1));
+  } else {
+    constexpr int i = F - 32, g = i >> 2, db = i & 3;
+    return col_frag(cur + 2 * TILE, G, g, db);
+  }
+}
+
+template <int U, int J, bool MASKED>   // value J (0..31) of half U: rows r < 8 of block 0, of block 1, then rows r >= 8 of block 0, of block 1
+__device__ __forceinline__ void dq_ew(DqState& st, float scale_log2, const float (&myL)[2], const float (&myD)[2], int kbase, int S) {
+  constexpr int h = J >> 4, qb = (J >> 3) & 1, R = h * 8 + (J & 7);
+  float p = __builtin_amdgcn_exp2f(st.sacc[qb][U][R] * scale_log2 - myL[qb]);
+  if constexpr (MASKED) {
+    const int key = kbase + U * 32 + 16 * (R >> 3) + (R & 7);   // kbase = s0 + 8 hi
+    p = key < S ? p : 0.f;
+  }
+  const float d = p * (st.dacc[qb][U][R] - myD[qb]);
+  st.dacc[qb][U][R] = d;
+  if constexpr ((R & 1) == 1) st.dsf[qb][U][R >> 3][(R & 7) >> 1] = pack_bf16x2(st.dacc[qb][U][R - 1], d);
+}
+
+template <int M, bool MASKED>
+__device__ __forceinline__ void dq_slot(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, const Rsrc4& R, const int (&row_src)[4],
+                                        const int (&col_src)[4], int wave, const Geo& G, const bf16x8_t (&pa)[2][8], const bf16x8_t (&pb)[2][8],
+                                        const float (&myL)[2], const float (&myD)[2], int kbase, int S, float scale_log2, f32x16_t (&oacc)[2][4],
+                                        DqState& st) {
+  constexpr int F = M >> 1, qb = M & 1;
+  if constexpr ((M & 1) == 0 && F + 3 < 48) st.fr[(F + 3) & 7] = dq_frag<F + 3>(cur, G);
+  if constexpr (M < 24 && (M & 1) == 0) {   // the next tile: piece j = (M / 2) >> 2 ... of tile (M / 2) % 3
+    constexpr int pc = M >> 1, j = pc / 3, tl = pc % 3;
+    char* dst = nxt + tl * TILE + (j * 256 + wave * 64) * 16;
+    if constexpr (tl == 0) dma16(R.a, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
+    if constexpr (tl == 1) dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
+    if constexpr (tl == 2) dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
+  }
+  if constexpr (M < 64) {
+    constexpr int u = F >> 4, i = F & 15, ds = i >> 1, which = i & 1;
+    if constexpr (which == 0) st.sacc[qb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[F & 7], pa[qb][ds], st.sacc[qb][u], 0, 0, 0);
+    else st.dacc[qb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[F & 7], pb[qb][ds], st.dacc[qb][u], 0, 0, 0);
+  } else {
+    constexpr int i = F - 32, g = i >> 2, db = i & 3;
+    oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[F & 7], __builtin_bit_cast(bf16x8_t, st.dsf[qb][g >> 1][g & 1]), oacc[qb][db], 0, 0, 0);
+  }
+  if constexpr (M >= 34 && M < 66) dq_ew<0, M - 34, MASKED>(st, scale_log2, myL, myD, kbase, S);
+  // half u1: values 0..15 in slots 66..79 (the first two slots carry two), values 16..31 two per slot in slots 80..87
+  if constexpr (M == 66 || M == 67) {
+    dq_ew<1, 2 * (M - 66), MASKED>(st, scale_log2, myL, myD, kbase, S);
+    dq_ew<1, 2 * (M - 66) + 1, MASKED>(st, scale_log2, myL, myD, kbase, S);
+  }
+  if constexpr (M >= 68 && M < 80) dq_ew<1, M - 64, MASKED>(st, scale_log2, myL, myD, kbase, S);
+  if constexpr (M >= 80 && M < 88) {
+    dq_ew<1, 16 + 2 * (M - 80), MASKED>(st, scale_log2, myL, myD, kbase, S);
+    dq_ew<1, 17 + 2 * (M - 80), MASKED>(st, scale_log2, myL, myD, kbase, S);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void dq_tile(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, int s0, const Rsrc4& R, const int (&row_src)[4],
+                                        const int (&col_src)[4], int wave, const Geo& G, const bf16x8_t (&pa)[2][8], const bf16x8_t (&pb)[2][8],
+                                        const float (&myL)[2], const float (&myD)[2], int S, float scale_log2, f32x16_t (&oacc)[2][4]) {
+  DqState st;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st.sacc[qb][u][r] = 0.f; st.dacc[qb][u][r] = 0.f; }
+  sfor<3>([&](auto fc) { st.fr[decltype(fc)::value & 7] = dq_frag<decltype(fc)::value>(cur, G); });
+  __builtin_amdgcn_sched_barrier(0);
+  const int kbase = s0 + 8 * G.hi;
+  sfor<96>([&](auto mc) {
+    dq_slot<decltype(mc)::value, MASKED>(cur, nxt, s_next, R, row_src, col_src, wave, G, pa, pb, myL, myD, kbase, S, scale_log2, oacc, st);
+  });
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT, const float* __restrict__ L2,
+                                                            const float* __restrict__ Dv, bf16_t* __restrict__ dQ, int H, int S, int Spad,
+                                                            float scale, float scale_log2, int nbatch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 3 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Geo G;
+  G.hi = lane >> 5; G.li = lane & 31;
+  {
+    const int kvm = (G.li & 0x13) | ((G.li & 4) << 1) | ((G.li & 8) >> 1);
+    G.k_row_off = kvm * 256; G.k_swz = kvm & 15; G.v_row_off = G.li * 128; G.v_swz = (G.li >> 1) & 7;
+  }
+  const int nblk = (Spad + 255) / 256;
+  int bid = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int blk = bid % nblk, h = (bid / nblk) % H, b = bid / (nblk * H);
+  const long long bh = (long long)b * H + h;
+  const long long hoff = bh * Spad * 128;
+  bf16x8_t pa[2][8], pb[2][8];
+  float myL[2], myD[2];
+  int r0[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    r0[qb] = blk * 256 + wave * 64 + qb * 32 + G.li;
+    const int rr = min(r0[qb], Spad - 1);
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      pa[qb][ds] = *(const bf16x8_t*)(Q + hoff + (long long)rr * 128 + ds * 16 + G.hi * 8);
+      pb[qb][ds] = *(const bf16x8_t*)(dO + hoff + (long long)rr * 128 + ds * 16 + G.hi * 8);
+    }
+    myL[qb] = L2[bh * Spad + rr];
+    myD[qb] = Dv[bh * Spad + rr];
+  }
+  int row_src[4], col_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = j * 256 + tid;
+    { const int row = p >> 4, c = p & 15; row_src[j] = row * 128 + ((c ^ (row & 15)) << 3); }
+    { const int row = p >> 3, c = p & 7; col_src[j] = row * Spad + ((c ^ ((row >> 1) & 7)) << 3); }
+  }
+  Rsrc4 R;
+  {
+    const uint32_t bytes = (uint32_t)Spad * 256u;
+    R.a = __builtin_amdgcn_make_buffer_rsrc((void*)(K + hoff), 0, bytes, 0x00020000);
+    R.b = __builtin_amdgcn_make_buffer_rsrc((void*)(V + hoff), 0, bytes, 0x00020000);
+    R.c = __builtin_amdgcn_make_buffer_rsrc((void*)(KT + hoff), 0, bytes, 0x00020000);
+    R.d = R.c;
+  }
+  f32x16_t oacc[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+  const int nt = (S + KVB - 1) / KVB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    char* dst = smem + (j * 256 + wave * 64) * 16;
+    dma16(R.a, (uint32_t)(row_src[j] * 2), dst);
+    dma16(R.b, (uint32_t)(row_src[j] * 2), dst + TILE);
+    dma16(R.c, (uint32_t)(col_src[j] * 2), dst + 2 * TILE);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int nfull = (S & 63) ? nt - 1 : nt;
+  for (int t = 0; t < nfull; ++t) {
+    const int buf = t & 1;
+    dq_tile<false>(smem + buf * STAGE, smem + (buf ^ 1) * STAGE, (t + 1) * KVB, t * KVB, R, row_src, col_src, wave, G, pa, pb, myL, myD, S, scale_log2, oacc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (nfull < nt) {
+    const int t = nt - 1, buf = t & 1;
+    dq_tile<true>(smem + buf * STAGE, smem + (buf ^ 1) * STAGE, (t + 1) * KVB, t * KVB, R, row_src, col_src, wave, G, pa, pb, myL, myD, S, scale_log2, oacc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) store_rows(dQ + hoff + (long long)r0[qb] * 128, oacc[qb], scale, G.hi, r0[qb] < S);
+}
+
 // D[b][h][s] = sum_d dO[b][s][h*128 + d] * O[b][s][h*128 + d] for s < S, 0 for the padding rows; 16 lanes x 8 elements per (token, head)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, long long do_bs, int lddo, const bf16_t* __restrict__ O,
                                                             long long o_bs, int ldo, float* __restrict__ Dv, int H, int S, int Spad) {
@@ -757,7 +937,13 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
   const bool overlap = x2i_options().attn_bwd_overlap && x2i_side_stream(stream, &side, &ev_fork, &ev_join) &&
                        hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
   hipStream_t qs = overlap ? side : stream;
-  if (x2i_options().attn_bwd_dq64) {  // dQ: 64 query rows per wave (attn_bwd_dq64_kernel); option 0 = the 32-row form (A/B, bit-identical)
+  if (x2i_options().attn_bwd_dq64 && x2i_options().attn_bwd_pipe) {   // dQ: 64 query rows per wave, software-pipelined (attn_bwd_dq_kernel)
+    const int shm = 2 * 3 * TILE;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dq_kernel, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((Spad + 255) / 256) * H * B), dim3(256), shm, qs, (const bf16_t*)Q, (const bf16_t*)dOh,
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)KT, (const float*)L2, Dv, (bf16_t*)dQ, H, S, Spad, scale, scale_log2, B);
+  } else if (x2i_options().attn_bwd_dq64) {  // phase after phase (attn_bwd_dq64_kernel); option attn_bwd_dq64 = 0: the 32-row form (A/B, bit-identical)
     const int shm = 2 * 3 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dq64_kernel, shm);
     if (rc) return rc;
