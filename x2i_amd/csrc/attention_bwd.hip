@@ -539,7 +539,22 @@ __device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff_
 }
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-constexpr int KV_STAGE = 4 * TILE + 512;   // Q rows | dO rows | dO^T | Q^T | L2[64] | D[64]
+// MFMAs of the pipelined passes as asm statements with the register FILE of every operand fixed: the persistent operands (K / V or Q / dO rows)
+// and the output accumulators in the accumulator file, the scores in VGPRs (the element-wise section reads them without v_accvgpr_read).  Left to
+// itself hipcc keeps three of the eight output accumulators in VGPRs and copies them into the accumulator file and back around their MFMAs
+// (48 + 48 moves per tile).  The compiler's hazard recogniser does not see into these statements: the slot order keeps every VALU read of a score
+// two MFMAs behind the MFMA that wrote it (>= 16 quad-cycles; 11 required), and an accumulator's consecutive MFMAs are exact SrcC = vDst chains.
+__device__ __forceinline__ void mfma_s0(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {   // scores, first MFMA: C = 0
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_s(f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_o(f32x16_t& acc, const bf16x8_t& a, const u32x4_t& b) {     // output accumulators
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+constexpr int KV_STAGE = 4 * TILE + 1024;  // Q rows | dO rows | dO^T | Q^T | L2[64] | D[64] | (waves 2, 3: the same rows again -- no branch in the loop)
 constexpr int KV_LEAD = 4;
 
 struct KvState {
@@ -588,10 +603,7 @@ __device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __re
     if constexpr (tl == 1) dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
     if constexpr (tl == 2) dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
     if constexpr (tl == 3) dma16(R.d, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
-    if constexpr (i == 15) {
-      if (wave == 0) dma4(rL, (uint32_t)((s_next + lane) * 4), nxt + 4 * TILE);
-      if (wave == 1) dma4(rD, (uint32_t)((s_next + lane) * 4), nxt + 4 * TILE + 256);
-    }
+    if constexpr (i == 15) dma4((wave & 1) ? rD : rL, (uint32_t)((s_next + lane) * 4), nxt + 4 * TILE + wave * 256);
     // statistics of half u0 (needed from slot 18 on), half u1 in phase B
     if constexpr (i >= 8) {
       constexpr int q = i - 8, a = (q >> 1) & 1, h8 = q & 1;
@@ -608,12 +620,12 @@ __device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __re
   }
   if constexpr (ph < 2) {
     constexpr int ds = i >> 1, which = i & 1;
-    if constexpr (which == 0) st.sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], pa[ds], st.sacc[u], 0, 0, 0);
-    else st.dacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], pb[ds], st.dacc[u], 0, 0, 0);
+    if constexpr (which == 0) { if constexpr (ds == 0) mfma_s0(st.sacc[u], st.fr[M & 7], pa[ds]); else mfma_s(st.sacc[u], st.fr[M & 7], pa[ds]); }
+    else { if constexpr (ds == 0) mfma_s0(st.dacc[u], st.fr[M & 7], pb[ds]); else mfma_s(st.dacc[u], st.fr[M & 7], pb[ds]); }
   } else {
     constexpr int kt = i >> 3, db = (i >> 1) & 3, which = i & 1;
-    if constexpr (which == 0) oacc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], __builtin_bit_cast(bf16x8_t, st.pf[u][kt]), oacc0[db], 0, 0, 0);
-    else oacc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[M & 7], __builtin_bit_cast(bf16x8_t, st.dsf[u][kt]), oacc1[db], 0, 0, 0);
+    if constexpr (which == 0) mfma_o(oacc0[db], st.fr[M & 7], st.pf[u][kt]);
+    else mfma_o(oacc1[db], st.fr[M & 7], st.dsf[u][kt]);
   }
   // element-wise values: half u0 in slots 18 .. 33, half u1 in slots 34 .. 49 (two slots behind the MFMAs that finish their scores)
   if constexpr (M >= 18 && M < 34) kv_ew<0, M - 18>(st, scale_log2);
@@ -626,10 +638,6 @@ __device__ __forceinline__ void dkdv_tile(const char* __restrict__ cur, char* __
                                           const Geo& G, const bf16x8_t (&pa)[8], const bf16x8_t (&pb)[8], float scale_log2,
                                           f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4]) {
   KvState st;
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { st.sacc[u][r] = 0.f; st.dacc[u][r] = 0.f; }
   sfor<KV_LEAD>([&](auto mc) { st.fr[decltype(mc)::value & 7] = kv_frag<decltype(mc)::value>(cur, G); });
   __builtin_amdgcn_sched_barrier(0);
   sfor<64>([&](auto mc) {
@@ -696,8 +704,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __r
     dma16(R.c, (uint32_t)(col_src[j] * 2), dst + 2 * TILE);
     dma16(R.d, (uint32_t)(col_src[j] * 2), dst + 3 * TILE);
   }
-  if (wave == 0) dma4(rL, (uint32_t)(lane * 4), smem + 4 * TILE);
-  if (wave == 1) dma4(rD, (uint32_t)(lane * 4), smem + 4 * TILE + 256);
+  dma4((wave & 1) ? rD : rL, (uint32_t)(lane * 4), smem + 4 * TILE + wave * 256);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
@@ -767,11 +774,11 @@ __device__ __forceinline__ void dq_slot(const char* __restrict__ cur, char* __re
   }
   if constexpr (M < 64) {
     constexpr int u = F >> 4, i = F & 15, ds = i >> 1, which = i & 1;
-    if constexpr (which == 0) st.sacc[qb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[F & 7], pa[qb][ds], st.sacc[qb][u], 0, 0, 0);
-    else st.dacc[qb][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[F & 7], pb[qb][ds], st.dacc[qb][u], 0, 0, 0);
+    if constexpr (which == 0) { if constexpr (ds == 0) mfma_s0(st.sacc[qb][u], st.fr[F & 7], pa[qb][ds]); else mfma_s(st.sacc[qb][u], st.fr[F & 7], pa[qb][ds]); }
+    else { if constexpr (ds == 0) mfma_s0(st.dacc[qb][u], st.fr[F & 7], pb[qb][ds]); else mfma_s(st.dacc[qb][u], st.fr[F & 7], pb[qb][ds]); }
   } else {
     constexpr int i = F - 32, g = i >> 2, db = i & 3;
-    oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.fr[F & 7], __builtin_bit_cast(bf16x8_t, st.dsf[qb][g >> 1][g & 1]), oacc[qb][db], 0, 0, 0);
+    mfma_o(oacc[qb][db], st.fr[F & 7], st.dsf[qb][g >> 1][g & 1]);
   }
   if constexpr (M >= 34 && M < 66) dq_ew<0, M - 34, MASKED>(st, scale_log2, myL, myD, kbase, S);
   // half u1: values 0..15 in slots 66..79 (the first two slots carry two), values 16..31 two per slot in slots 80..87
@@ -792,12 +799,6 @@ __device__ __forceinline__ void dq_tile(const char* __restrict__ cur, char* __re
                                         const int (&col_src)[4], int wave, const Geo& G, const bf16x8_t (&pa)[2][8], const bf16x8_t (&pb)[2][8],
                                         const float (&myL)[2], const float (&myD)[2], int S, float scale_log2, f32x16_t (&oacc)[2][4]) {
   DqState st;
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st.sacc[qb][u][r] = 0.f; st.dacc[qb][u][r] = 0.f; }
   sfor<3>([&](auto fc) { st.fr[decltype(fc)::value & 7] = dq_frag<decltype(fc)::value>(cur, G); });
   __builtin_amdgcn_sched_barrier(0);
   const int kbase = s0 + 8 * G.hi;
