@@ -490,6 +490,41 @@ def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     assert torch.equal(dQ4, dQ2) and torch.equal(dK4, dK2) and torch.equal(dV4, dV2)
 
 
+@pytest.mark.parametrize("S", [4608, 4600])
+def test_pipelined_attention_backward_bit_identical_at_model_length(ops, S):
+    """The software-pipelined dQ and dK / dV passes (attn_bwd_pipe = 1, default) against the phase-after-phase kernels at the model's sequence
+    length (72 streamed tiles; S = 4600: a ragged last tile, the masked form of the dQ pass) -- bit for bit, on random operands."""
+    from x2i_amd import _lib
+    B, H = 1, 2
+    Spad = ops.pad128(S)
+    scale = 1.0 / math.sqrt(128.0)
+    gen = torch.Generator(device=DEV).manual_seed(90 + S)
+
+    def padded(sc=1.0):
+        t = torch.zeros((B, H, Spad, 128), device=DEV)
+        t[:, :, :S] = torch.randn((B, H, S, 128), device=DEV, generator=gen) * sc
+        return t.bfloat16()
+    Q, K, V, dOh4 = padded(), padded(), padded(), padded(0.5)
+    dOh = dOh4.view(B * H, Spad, 128)
+    QT, KT, dOT = ops.transpose(Q.view(B * H, Spad, 128)), ops.transpose(K.view(B * H, Spad, 128)), ops.transpose(dOh)
+    Dv = torch.zeros((B, H, Spad), device=DEV)
+    Dv[:, :, :S] = torch.randn((B, H, S), device=DEV, generator=gen) * 0.1
+    lse = torch.empty((B, H, Spad), device=DEV)
+    outs = {}
+    for pipe in (1, 0):
+        old = _lib.set_option("attn_bwd_pipe", pipe)
+        try:
+            dQ, dK, dV = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
+            ops.attention_bwd(Q, K, V, QT, KT, dOh, dOT, lse, Dv, dQ, dK, dV, B, H, S, Spad, scale)   # (statistics pass included)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("attn_bwd_pipe", old)
+        outs[pipe] = (dQ, dK, dV)
+    for a, b_ in zip(outs[1], outs[0]):
+        assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0
+        assert torch.equal(a, b_)
+
+
 def test_full_width_distillation_gradient_vs_oracle_autograd():
     """D = 3072, 24 heads, one double + one single block on 512 + 1024 tokens, B = 2: the training chain at the real GEMM / attention
     shapes (256^2 MFMA kernels in the dgrad launches, the fused attention backward at S = 1536, the 43 008-row modulation table) with

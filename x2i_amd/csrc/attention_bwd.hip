@@ -589,6 +589,12 @@ __device__ __forceinline__ void kv_ew(KvState& st, float scale_log2) {
   }
 }
 
+constexpr int kv_u0_value(int m) {
+  for (int r = 0; r < 16; ++r)
+    if (18 + r * 11 / 8 == m) return r;
+  return -1;
+}
+
 template <int M>
 __device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, const Rsrc4& R,
                                         __amdgpu_buffer_rsrc_t rL, __amdgpu_buffer_rsrc_t rD, const int (&row_src)[4], const int (&col_src)[4],
@@ -627,9 +633,10 @@ __device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __re
     if constexpr (which == 0) mfma_o(oacc0[db], st.fr[M & 7], st.pf[u][kt]);
     else mfma_o(oacc1[db], st.fr[M & 7], st.dsf[u][kt]);
   }
-  // element-wise values: half u0 in slots 18 .. 33, half u1 in slots 34 .. 49 (two slots behind the MFMAs that finish their scores)
-  if constexpr (M >= 18 && M < 34) kv_ew<0, M - 18>(st, scale_log2);
-  if constexpr (M >= 34 && M < 50) kv_ew<1, M - 34>(st, scale_log2);
+  // element-wise values (from two slots behind the MFMAs that finish their scores; a half's rows r < 8 before its kt = 0 MFMAs, r >= 8 before its
+  // kt = 1 MFMAs): half u0 spread over slots 18 .. 39 (value r in slot 18 + 11 r / 8), half u1 one per slot in 40 .. 55
+  if constexpr (kv_u0_value(M) >= 0) kv_ew<0, (kv_u0_value(M) >= 0 ? kv_u0_value(M) : 0)>(st, scale_log2);
+  if constexpr (M >= 40 && M < 56) kv_ew<1, M - 40>(st, scale_log2);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -728,6 +735,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __r
 //                                                     rows r >= 8 by slot 87 (two values per slot there: the groups that need them follow)
 // Same MFMA order per accumulator and element-wise operations as attn_bwd_dq64_kernel: bit-identical (tested).  MASKED: the last tile of a
 // sequence with S % 64 != 0 (keys at or behind S get p = 0); every other tile runs without the compare / select per value.
+constexpr int DQ_LEAD = 3;   // fragments (= pairs of slots) a read runs ahead of its MFMAs
 struct DqState {
   f32x16_t sacc[2][2], dacc[2][2];   // [qb][u]
   bf16x8_t fr[8];
@@ -764,7 +772,7 @@ __device__ __forceinline__ void dq_slot(const char* __restrict__ cur, char* __re
                                         const float (&myL)[2], const float (&myD)[2], int kbase, int S, float scale_log2, f32x16_t (&oacc)[2][4],
                                         DqState& st) {
   constexpr int F = M >> 1, qb = M & 1;
-  if constexpr ((M & 1) == 0 && F + 3 < 48) st.fr[(F + 3) & 7] = dq_frag<F + 3>(cur, G);
+  if constexpr ((M & 1) == 0 && F + DQ_LEAD < 48) st.fr[(F + DQ_LEAD) & 7] = dq_frag<F + DQ_LEAD>(cur, G);
   if constexpr (M < 24 && (M & 1) == 0) {   // the next tile: piece j = (M / 2) >> 2 ... of tile (M / 2) % 3
     constexpr int pc = M >> 1, j = pc / 3, tl = pc % 3;
     char* dst = nxt + tl * TILE + (j * 256 + wave * 64) * 16;
@@ -799,7 +807,7 @@ __device__ __forceinline__ void dq_tile(const char* __restrict__ cur, char* __re
                                         const int (&col_src)[4], int wave, const Geo& G, const bf16x8_t (&pa)[2][8], const bf16x8_t (&pb)[2][8],
                                         const float (&myL)[2], const float (&myD)[2], int S, float scale_log2, f32x16_t (&oacc)[2][4]) {
   DqState st;
-  sfor<3>([&](auto fc) { st.fr[decltype(fc)::value & 7] = dq_frag<decltype(fc)::value>(cur, G); });
+  sfor<DQ_LEAD>([&](auto fc) { st.fr[decltype(fc)::value & 7] = dq_frag<decltype(fc)::value>(cur, G); });
   __builtin_amdgcn_sched_barrier(0);
   const int kbase = s0 + 8 * G.hi;
   sfor<96>([&](auto mc) {
