@@ -16,11 +16,11 @@
  *     library-owned workspace ("PyTorch allocates and owns every buffer ... workspace via a
  *     workspace_size query") -- weights are consumed in the reference's own nn.Linear [N,K] layout, fused only by
  *     row-concatenation on the host side, and every scratch buffer is a caller-owned argument sized by a query:
- *     x2i_groupnorm_scratch_floats, x2i_streamk_workspace_bytes (x2i_gemm_args.workspace).  Process-wide state, all of it
+ *     x2i_groupnorm_scratch_floats, x2i_streamk_workspace_bytes (x2i_gemm_args.workspace, x2i_attention_vp_ws_bf16).  Process-wide state, all of it
  *     mutex-protected: the option table below, a per-kernel "dynamic LDS size already raised" cache, and ONE HIP object set per
  *     device that holds no memory -- a side stream with two events, created on the first x2i_attention_bwd_bf16 call that runs
  *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
- *   - ABI version 4 (x2i_abi_version; 4 appends `w_group` to x2i_gemm_args, 0 = what version 3 did, and adds the *_grouped entry points).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
+ *   - ABI version 5 (x2i_abi_version; 5 adds x2i_attention_vp_ws_bf16 -- no struct changed; 4 appended `w_group` to x2i_gemm_args, 0 = what version 3 did, and added the *_grouped entry points).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
  *     zero-initialised descriptor means what it meant in version 1), appends `out_w`, `out_h`, `out_row_pitch` (0 = computed / dense) and the `moments` fields (NULL = off) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
  *     library (x2i_amd/_lib.py checks).
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define X2I_ABI_VERSION 4
+#define X2I_ABI_VERSION 5
 
 #define X2I_OK 0
 #define X2I_ERR_ARG (-1)
@@ -69,6 +69,7 @@ const char* x2i_last_error(void);
  * "attn_w16" (1: x2i_attention_prefers_vt_perm may answer 1 -- the sampling path then uses the 16 x 16 x 32 attention kernel; 0: never; 2: at any size -- tests),
  * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
  * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
+ * "attn_streamk" (1: x2i_attention_vp_ws_bf16 cuts the items of a partly filled last round along the key axis, chained through the workspace; 0: whole items),
  * "attn_bwd_pipe" (1: the dK / dV pass runs software-pipelined -- element-wise section under the MFMAs; 0: phase after phase; bit-identical),
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
  * same values up to the summation order of the row statistics),
@@ -274,6 +275,16 @@ int x2i_attention_bf16(const void* Q, const void* K, const void* VT, void* O, in
 int x2i_attention_vp_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
                           int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream);
 int x2i_attention_prefers_vt_perm(int32_t H, int32_t S, float scale);
+/* x2i_attention_vp_bf16 with the caller's stream-K workspace (the one x2i_gemm_args.workspace names: x2i_streamk_workspace_bytes(), 256-byte
+ * aligned, flags zero between launches; NULL = none): when B * H * ceil(S / 256) work items leave a partly filled last round of one-workgroup-per-CU
+ * blocks (1024^2: 1.7 / 3.4 / 6.75 rounds at batch 1 / 2 / 4), that round's items are cut along the KEY axis over all CUs and the parts of an item are
+ * CHAINED through the workspace -- the closing part continues from the un-normalised output, running maximum and row sums of the opening part, so
+ * every row is summed in the order of an undivided item: bit-identical to x2i_attention_vp_bf16 whatever the cuts (they depend on the batch; a
+ * sample's result does not).  Same co-residency assumption and give-up marker as the GEMMs' chained segments.  Option "attn_streamk" (default 1).
+ * Stands behind the same call (lightcontrol_flux.py:92-95,173-177). */
+int x2i_attention_vp_ws_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S,
+                             int32_t Spad, int32_t ldo, int64_t o_batch_stride, float scale, void* workspace, int64_t workspace_bytes,
+                             x2i_stream_t stream);
 
 /* The same attention with an e4m3 output O8[b][s][h*128 + d] = sat(o * out_inv_scale) (ldo / o_batch_stride in bytes, multiples
  * of 8): the A operand of an fp8 projection (single blocks' proj_out in the fp8 configuration), no bf16 round trip. */

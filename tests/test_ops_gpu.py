@@ -502,6 +502,40 @@ def test_rope_table_matches_float64_reference(ops):
     assert torch.equal(cos[:40].cpu(), torch.ones(40, 128)) and torch.equal(sin[:40].cpu(), torch.zeros(40, 128))
 
 
+@pytest.mark.parametrize("B,H,S,pres", [(1, 24, 4608, 0), (2, 24, 4608, 0), (4, 24, 4608, 0), (3, 24, 4600, 0), (1, 40, 2000, 1), (5, 8, 3100, 0)])
+def test_attention_streamk_bit_identical(ops, opt, B, H, S, pres):
+    """x2i_attention_vp_ws_bf16: the items of a partly filled last round cut along the key axis (opening parts in front of the last whole round on
+    some workgroups, one to three closing parts behind it on the others) and chained through the workspace; one to seven whole rounds, ragged last
+    tiles, the kernel's own Q scaling -- bit for bit the undivided launch's output, flags back at zero, no give-up marker; twice in a row on the
+    same workspace."""
+    import math
+    Spad = ops.pad128(S)
+    D = H * 128
+    gen = torch.Generator(device=DEV).manual_seed(2000 + S + B)
+    Q = (torch.randn((B, H, Spad, 128), device=DEV, generator=gen) * 1.5).bfloat16()
+    K = (torch.randn((B, H, Spad, 128), device=DEV, generator=gen) * 1.5).bfloat16()
+    VTP = torch.randn((B, H, 128, Spad), device=DEV, generator=gen).bfloat16()
+    if pres:
+        scale = 1 / math.sqrt(128)
+    else:
+        Q = (Q.float() * (1.4426950408889634 / math.sqrt(128))).bfloat16()
+        scale = math.log(2.0)
+    opt("attn_streamk", 0)
+    ref = torch.zeros((B, S, D), device=DEV, dtype=torch.bfloat16)
+    ops.attention(Q, K, VTP, ref, B, H, S, Spad, D, S * D, scale, vt_perm=True)
+    opt("attn_streamk", 1)
+    for _ in range(2):
+        out = torch.full((B, S, D), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.attention(Q, K, VTP, out, B, H, S, Spad, D, S * D, scale, vt_perm=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        bad = (out != ref)
+        assert not bool(bad.any()), f"{int(bad.sum())} elements differ, first at {bad.nonzero()[0].tolist()}"
+    ws = ops._sk_workspace()
+    assert int(ws.buf[:4096].view(torch.int32).abs().sum()) == 0      # every flag returned to zero, no give-up marker
+    ops.streamk_check(sync=True)
+
+
 @pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 136), (1, 2, 1152), (1, 3, 700), (2, 1, 2000), (1, 24, 4608)])
 def test_attention_hand_scheduled_16x16x32_kernel(ops, opt, B, H, S):
     """attention_w16.hip (attn_variant = 12, A/B): attention_w4.hip's program on v_mfma_f32_16x16x32_bf16 -- P^T from the lane's own registers

@@ -14,7 +14,7 @@ _VARIANT = os.environ.get("X2I_LIB_VARIANT", "")
 LIB_PATH = os.path.join(_HERE, "libx2i_hip_%s.so" % _VARIANT if _VARIANT else "libx2i_hip.so")
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
-ABI_VERSION = 4  # include/x2i.h: X2I_ABI_VERSION
+ABI_VERSION = 5  # include/x2i.h: X2I_ABI_VERSION
 
 
 class X2IError(RuntimeError):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "x2i_groupnorm_nhwc_from_moments_bf16": [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
     "x2i_attention_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
     "x2i_attention_vp_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp],
+    "x2i_attention_vp_ws_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _vp, _i64, _vp],
     "x2i_attention_prefers_vt_perm": [_i32, _i32, _f32],
     "x2i_attention_e4m3out": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _f32, _f32, _vp],
     "x2i_qkv_split_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp],

@@ -7,31 +7,42 @@
 #include "x2i_common.h"
 #include "x2i_kernels.h"
 #include "attn_w16_loop.inc"
+#include <algorithm>
 
 namespace {
 
+constexpr int SKA_SLAB_BYTES = 34 * 4096;   // hand-over state of a cut item: 32 pieces of O + one of -m + one of l, 256 lanes x 16 B each (gen_attn_w16.py)
+constexpr int SKA_FLAG0 = 768;              // workspace flags [768, 1024): K tiles of last-round item E accumulated so far (the GEMMs use [0, 257) and [512, 768))
+constexpr int SKA_ERR_SLOT = 256;           // the workspace's give-up marker (csrc/gemm_device.h SK_ERR_SLOT)
+constexpr int SKA_MIN_TILES = 4;            // no part shorter than this: a cut that close to an item edge moves onto it
+constexpr int SKA_G = 256;                  // workgroups of a stream-K launch (= CUs of the part)
+constexpr int SKA_UNIT_TILES = 7;           // what starting + finishing a unit costs, in key tiles (prologue, pipeline fill / drain, epilogue or hand-over: ~9 us)
+
+// SK = false: one work item (256 queries of one head) per workgroup, from its first key tile to its last -- the kernel of round 5.
+// SK = true (stream-K, round 6): one workgroup per CU.  nitems = R G + r: every workgroup takes R whole items (item j G + w in round j, the
+// order a plain launch is dispatched in) and a share of the LAST round's r items: each of them is cut along the KEY axis at tile c into an opening
+// part [0, c) and a closing part [c, nt), CHAINED -- the closing part continues from the un-normalised O, the running maximum and the row sums the
+// opening part leaves in the caller's workspace, so every query row is summed in exactly the order of an undivided item: bit-identical results,
+// whatever the cut (it depends on the batch; the results do not).  Per XCD (workgroup w runs on XCD w & 7; its last-round items are r / 8
+// consecutive ones, i.e. one or two heads): the first r / 8 workgroups run an opening part in front of their last whole item; the others run their
+// whole items and then up to m closing parts -- long after the opening parts were published (the wait is bounded all the same and leaves the
+// workspace's give-up marker instead of a hung GPU).  All opening parts of an XCD stream the same key tiles of the same heads at the same time, all
+// closing parts likewise, and only its last whole-item round runs in two phase groups: the K / V^T tiles stay shared through the XCD's L2.  (A flat deal of
+// the last round's tiles over the workgroups -- every workgroup another cut -- lost that sharing and ran SLOWER than whole items.)  c balances the two
+// kinds of workgroup with the cost of starting and finishing a unit counted in: c + u = m (nt - c + u).
+template <bool SK>
 __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                        bf16_t* __restrict__ O, int H, int S, int Spad, int ldo, long long o_bs, float scale_log2,
-                                                       int nbatch, float* __restrict__ lse, int prescale) {
+                                                       int nbatch, float* __restrict__ lse, int prescale, int nitems, char* __restrict__ slabs,
+                                                       unsigned* __restrict__ flags, int sk_c, int sk_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int nqt = gridDim.x / (H * nbatch);
-  int bid = blockIdx.x;
-  {
-    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int qt = bid % nqt, h = (bid / nqt) % H, b = bid / (nqt * H);
-  const int q0 = qt * 256 + wave * 64;
-  const long long bh = (long long)b * H + h;
-  const bf16_t* Qh = Q + bh * Spad * 128;
-  const bf16_t* Kh = K + bh * Spad * 128;
-  const bf16_t* Vh = VT + bh * 128 * Spad;
-  __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (uint32_t)Spad * 256u, 0x00020000);
-  __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (uint32_t)Spad * 256u, 0x00020000);
+  const int nqt = nitems / (H * nbatch);
+  const int nt_full = (S + 63) / 64;
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
   // LDS-DMA source offsets: the images and swizzles of attention_w4.hip (K [64 keys][256 B], chunk ^ (row & 15); V^T [128 d][128 B], chunk ^ ((row >> 1) & 7))
   uint32_t kd[4], vd[4];
@@ -57,44 +68,143 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
   for (int sp = 0; sp < 2; ++sp) va[sp] = sbase + 32768 + c * 128 + (((sp * 4 + g) ^ ((c >> 1) & 7)) << 4);
   const uint32_t kdst = __builtin_amdgcn_readfirstlane(sbase + wave * 1024);
   const uint32_t vdst = __builtin_amdgcn_readfirstlane(sbase + 32768 + wave * 1024);
-
-  const int q = q0 + c;   // query of block 0; block qb: + 16 qb
-  uint32_t qo[4];
-#pragma unroll
-  for (int qb = 0; qb < 4; ++qb) qo[qb] = (uint32_t)(min(q + 16 * qb, Spad - 1) * 128 + g * 8) * 2u;   // rows at or behind S are never stored: clamp the read
-  // 16-byte store of a d-block pair: even g -> first block at d = 4 g, odd g -> second block at d = 16 + 4 (g - 1)
-  uint32_t oo = (uint32_t)(((long long)q * ldo) * 2) + ((g & 1) ? 32u + 8u * (uint32_t)(g - 1) : 8u * (uint32_t)g);
-  const uint32_t lo = (uint32_t)q * 4u;
-  const char* Ob = (const char*)O + ((long long)b * o_bs + h * 128) * 2;
-  const float* Lb = lse ? lse + bh * Spad : nullptr;
-  const int nt = (S + 63) / 64;
-  const int lim = S - (nt - 1) * 64 - 4 * g;
-  uint32_t cnt = (uint32_t)(nt > 2 ? nt - 2 : 0);
-  const uint32_t ostep = (uint32_t)ldo * 32u;  // 16 rows of bf16
   const uint32_t lsef = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)lse >> 32) | (uint32_t)(uintptr_t)lse);
+  const uint32_t ostep = (uint32_t)ldo * 32u;  // 16 rows of bf16
   const float thr = 8.0f;
-  uint32_t s_so, s_so2, s_fl;
-  unsigned long long s_cnd, s_exs;
-  asm volatile(X2I_ATTN_W16_TEXT
-               : [oo] "+v"(oo), [cnt] "+s"(cnt), [so] "=&s"(s_so), [so2] "=&s"(s_so2), [fl] "=&s"(s_fl), [cnd] "=&s"(s_cnd), [exs] "=&s"(s_exs)
-               : [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [va0] "v"(va[0]), [va1] "v"(va[1]), [kd0] "v"(kd[0]),
-                 [kd1] "v"(kd[1]), [kd2] "v"(kd[2]), [kd3] "v"(kd[3]), [vd0] "v"(vd[0]), [vd1] "v"(vd[1]), [vd2] "v"(vd[2]), [vd3] "v"(vd[3]),
-                 [kdst] "s"(kdst), [vdst] "s"(vdst), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [qo3] "v"(qo[3]), [lo] "v"(lo), [qv] "v"(q),
-                 [lim] "v"(lim), [hi] "v"(g), [kr] "s"(k_rsrc), [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2),
-                 [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt), [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale)
-               : "memory", "vcc", "scc", "m0", X2I_ATTN_W16_CLOBBERS);
+  const uint32_t sto = (uint32_t)tid * 16u;
+
+  // ---- this workgroup's units: (item id, first key tile, tiles, slab); SK = false: one whole item
+  struct Unit { int id, k0, len, slab; };
+  const int G = gridDim.x, w = blockIdx.x;
+  int R = 0, n_part = 0, part_e0 = 0, part_step = 0, part_big = 0;
+  if constexpr (SK) {
+    R = nitems / G;
+    const int r8 = (nitems - R * G) >> 3;               // last-round items per XCD (the launcher: r % 8 == 0, 0 < r8 < 32)
+    const int x = w & 7, i = w >> 3, others = (G >> 3) - r8;
+    if (i < r8) { part_big = 1; n_part = 1; part_e0 = x * r8 + i; }
+    else { const int k = i - r8; n_part = k < r8 ? (r8 - 1 - k) / others + 1 : 0; part_e0 = x * r8 + k; part_step = others; }
+  }
+  const int n_units = SK ? R + n_part : 1;
+  for (int ui = 0; ui < n_units; ++ui) {
+    Unit u = {(int)blockIdx.x, 0, nt_full, -1};
+    if constexpr (SK) {
+      // an opening part runs in front of the workgroup's LAST whole item: published before any closing part is reached (those follow R whole
+      // items), and only that one round of the XCD runs in two phase groups (in front of all R: -2 % at ten rounds instead of +3 %)
+      const int pos_big = R > 0 ? R - 1 : 0;
+      const int j = ui - ((part_big && ui > pos_big) ? 1 : 0);                   // whole item of round j ...
+      u = Unit{w + j * G, 0, nt_full, -1};
+      if (part_big && ui == pos_big) u = Unit{R * G + (part_e0 % ((nitems - R * G) >> 3)) * 8 + part_e0 / ((nitems - R * G) >> 3), 0, sk_c, part_e0};
+      else if (!part_big && ui >= R) {                  // ... or closing part ui - R
+        const int E = part_e0 + (ui - R) * part_step, r8 = (nitems - R * G) >> 3;
+        u = Unit{R * G + (E % r8) * 8 + E / r8, sk_c, nt_full - sk_c, E};
+      }
+      u = Unit{uni(u.id), uni(u.k0), uni(u.len), uni(u.slab)};
+    }
+    int bid = u.id;
+    {
+      const int T = nitems, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int qt = bid % nqt, h = (bid / nqt) % H, b = bid / (nqt * H);
+    const int q0 = qt * 256 + wave * 64;
+    const long long bh = (long long)b * H + h;
+    const bf16_t* Qh = Q + bh * Spad * 128;
+    const bf16_t* Kh = K + bh * Spad * 128;
+    const bf16_t* Vh = VT + bh * 128 * Spad;
+    __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, (uint32_t)Spad * 256u, 0x00020000);
+    __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, (uint32_t)Spad * 256u, 0x00020000);
+    const int q = q0 + c;   // query of block 0; block qb: + 16 qb
+    uint32_t qo[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) qo[qb] = (uint32_t)(min(q + 16 * qb, Spad - 1) * 128 + g * 8) * 2u;   // rows at or behind S are never stored: clamp the read
+    // 16-byte store of a d-block pair: even g -> first block at d = 4 g, odd g -> second block at d = 16 + 4 (g - 1)
+    uint32_t oo = (uint32_t)(((long long)q * ldo) * 2) + ((g & 1) ? 32u + 8u * (uint32_t)(g - 1) : 8u * (uint32_t)g);
+    const uint32_t lo_ = (uint32_t)q * 4u;
+    const char* Ob = (const char*)O + ((long long)b * o_bs + h * 128) * 2;
+    const float* Lb = lse ? lse + bh * Spad : nullptr;
+    const int nt = u.len;
+    // (integer arithmetic, not comparisons: hipcc materialises an i1 in a VGPR, which cannot feed an "s" operand)
+    const uint32_t cont = (uint32_t)uni(min(u.k0, 1)), hand = (uint32_t)uni(min(nt_full - (u.k0 + u.len), 1));   // hand = 0: this part holds the item's last key tile
+    const int closes = 1 - (int)hand;
+    const int lim = closes ? S - (nt_full - 1) * 64 - 4 * g : 0x10000;   // keys at or behind S are masked in the item's last tile only
+    uint32_t cnt = (uint32_t)(nt > 2 ? nt - 2 : 0);
+    const uint32_t so0 = (uint32_t)u.k0 * 0x4000u, so20 = (uint32_t)u.k0 * 128u;
+    __amdgpu_buffer_rsrc_t s_rsrc = k_rsrc;   // (a valid descriptor when no slab is read or written)
+    if constexpr (SK) {
+      if (u.slab >= 0) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)slabs + (unsigned long long)u.slab * SKA_SLAB_BYTES;
+        const unsigned long long au = ((unsigned long long)(unsigned)uni((int)(a >> 32)) << 32) | (unsigned)uni((int)(a & 0xffffffffu));
+        s_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)au, 0, (uint32_t)SKA_SLAB_BYTES, 0x00020000);
+      }
+      if (cont) {   // wait until the predecessor has published key tiles [0, k0) of this item
+        if (tid == 0) {
+          unsigned* flag = flags + SKA_FLAG0 + u.slab;
+          int spins = 0;
+          while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)u.k0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1 << 22)) {
+              __hip_atomic_store(flags + SKA_ERR_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+      }
+    }
+    uint32_t s_so, s_so2, s_fl;
+    unsigned long long s_cnd, s_exs;
+    asm volatile(X2I_ATTN_W16_TEXT
+                 : [oo] "+v"(oo), [cnt] "+s"(cnt), [so] "=&s"(s_so), [so2] "=&s"(s_so2), [fl] "=&s"(s_fl), [cnd] "=&s"(s_cnd), [exs] "=&s"(s_exs)
+                 : [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [va0] "v"(va[0]), [va1] "v"(va[1]), [kd0] "v"(kd[0]),
+                   [kd1] "v"(kd[1]), [kd2] "v"(kd[2]), [kd3] "v"(kd[3]), [vd0] "v"(vd[0]), [vd1] "v"(vd[1]), [vd2] "v"(vd[2]), [vd3] "v"(vd[3]),
+                   [kdst] "s"(kdst), [vdst] "s"(vdst), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [qo3] "v"(qo[3]), [lo] "v"(lo_), [qv] "v"(q),
+                   [lim] "v"(lim), [hi] "v"(g), [kr] "s"(k_rsrc), [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2),
+                   [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt), [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale),
+                   [so0] "s"(so0), [so20] "s"(so20), [cont] "s"(cont), [hand] "s"(hand), [sr] "s"(s_rsrc), [sto] "v"(sto)
+                 : "memory", "vcc", "scc", "m0", X2I_ATTN_W16_CLOBBERS);
+    if constexpr (SK) {
+      __syncthreads();   // every wave is done with the K / V^T rings (and, for a hand-over, has drained its slab stores) before the next unit
+      if (tid == 0 && u.slab >= 0) {
+        // opening / middle part: publish the tiles accumulated so far; closing part of a cut item: the flag returns to zero (workspace invariant)
+        if (hand) __hip_atomic_store(flags + SKA_FLAG0 + u.slab, (unsigned)(u.k0 + u.len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (cont) __hip_atomic_store(flags + SKA_FLAG0 + u.slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 }  // namespace
 
+// stream-K form: possible (nitems > CUs, a last round of a multiple of 8 items whose shares are long enough) and wanted (a workspace was handed over)?
+static bool w16_streamk(int nitems, int nt, int cus, void* ws, long long ws_bytes) {
+  if (!ws || !x2i_options().attn_streamk || cus != SKA_G || nitems <= cus || nt < 4 * SKA_MIN_TILES) return false;
+  const int r = nitems % cus;
+  if (r == 0 || (r & 7)) return false;
+  return ws_bytes >= 4096 + (long long)r * SKA_SLAB_BYTES && !(((uintptr_t)ws) & 255);
+}
+
 // X2I_ERR_STATE: shape / alignment not served (the caller falls back to the other forms)
 int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
-                             float scale_log2, int prescale, hipStream_t stream, float* lse) {
+                             float scale_log2, int prescale, hipStream_t stream, float* lse, void* workspace, long long workspace_bytes) {
   if ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7) || (long long)S * ldo * 2 >= 0x7f000000LL) return X2I_ERR_STATE;
-  const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel, 65536);
+  const int nitems = ((S + 255) / 256) * H * B;
+  const int cus = x2i_num_cus();
+  if (!lse && w16_streamk(nitems, (S + 63) / 64, cus, workspace, workspace_bytes)) {
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<true>, 65536);
+    if (rc) return rc;
+    // the cut: m = closing parts per closing workgroup, c from c + u = m (nt - c + u) (see the kernel's header)
+    const int nt = (S + 63) / 64, r8 = (nitems % cus) >> 3, others = (cus >> 3) - r8;
+    const int m = (r8 + others - 1) / others;
+    int c = (m * nt + (m - 1) * SKA_UNIT_TILES + (m + 1) / 2) / (m + 1);
+    c = std::min(std::max(c, SKA_MIN_TILES), nt - SKA_MIN_TILES);
+    hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
+                       ldo, o_bs, scale_log2, B, lse, prescale, nitems, (char*)workspace + 4096, (unsigned*)workspace, c, m);
+    return x2i_check_launch("attention (w16, stream-K)");
+  }
+  const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<false>, 65536);
   if (rc) return rc;
-  dim3 grid(((S + 255) / 256) * H * B);
-  hipLaunchKernelGGL(attn_w16_kernel, grid, dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo,
-                     o_bs, scale_log2, B, lse, prescale);
+  hipLaunchKernelGGL(attn_w16_kernel<false>, dim3(nitems), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo,
+                     o_bs, scale_log2, B, lse, prescale, nitems, (char*)nullptr, (unsigned*)nullptr, 0, 0);
   return x2i_check_launch("attention (w16)");
 }

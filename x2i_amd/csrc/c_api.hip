@@ -58,6 +58,7 @@ X2IOptions make_options() {
   o.conv_korder = env_int("X2I_CONV_KORDER", 1);
   o.attn_variant = env_int("X2I_ATTN_VARIANT", 0);
   o.attn_w16 = env_int("X2I_ATTN_W16", 1);
+  o.attn_streamk = env_int("X2I_ATTN_STREAMK", 1);
   o.conv5_variant = env_int("X2I_CONV5_VARIANT", 0);
   o.fp8 = env_int("X2I_FP8", 0);
   o.last_gemm_tile = -1;
@@ -155,7 +156,7 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_fp8_persist) X2I_OPT_INT(gemm_fx) X2I_OPT_INT(gemm_fx_nk) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(train_rows_wg) X2I_OPT_INT(attn_bwd_overlap) X2I_OPT_INT(attn_bwd_dq64) X2I_OPT_INT(attn_bwd_pipe) X2I_OPT_INT(conv256) X2I_OPT_INT(conv_w4) X2I_OPT_INT(conv_korder) X2I_OPT_INT(attn_variant) X2I_OPT_INT(attn_w16) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_fp8_persist) X2I_OPT_INT(gemm_fx) X2I_OPT_INT(gemm_fx_nk) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(train_rows_wg) X2I_OPT_INT(attn_bwd_overlap) X2I_OPT_INT(attn_bwd_dq64) X2I_OPT_INT(attn_bwd_pipe) X2I_OPT_INT(attn_streamk) X2I_OPT_INT(conv256) X2I_OPT_INT(conv_w4) X2I_OPT_INT(conv_korder) X2I_OPT_INT(attn_variant) X2I_OPT_INT(attn_w16) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
   X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate) X2I_OPT_INT(gemm_r2)
 #endif
@@ -296,17 +297,24 @@ int x2i_attention_prefers_vt_perm(int32_t H, int32_t S, float scale) {
   return (mode && fabsf(sl2 - 1.f) < 1e-6f && S > 0 && (mode == 2 || (long long)((S + 255) / 256) * H >= 128)) ? 1 : 0;
 }
 
-int x2i_attention_vp_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
-                          int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
+int x2i_attention_vp_ws_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                             int32_t ldo, int64_t o_batch_stride, float scale, void* workspace, int64_t workspace_bytes, x2i_stream_t stream) {
   if (!Q || !K || !VT || !O) return x2i_set_error(X2I_ERR_ARG, "attention_vp: null pointer");
   if (B <= 0 || H <= 0 || S <= 0 || Spad < S || Spad % 128) return x2i_set_error(X2I_ERR_SHAPE, "attention_vp: need Spad %% 128 == 0 and Spad >= S (S=%d Spad=%d)", S, Spad);
+  if (workspace && (workspace_bytes < x2i_streamk_workspace_bytes() || (((uintptr_t)workspace) & 255)))
+    return x2i_set_error(X2I_ERR_ARG, "attention_vp: the stream-K workspace must be 256-byte aligned and >= x2i_streamk_workspace_bytes() bytes (got %lld)", (long long)workspace_bytes);
   float sl2 = scale * 1.4426950408889634f;
   const bool unit = fabsf(sl2 - 1.f) < 1e-6f;
   if (unit) sl2 = 1.f;
-  const int rc = x2i_launch_attention_w16(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, sl2, unit ? 0 : 1, (hipStream_t)stream, nullptr);
+  const int rc = x2i_launch_attention_w16(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, sl2, unit ? 0 : 1, (hipStream_t)stream, nullptr, workspace, workspace_bytes);
   if (rc == X2I_ERR_STATE)
     return x2i_set_error(X2I_ERR_SHAPE, "attention_vp: the span-permuted V^T layout is only read by the 16x16x32 kernel, which needs 16-byte aligned output rows (ldo=%d)", ldo);
   return rc;
+}
+
+int x2i_attention_vp_bf16(const void* Q, const void* K, const void* VT, void* O, int32_t B, int32_t H, int32_t S, int32_t Spad,
+                          int32_t ldo, int64_t o_batch_stride, float scale, x2i_stream_t stream) {
+  return x2i_attention_vp_ws_bf16(Q, K, VT, O, B, H, S, Spad, ldo, o_batch_stride, scale, nullptr, 0, stream);
 }
 
 int x2i_attention_lse_bf16(const void* Q, const void* K, const void* VT, void* O, float* lse2, int32_t B, int32_t H, int32_t S, int32_t Spad,

@@ -335,12 +335,12 @@ def issue_cost(line):
     return 3
 
 
-def iteration(st, has_qk, has_pv, masked, first, next_kinds):
+def iteration(st, has_qk, has_pv, masked, first, next_kinds, force_rescale=False):
     """The iteration with its softmax stream BALANCED against everything else the gaps carry: a dry run without the softmax gives
     the issue time of the reads / waits / DMA pieces behind each MFMA; the VALU stream then fills every gap up to a common level
     (water-filling), so that no gap outlasts its MFMA while others idle."""
     n2 = n_mfmas(unit_list(has_qk, has_pv))
-    dry = _iteration(st, has_qk, has_pv, masked, first, next_kinds, None, True)
+    dry = _iteration(st, has_qk, has_pv, masked, first, next_kinds, None, True, force_rescale)
     others, g = [0] * (n2 + 1), 0
     for line in dry[0]:
         if line.startswith("v_mfma"):
@@ -367,10 +367,10 @@ def iteration(st, has_qk, has_pv, masked, first, next_kinds):
             if g in elig:
                 acc += max(0.0, hi - others[g])
             targets[g] = int(acc + 0.5)
-    return _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, False)[0]
+    return _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, False, force_rescale)[0]
 
 
-def _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, dry):
+def _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, dry, force_rescale=False):
     """One pipelined iteration i (st = i & 1): softmax of score set `st`, S(i+1) into set st ^ 1, O += V(i-1) P(i-1).  K(i+1) and
     V(i-1) sit in ring slot st ^ 1.  The first LEAD fragments arrive pre-read (ring slots 0 .. LEAD-1).  The iteration ends with the
     ring hand-over and the pre-reads of the next iteration; `next_kinds` = [(conditional, (has_qk, has_pv), label)]: the first entry
@@ -481,7 +481,7 @@ def _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, dry):
         L += post
         while vi < len(va):
             assert emit_next(), "a P group is still being read"
-        if has_pv:
+        if has_pv or force_rescale:
             L += o_rescale(f"{uid}x{ci}")
         L.append(f"s_branch {label}")
         if cond:
@@ -489,7 +489,7 @@ def _iteration(st, has_qk, has_pv, masked, first, next_kinds, targets, dry):
     return L, total_cost
 
 
-def solo(kind, s_dst, par, preread):
+def solo(kind, s_dst, par, preread, c_init=False):
     """A unit list on its own (prologue S(0) with C = 0, tail PV): reads LEAD ahead, no VALU stream."""
     us = unit_list(*kind)
     sm = Stream(us, LEAD if preread else 0, par)
@@ -499,45 +499,98 @@ def solo(kind, s_dst, par, preread):
     for k in range(len(us)):
         sm.read_upto_unit(L, k + LEAD + 1)
         sm.wait(L, k)
-        L += sm.mfmas(k, s_dst, False)
+        L += sm.mfmas(k, s_dst, c_init)
     return L
 
 
-def prologue():
+STATE_PIECE = 4096      # bytes per state load / store instruction of a workgroup (256 lanes x 16 B)
+
+
+def state_io(op, regs):
+    """One 16-byte piece per lane of the hand-over state (%[sr] = the slab's descriptor, %[sto] = lane * 16, %[so] = running piece offset)."""
+    return [f"buffer_{op}_dwordx4 v[{regs}:{regs + 3}], %[sto], %[sr], %[so] offen sc1", f"s_add_u32 %[so], %[so], {STATE_PIECE}"]   # (write-through stores, loads past the L1: the stream-K slabs' protocol, gen_gemm256w.py)
+
+
+def prologue(cont=False):
+    """cont = False: a work item from its first key tile (%[so0] = 0) or from any tile (the offsets are inputs).  cont = True (stream-K, the closing part of
+    an item cut along the key axis): O, -m and the row sums arrive from the slab the opening part left (state layout: 32 pieces of O -- accumulator
+    registers 4 k .. 4 k + 3 --, one of -m, one of l), S(t0) starts from C = -m like every later tile's, and the first iteration is an ordinary
+    (non-first) softmax pass without a PV product."""
     L = ["s_nop 4"]
     L += [f"v_mov_b32 v{ONES + k}, 0x3f803f80" for k in range(4)]
     for qb in range(4):
         L += [f"v_mov_b32 v{ALPHA + qb}, 1.0"]
     L += ["s_mov_b32 %[fl], 0"]
-    for db in range(8):
-        for qb in range(4):
-            L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(4)]
+    if not cont:
+        for db in range(8):
+            for qb in range(4):
+                L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(4)]
     # Q fragments (second operand of S^T = K Q^T): lane holds Q[q0 + 16 qb + c][32 ds + 8 g .. + 8]
     for qb in range(4):
         for ds in range(4):
             b = QTMP + (qb * 4 + ds) * 4
             L.append(f"global_load_dwordx4 v[{b}:{b + 3}], %[qo{qb}], %[qp] offset:{ds * 64}")
-    # K(0) -> slot 0, K(1) -> slot 1 (rows behind Spad read as zero)
-    L += ["s_mov_b32 %[so], 0"]
+    # K(t0) -> slot 0, K(t0 + 1) -> slot 1 (rows behind Spad read as zero)
+    L += ["s_mov_b32 %[so], %[so0]"]
     for j in range(4):
         L += [f"s_add_u32 m0, %[kdst], {j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
-    L += ["s_mov_b32 %[so], 0x4000"]
+    L += ["s_add_u32 %[so], %[so0], 0x4000"]
     for j in range(4):
         L += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
-    L += ["s_mov_b32 %[so], 0x8000", "s_mov_b32 %[so2], 0"]
+    if cont:
+        # the slab: O pieces 0 .. 15 through score set 0 (the raw Q fragments sit in set 1), -m and l through the temporaries
+        L += ["s_mov_b32 %[so], 0"]
+        for k in range(16):
+            L += state_io("load", SA + 4 * k)
+        L += ["s_mov_b32 %[so], " + str(32 * STATE_PIECE)]
+        L += state_io("load", TMP) + state_io("load", TMP + 4)
+        L += ["s_waitcnt vmcnt(0)"]
+        for qb in range(4):
+            L += [f"v_mov_b32 {NM(qb, r)}, {T(qb)}" for r in range(4)]
+            L += [f"v_mov_b32 {LA(qb, r)}, {T(4 + qb)}" for r in range(4)]
+        L += [f"v_accvgpr_write_b32 a{OA + i}, v{SA + i}" for i in range(64)]
+    else:
+        L += ["s_waitcnt vmcnt(8)"]
     # under the K flight: Q fragments into the accumulator file.  %[pres] == 0: Q already carries scale * log2 e (x2i_qkv_desc.q_scale);
     # otherwise Q~ = bf16(Q * scale * log2 e) here (a second rounding of Q).  Either way p = exp2(s') with s' = q~ . k - m
-    L += ["s_waitcnt vmcnt(8)", "s_cmp_lg_u32 %[pres], 0", "s_cbranch_scc1 .Lpres_%="]
+    sfx = "c" if cont else ""
+    L += ["s_cmp_lg_u32 %[pres], 0", f"s_cbranch_scc1 .Lpres{sfx}_%="]
     L += [f"v_accvgpr_write_b32 a{QF + i}, v{QTMP + i}" for i in range(64)]
-    L += ["s_branch .Lqdone_%=", ".Lpres_%=:"]
+    L += [f"s_branch .Lqdone{sfx}_%=", f".Lpres{sfx}_%=:"]
     for i in range(64):
         L += [f"v_lshlrev_b32 {T(0)}, 16, v{QTMP + i}", f"v_and_b32 {T(1)}, 0xffff0000, v{QTMP + i}",
               f"v_mul_f32 {T(0)}, %[sc], {T(0)}", f"v_mul_f32 {T(1)}, %[sc], {T(1)}",
               f"v_cvt_pk_bf16_f32 {T(0)}, {T(0)}, {T(1)}", f"v_accvgpr_write_b32 a{QF + i}, {T(0)}"]
-    L += [".Lqdone_%=:"]
+    L += [f".Lqdone{sfx}_%=:"]
+    if cont:
+        # O pieces 16 .. 31 (accumulator registers 64 .. 127) through score set 1, now that the raw Q fragments have left it
+        L += ["s_mov_b32 %[so], " + str(16 * STATE_PIECE)]
+        for k in range(16):
+            L += state_io("load", SA + 64 + 4 * k)
+        L += ["s_waitcnt vmcnt(0)"]
+        L += [f"v_accvgpr_write_b32 a{OA + 64 + i}, v{SA + 64 + i}" for i in range(64)]
+    L += ["s_add_u32 %[so], %[so0], 0x8000", "s_mov_b32 %[so2], %[so20]"]
     L += ["s_waitcnt vmcnt(0)", "s_barrier"]
-    # S(0) = K(0) Q~^T alone (score set 0, raw: the first softmax subtracts its maxima itself)
-    L += solo((True, False), 0, 0, False)
+    # S(t0) = K(t0) Q~^T alone (score set 0; raw for a fresh item: the first softmax subtracts its maxima itself; with the running maximum
+    # subtracted, like every other tile's scores, for a continued one)
+    L += solo((True, False), 0, 0, False, c_init=cont)
+    return L
+
+
+def state_store():
+    """Stream-K hand-over (the opening part of an item cut along the key axis): the un-normalised O, -m and the row sums into the slab instead of
+    the epilogue; the closing part continues from them, so every row is summed in exactly the order of an undivided item."""
+    L = ["s_nop 15", "s_nop 15", "s_mov_b32 %[so], 0"]
+    for k in range(32):
+        L += [f"v_accvgpr_read_b32 v{SA + 4 * k + r}, a{OA + 4 * k + r}" for r in range(4)]
+    L += ["s_nop 1"]
+    for k in range(32):
+        L += state_io("store", SA + 4 * k)
+    for qb in range(4):
+        L += [f"v_mov_b32 {T(qb)}, {NM(qb, 0)}", f"v_mov_b32 {T(4 + qb)}, {LA(qb, 0)}"]
+    L += ["s_nop 1"]
+    L += state_io("store", TMP) + state_io("store", TMP + 4)
+    L += ["s_waitcnt vmcnt(0)"]
     return L
 
 
@@ -594,8 +647,9 @@ def build():
          i = nt-1    LAST  : softmax(nt-1), masked                + O += V(nt-2) P(nt-2)
          tail              :                                        O += V(nt-1) P(nt-1)
          (nt == 1: ONLY = softmax(0) masked, then the tail)"""
-    L = prologue()
     MIDK, LASTK, TAILK = (True, True), (False, True), (False, True)
+    L = ["s_cmp_lg_u32 %[cont], 0", "s_cbranch_scc1 .Lcont_%="]
+    L += prologue()
     # hand-over behind S(0): frees K slot 0, fetches K(2) / V(0); the fragment addresses now point at the slots of tile 1
     L += sync_block(0)
     L += ["s_cmp_eq_u32 %[nt], 1", "s_cbranch_scc1 .Lonly_%="]
@@ -612,9 +666,15 @@ def build():
     # ONLY (nt == 1): softmax(0) masked, then the hand-over that waits for V(0)
     L += [".Lonly_%=:"]
     L += iteration(0, False, False, True, True, [(False, TAILK, ".Ltail0_%=")])
+    # CONT (stream-K; nt >= 2, the launcher's cuts keep it so): the closing part of a cut item -- its own prologue, then the first tile as an
+    # ordinary softmax pass (the rare rescale of the loaded O included) + S(t0 + 1), and on into the common MID / LAST code
+    L += [".Lcont_%=:"] + prologue(cont=True)
+    L += sync_block(0)
+    L += prereads((True, False), 1)
+    L += iteration(0, True, False, False, False, [(True, LASTK, ".Llast1_%="), (False, MIDK, ".Lmid1_%=")], force_rescale=True)
     for par in (1, 0):
         L += [f".Ltail{par}_%=:"] + solo((False, True), 0, par, True) + ["s_branch .Lepi_%="]
-    L += [".Lepi_%=:"] + epilogue()
+    L += [".Lepi_%=:", "s_cmp_lg_u32 %[hand], 0", "s_cbranch_scc1 .Lhand_%="] + epilogue() + ["s_branch .Lend_%=", ".Lhand_%=:"] + state_store() + [".Lend_%=:"]
     return L
 
 

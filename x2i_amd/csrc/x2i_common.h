@@ -53,6 +53,8 @@ struct X2IOptions {
                           // L2 (default); 0 = (filter row, kx, channel slice), the other kernels' order: bit-identical to them              X2I_CONV_KORDER
   int attn_variant;       // 0 = automatic (8-wave ping-pong when the grid fills the chip, else 4-wave); 1..8 = A/B   X2I_ATTN_VARIANT
   int attn_w16;           // 1 = x2i_attention_prefers_vt_perm may say yes (sampling path on attention_w16.hip; default); 0 = never; 2 = at any size   X2I_ATTN_W16
+  int attn_streamk;       // 1 = x2i_attention_vp_ws_bf16 cuts the items of a partly filled last round along the key axis over all CUs (chained through the
+                          // caller's workspace: bit-identical; default); 0 = whole items only                                X2I_ATTN_STREAMK
   int conv5_variant;      // matrix-core projector conv: 0 = automatic form choice; 1 = plain stages, 2 = pipelined, 3 = two row blocks   X2I_CONV5_VARIANT
   int fp8;                // 2 = x2i_ln_modulate_fp8 keeps its per-row kernel at the model's width (A/B against the four-rows-per-wave form); else unused   X2I_FP8
   int last_gemm_tile;     // read-only introspection for the parity tests: tile edge of the kernel the last GEMM / conv launch used

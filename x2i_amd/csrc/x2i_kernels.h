@@ -29,7 +29,7 @@ int x2i_launch_groupnorm_from_moments(const void* x, void* y, int B, long long H
 int x2i_launch_attention(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,
                          long long o_bs, float scale, hipStream_t stream, int out8 = 0, float oinv = 1.f, float* lse = nullptr);
 int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
-                             float scale_log2, int prescale, hipStream_t stream, float* lse);   // A/B: hand-scheduled, 16x16x32 (attention_w16.hip, attn_variant = 12)
+                             float scale_log2, int prescale, hipStream_t stream, float* lse, void* workspace = nullptr, long long workspace_bytes = 0);   // hand-scheduled, 16x16x32 (attention_w16.hip); workspace: the caller's stream-K workspace (or none)
 int x2i_launch_attention_16(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo, long long o_bs,
                             float scale_log2, hipStream_t stream, float* lse, int vperm);   // A/B: 16x16x32 MFMA shape (attention16.hip, attn_variant = 10 / 11)
 int x2i_launch_attention_pp(const void* Q, const void* K, const void* VT, void* O, int B, int H, int S, int Spad, int ldo,

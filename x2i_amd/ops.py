@@ -275,8 +275,12 @@ def attention_prefers_vt_perm(H, S, scale):
 def attention(Q, K, VT, out, B, H, S, Spad, ldo, o_batch_stride, scale, o_offset=0, vt_perm=False):
     lib = _lib.load()
     if vt_perm:
-        check(lib.x2i_attention_vp_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), B, H, S, Spad, ldo,
-                                        o_batch_stride, scale, _stream()), "attention_vp")
+        # with the stream-K workspace of this stream / graph (the GEMMs' one): a partly filled last round of work items is cut along the key axis over
+        # all CUs, chained through the workspace -- bit-identical to the undivided launch (include/x2i.h: x2i_attention_vp_ws_bf16)
+        ws = _sk_workspace()
+        check(lib.x2i_attention_vp_ws_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), B, H, S, Spad, ldo,
+                                           o_batch_stride, scale, C.c_void_p(ws.buf.data_ptr()) if ws is not None else None,
+                                           ws.nbytes if ws is not None else 0, _stream()), "attention_vp")
         return out
     check(lib.x2i_attention_bf16(_p(Q), _p(K), _p(VT), C.c_void_p(out.data_ptr() + o_offset * 2), B, H, S, Spad, ldo,
                                  o_batch_stride, scale, _stream()), "attention")
