@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
                                     "x2i_streamk_workspace_bytes", "x2i_groupnorm_moments_scratch_floats", "x2i_conv_moments_scratch_floats"}
     assert declared == bound, (declared ^ bound)
     ver = int(re.search(r"#define X2I_ABI_VERSION (\d+)", hdr).group(1))
-    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 4   # header, library and binding move together
+    assert lib.x2i_abi_version() == ver == _lib.ABI_VERSION == 5   # header, library and binding move together
     assert lib.x2i_streamk_workspace_bytes() == 4096 + 512 * 256 * 1024   # the caller-owned workspace: flags + 512 slabs of 256 KiB (round 5: the K split double-buffers)
 
 
@@ -243,6 +243,9 @@ def test_c_abi_argument_validation_returns_codes_without_a_gpu():
     # the span-permuted V^T: only the 16 x 16 x 32 kernel reads it, and that one wants 16-byte aligned output rows
     assert lib.x2i_attention_vp_bf16(fake, fake, fake, fake, 1, 1, 100, 100, 128, 12800, 0.1, None) < 0 and b"Spad" in lib.x2i_last_error()
     assert lib.x2i_attention_vp_bf16(fake, fake, None, fake, 1, 1, 128, 128, 128, 16384, 0.1, None) < 0
+    # ... and its stream-K form: a workspace that is too small or misaligned is an argument error (never a silent whole-item launch)
+    assert lib.x2i_attention_vp_ws_bf16(fake, fake, fake, fake, 1, 1, 128, 128, 128, 16384, 0.1, fake, 4096, None) < 0 and b"workspace" in lib.x2i_last_error()
+    assert lib.x2i_attention_vp_ws_bf16(fake, fake, fake, fake, 1, 1, 100, 100, 128, 12800, 0.1, None, 0, None) < 0 and b"Spad" in lib.x2i_last_error()
     _lib.set_option("attn_w16", 0)
     assert lib.x2i_attention_prefers_vt_perm(24, 4608, 0.6931471805599453) == 0
     _lib.set_option("attn_w16", 1)
