@@ -67,8 +67,9 @@ const char* x2i_last_error(void);
  * through the CALLER's workspace, x2i_gemm_args.workspace -- bit-identical to the one-tile kernel; 0, or no workspace: the peeled
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_w16" (1: x2i_attention_prefers_vt_perm may answer 1 -- the sampling path then uses the 16 x 16 x 32 attention kernel; 0: never; 2: at any size -- tests),
- * "attn_bwd_overlap" (1: the dQ pass of x2i_attention_bwd_bf16 runs on a library-owned side stream beside the dK / dV pass, forked
- * and joined by events on the caller's stream -- capturable; 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
+ * "attn_bwd_overlap" (1: the dQ and the dK / dV pass of x2i_attention_bwd_bf16 fill each other's partly filled last rounds -- as one launch when both run
+ * software-pipelined ("attn_bwd_pipe" = 1, the default), else the dQ pass on a library-owned side stream, forked and joined by events on the caller's
+ * stream (capturable); 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
  * "attn_streamk" (1: x2i_attention_vp_ws_bf16 cuts the items of a partly filled last round along the key axis, chained through the workspace; 0: whole items),
  * "attn_bwd_pipe" (1: the dK / dV pass runs software-pipelined -- element-wise section under the MFMAs; 0: phase after phase; bit-identical),
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --

@@ -21,8 +21,26 @@ def timeit(fn, iters=30):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def cut_sweep(B):
+    """measurement library only (X2I_LIB_VARIANT=ablate): the cut tile c of the last round's items, swept"""
+    H, S = 24, 4608
+    Spad, D = ops.pad128(S), H * 128
+    rnd = lambda *sh: torch.randn(sh, device="cuda").bfloat16()  # noqa: E731
+    Q, K, VT = (rnd(B, H, Spad, 128).float() * (1.4426950408889634 / math.sqrt(128))).bfloat16(), rnd(B, H, Spad, 128), rnd(B, H, 128, Spad)
+    O = torch.empty((B, S, D), device="cuda", dtype=torch.bfloat16)
+    for c in (0, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64):
+        _lib.set_option("attn_ablate", 100 + c if c else 0)
+        ts = sorted(timeit(lambda: ops.attention(Q, K, VT, O, B, H, S, Spad, D, S * D, math.log(2.0), vt_perm=True)) for _ in range(3))
+        print(f"B={B} cut at tile {c if c else 'auto'}: {ts[1] * 1e6:8.1f} us")
+    _lib.set_option("attn_ablate", 0)
+
+
 def main():
     H, S = 24, 4608
+    if "--cut" in sys.argv:
+        for a in [x for x in sys.argv[1:] if x != "--cut"]:
+            cut_sweep(int(a))
+        return
     for a in (sys.argv[1:] or ["1", "2", "4", "8"]):
         B = int(a)
         Spad, D = ops.pad128(S), H * 128

@@ -652,12 +652,11 @@ __device__ __forceinline__ void dkdv_tile(const char* __restrict__ cur, char* __
   });
 }
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ Q,
-                                                              const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
-                                                              const bf16_t* __restrict__ QT, const float* __restrict__ L2, const float* __restrict__ Dv,
-                                                              bf16_t* __restrict__ dV, bf16_t* __restrict__ dK, int H, int S, int Spad, float scale,
-                                                              float scale_log2, int nbatch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// (bid0 of T: the block's place among the pass's blocks -- blockIdx.x of gridDim.x in a launch of its own, an offset place in the fused launch)
+__device__ __forceinline__ void dkdv_body(char* smem, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ Q,
+                                          const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT, const bf16_t* __restrict__ QT,
+                                          const float* __restrict__ L2, const float* __restrict__ Dv, bf16_t* __restrict__ dV, bf16_t* __restrict__ dK,
+                                          int H, int S, int Spad, float scale, float scale_log2, int bid0, int T) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   Geo G;
@@ -667,9 +666,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __r
     G.k_row_off = kvm * 256; G.k_swz = kvm & 15; G.v_row_off = G.li * 128; G.v_swz = (G.li >> 1) & 7;
   }
   const int nblk = Spad / 128;
-  int bid = blockIdx.x;
+  int bid = bid0;
   {
-    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int blk = bid % nblk, h = (bid / nblk) % H, b = bid / (nblk * H);
@@ -724,6 +723,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __r
   const bool live = r0 < S;
   store_rows(dV + hoff + (long long)r0 * 128, oacc0, 1.f, G.hi, live);
   store_rows(dK + hoff + (long long)r0 * 128, oacc1, scale, G.hi, live);
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ Q,
+                                                              const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
+                                                              const bf16_t* __restrict__ QT, const float* __restrict__ L2, const float* __restrict__ Dv,
+                                                              bf16_t* __restrict__ dV, bf16_t* __restrict__ dK, int H, int S, int Spad, float scale,
+                                                              float scale_log2, int nbatch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  dkdv_body(smem, K, V, Q, dO, dOT, QT, L2, Dv, dV, dK, H, S, Spad, scale, scale_log2, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -815,11 +823,10 @@ __device__ __forceinline__ void dq_tile(const char* __restrict__ cur, char* __re
   });
 }
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ K,
-                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT, const float* __restrict__ L2,
-                                                            const float* __restrict__ Dv, bf16_t* __restrict__ dQ, int H, int S, int Spad,
-                                                            float scale, float scale_log2, int nbatch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void dq_body(char* smem, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ K,
+                                        const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT, const float* __restrict__ L2,
+                                        const float* __restrict__ Dv, bf16_t* __restrict__ dQ, int H, int S, int Spad, float scale, float scale_log2,
+                                        int bid0, int T) {
   constexpr int STAGE = 3 * TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -830,9 +837,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __res
     G.k_row_off = kvm * 256; G.k_swz = kvm & 15; G.v_row_off = G.li * 128; G.v_swz = (G.li >> 1) & 7;
   }
   const int nblk = (Spad + 255) / 256;
-  int bid = blockIdx.x;
+  int bid = bid0;
   {
-    const int T = gridDim.x, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int blk = bid % nblk, h = (bid / nblk) % H, b = bid / (nblk * H);
@@ -901,6 +908,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __res
   for (int qb = 0; qb < 2; ++qb) store_rows(dQ + hoff + (long long)r0[qb] * 128, oacc[qb], scale, G.hi, r0[qb] < S);
 }
 
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT, const float* __restrict__ L2,
+                                                            const float* __restrict__ Dv, bf16_t* __restrict__ dQ, int H, int S, int Spad,
+                                                            float scale, float scale_log2, int nbatch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  dq_body(smem, Q, dO, K, V, KT, L2, Dv, dQ, H, S, Spad, scale, scale_log2, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Both passes as ONE launch: the dQ blocks (the longer ones: 96 MFMAs per tile) in front, the dK / dV blocks behind them.  Each pass on its own ends in a
+// partly filled round of one-workgroup-per-CU blocks (B = 1: 1.7 and 3.4 rounds); in one launch the dispatcher fills a CU as soon as any block ends.
+__global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               const bf16_t* __restrict__ QT, const bf16_t* __restrict__ KT,
+                                                               const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
+                                                               const float* __restrict__ L2, const float* __restrict__ Dv, bf16_t* __restrict__ dQ,
+                                                               bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int H, int S, int Spad, float scale,
+                                                               float scale_log2, int n_dq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  if (b < n_dq) dq_body(smem, Q, dO, K, V, KT, L2, Dv, dQ, H, S, Spad, scale, scale_log2, b, n_dq);
+  else dkdv_body(smem, K, V, Q, dO, dOT, QT, L2, Dv, dV, dK, H, S, Spad, scale, scale_log2, b - n_dq, (int)gridDim.x - n_dq);
+}
+
 // D[b][h][s] = sum_d dO[b][s][h*128 + d] * O[b][s][h*128 + d] for s < S, 0 for the padding rows; 16 lanes x 8 elements per (token, head)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, long long do_bs, int lddo, const bf16_t* __restrict__ O,
                                                             long long o_bs, int ldo, float* __restrict__ Dv, int H, int S, int Spad) {
@@ -941,6 +970,18 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
   // The dQ pass and the dK / dV pass are independent (both read Q, K, V, dO and the statistics; they write different tensors) and each
   // ends in a partly filled round of one-workgroup-per-CU blocks (B = 1: 1.7 and 3.4 rounds): dQ goes to a side stream, forked and
   // joined by events, so that the two launches fill each other's tails.  (Option attn_bwd_overlap = 0: one after the other.)
+  if (x2i_options().attn_bwd_pipe && x2i_options().attn_bwd_dq64 && x2i_options().attn_bwd_overlap) {
+    // the software-pipelined passes as ONE launch (attn_bwd_fused_kernel): dQ blocks in front, dK / dV blocks behind them -- each CU takes the next
+    // block as soon as one ends, whichever pass it belongs to (the two-stream form below leaves that to two queues that each want whole CUs)
+    const int shm = 2 * KV_STAGE;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_fused_kernel, shm);
+    if (rc) return rc;
+    const int n_dq = ((Spad + 255) / 256) * H * B, n_kv = (Spad / 128) * H * B;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(n_dq + n_kv), dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)QT,
+                       (const bf16_t*)KT, (const bf16_t*)dOh, (const bf16_t*)dOT, (const float*)L2, Dv, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, H, S, Spad, scale,
+                       scale_log2, n_dq);
+    return x2i_check_launch("attention_bwd (fused passes)");
+  }
   hipStream_t side = stream;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   const bool overlap = x2i_options().attn_bwd_overlap && x2i_side_stream(stream, &side, &ev_fork, &ev_join) &&

@@ -197,6 +197,9 @@ int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void*
     const int nt = (S + 63) / 64, r8 = (nitems % cus) >> 3, others = (cus >> 3) - r8;
     const int m = (r8 + others - 1) / others;
     int c = (m * nt + (m - 1) * SKA_UNIT_TILES + (m + 1) / 2) / (m + 1);
+#ifdef X2I_ABLATION
+    if (x2i_options().attn_ablate >= 100) c = x2i_options().attn_ablate - 100;   // measurement library only (tools/attn_sk_bench.py --cut): the cut tile
+#endif
     c = std::min(std::max(c, SKA_MIN_TILES), nt - SKA_MIN_TILES);
     hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
                        ldo, o_bs, scale_log2, B, lse, prescale, nitems, (char*)workspace + 4096, (unsigned*)workspace, c, m);

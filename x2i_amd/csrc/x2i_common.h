@@ -28,7 +28,7 @@ struct X2IOptions {
   int gemm_gm;            // 0 = per-shape XCD patch height; > 0 forces it                                 X2I_GEMM_GM
   int gemm_split_tail;    // 1 = peel a thin last round into a 128^2 launch (default)                      X2I_GEMM_NOSPLIT=1 -> 0
   int gemm_w4;            // 1 = plain 256^2 launches take the 4-wave hand-scheduled kernel (gemm256w.hip, default); 0 = 8-wave gemm256.hip   X2I_GEMM_W4
-  int attn_bwd_overlap;   // 1 = the dQ pass runs on a side stream beside the dK / dV pass (their partly filled last rounds fill each other)
+  int attn_bwd_overlap;   // 1 = the dQ and dK / dV passes fill each other's partly filled last rounds: one fused launch (pipelined kernels) or a side stream (the older ones)
   int attn_bwd_dq64;      // 1 = the dQ pass of the attention backward keeps 64 query rows per wave (0: 32, A/B; bit-identical)
   int attn_bwd_pipe;      // 1 = the dK / dV pass runs the software-pipelined kernel (attn_bwd_dkdv_kernel: element-wise section under the MFMAs; default);
                           // 0 = attn_bwd_kernel<1> (A/B; bit-identical)                                          X2I_ATTN_BWD_PIPE
