@@ -1,9 +1,10 @@
 // Flash attention forward, hand-scheduled, on v_mfma_f32_16x16x32_bf16: attention_w4.hip's organisation (ONE wave per SIMD, four waves x 64
 // query rows per workgroup, the whole kernel one generated asm statement: gen_attn_w16.py -> attn_w16_loop.inc) on the MFMA shape the matrix
-// pipe sustains 11-14 % faster at this part's power cap.  A/B kernel (attn_variant = 12): V^T must arrive
-// with its keys permuted within every 32-key span (position kk holds key 16 ((kk >> 2) & 1) + 4 (kk >> 3) + (kk & 3)) -- the caller's
-// job until the fused QKV epilogue writes that order; bf16 output only.  Stands behind F.scaled_dot_product_attention of
-// FluxAttnProcessor2_0 (lightcontrol/lightcontrol_flux.py:92-95,173-177).  This file only computes the per-lane addresses.
+// pipe sustains 11-14 % faster at this part's power cap.  The sampling path's attention kernel
+// (x2i_attention_vp_bf16 / x2i_attention_vp_ws_bf16; attn_variant = 12 forces it for tools and tests): V^T must arrive with its keys permuted
+// within every 32-key span (position kk holds key 16 ((kk >> 2) & 1) + 4 (kk >> 3) + (kk & 3)) -- the fused QKV epilogues write that order
+// (x2i_qkv_desc.vt_perm); bf16 output only.  Stands behind F.scaled_dot_product_attention of FluxAttnProcessor2_0
+// (lightcontrol/lightcontrol_flux.py:92-95,173-177).  This file computes the per-lane addresses and, in the stream-K form, the unit lists.
 #include "x2i_common.h"
 #include "x2i_kernels.h"
 #include "attn_w16_loop.inc"
@@ -16,7 +17,7 @@ constexpr int SKA_FLAG0 = 768;              // workspace flags [768, 1024): K ti
 constexpr int SKA_ERR_SLOT = 256;           // the workspace's give-up marker (csrc/gemm_device.h SK_ERR_SLOT)
 constexpr int SKA_MIN_TILES = 4;            // no part shorter than this: a cut that close to an item edge moves onto it
 constexpr int SKA_G = 256;                  // workgroups of a stream-K launch (= CUs of the part)
-constexpr int SKA_UNIT_TILES = 7;           // what starting + finishing a unit costs, in key tiles (prologue, pipeline fill / drain, epilogue or hand-over: ~9 us)
+constexpr int SKA_UNIT_TILES = 11;          // what starting + finishing a unit costs, in key tiles (prologue, pipeline fill / drain, epilogue or hand-over); from the cut sweep of tools/attn_sk_bench.py --cut (profiles/r06ze_*)
 
 // SK = false: one work item (256 queries of one head) per workgroup, from its first key tile to its last -- the kernel of round 5.
 // SK = true (stream-K, round 6): one workgroup per CU.  nitems = R G + r: every workgroup takes R whole items (item j G + w in round j, the
@@ -34,7 +35,7 @@ template <bool SK>
 __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ VT,
                                                        bf16_t* __restrict__ O, int H, int S, int Spad, int ldo, long long o_bs, float scale_log2,
                                                        int nbatch, float* __restrict__ lse, int prescale, int nitems, char* __restrict__ slabs,
-                                                       unsigned* __restrict__ flags, int sk_c, int sk_m) {
+                                                       unsigned* __restrict__ flags, int sk_c) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -202,12 +203,12 @@ int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void*
 #endif
     c = std::min(std::max(c, SKA_MIN_TILES), nt - SKA_MIN_TILES);
     hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
-                       ldo, o_bs, scale_log2, B, lse, prescale, nitems, (char*)workspace + 4096, (unsigned*)workspace, c, m);
+                       ldo, o_bs, scale_log2, B, lse, prescale, nitems, (char*)workspace + 4096, (unsigned*)workspace, c);
     return x2i_check_launch("attention (w16, stream-K)");
   }
   const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<false>, 65536);
   if (rc) return rc;
   hipLaunchKernelGGL(attn_w16_kernel<false>, dim3(nitems), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad, ldo,
-                     o_bs, scale_log2, B, lse, prescale, nitems, (char*)nullptr, (unsigned*)nullptr, 0, 0);
+                     o_bs, scale_log2, B, lse, prescale, nitems, (char*)nullptr, (unsigned*)nullptr, 0);
   return x2i_check_launch("attention (w16)");
 }

@@ -17,6 +17,11 @@ shape: the matrix pipe alone sustains 11-14 % more FLOP/s at this part's power c
   * a query's keys sit in four lanes (g = 0 .. 3): the tile maximum is combined with v_permlane16_swap + v_permlane32_swap, the row sums stay
     per lane until the epilogue; the -m copies are 4 registers per query block (every register of a lane's accumulator is the same query).
 
+Round 6 (stream-K, attention_w16.hip): the program can START at any key tile (%[so0] / %[so20]) from a state left in memory (%[cont]: prologue(cont=True) --
+O, -m and the row sums come from the slab %[sr], S(t0) gets C = -m, and the first iteration is an ordinary softmax pass with the rare rescale of the loaded O)
+and can END by leaving that state instead of the epilogue (%[hand]: state_store()).  An item cut along the key axis into chained parts is summed in exactly
+the order of the undivided item: bit-identical.
+
 `python gen_attn_w16.py` rewrites attn_w16_loop.inc (committed; tests/test_host_cpu.py regenerates and compares).
 """
 import os
@@ -521,10 +526,6 @@ def prologue(cont=False):
     for qb in range(4):
         L += [f"v_mov_b32 v{ALPHA + qb}, 1.0"]
     L += ["s_mov_b32 %[fl], 0"]
-    if not cont:
-        for db in range(8):
-            for qb in range(4):
-                L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(4)]
     # Q fragments (second operand of S^T = K Q^T): lane holds Q[q0 + 16 qb + c][32 ds + 8 g .. + 8]
     for qb in range(4):
         for ds in range(4):
@@ -550,6 +551,10 @@ def prologue(cont=False):
             L += [f"v_mov_b32 {LA(qb, r)}, {T(4 + qb)}" for r in range(4)]
         L += [f"v_accvgpr_write_b32 a{OA + i}, v{SA + i}" for i in range(64)]
     else:
+        # O = 0 under the flight of Q and the first K tiles (in front of the loads it was 512 cycles before the first request left)
+        for db in range(8):
+            for qb in range(4):
+                L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(4)]
         L += ["s_waitcnt vmcnt(8)"]
     # under the K flight: Q fragments into the accumulator file.  %[pres] == 0: Q already carries scale * log2 e (x2i_qkv_desc.q_scale);
     # otherwise Q~ = bf16(Q * scale * log2 e) here (a second rounding of Q).  Either way p = exp2(s') with s' = q~ . k - m
