@@ -527,17 +527,21 @@ def prologue(cont=False):
         L += [f"v_mov_b32 v{ALPHA + qb}, 1.0"]
     L += ["s_mov_b32 %[fl], 0"]
     # Q fragments (second operand of S^T = K Q^T): lane holds Q[q0 + 16 qb + c][32 ds + 8 g .. + 8]
+    PL = []
     for qb in range(4):
         for ds in range(4):
             b = QTMP + (qb * 4 + ds) * 4
-            L.append(f"global_load_dwordx4 v[{b}:{b + 3}], %[qo{qb}], %[qp] offset:{ds * 64}")
+            PL.append(f"global_load_dwordx4 v[{b}:{b + 3}], %[qo{qb}], %[qp] offset:{ds * 64}")
     # K(t0) -> slot 0, K(t0 + 1) -> slot 1 (rows behind Spad read as zero)
-    L += ["s_mov_b32 %[so], %[so0]"]
+    PL += ["s_mov_b32 %[so], %[so0]"]
     for j in range(4):
-        L += [f"s_add_u32 m0, %[kdst], {j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
-    L += ["s_add_u32 %[so], %[so0], 0x4000"]
+        PL += [f"s_add_u32 m0, %[kdst], {j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
+    PL += ["s_add_u32 %[so], %[so0], 0x4000"]
     for j in range(4):
-        L += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
+        PL += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
+    if "noprold" in ABLS:      # measurement only (tools/attn_item_parts_build.sh): no Q loads, no first K tiles -- what the prologue's memory latency costs an item
+        PL = [x for x in PL if not (x.startswith("global_load") or x.startswith("buffer_load"))]
+    L += PL
     if cont:
         # the slab: O pieces 0 .. 15 through score set 0 (the raw Q fragments sit in set 1), -m and l through the temporaries
         L += ["s_mov_b32 %[so], 0"]
@@ -679,7 +683,7 @@ def build():
     L += iteration(0, True, False, False, False, [(True, LASTK, ".Llast1_%="), (False, MIDK, ".Lmid1_%=")], force_rescale=True)
     for par in (1, 0):
         L += [f".Ltail{par}_%=:"] + solo((False, True), 0, par, True) + ["s_branch .Lepi_%="]
-    L += [".Lepi_%=:", "s_cmp_lg_u32 %[hand], 0", "s_cbranch_scc1 .Lhand_%="] + epilogue() + ["s_branch .Lend_%=", ".Lhand_%=:"] + state_store() + [".Lend_%=:"]
+    L += [".Lepi_%=:", "s_cmp_lg_u32 %[hand], 0", "s_cbranch_scc1 .Lhand_%="] + ([] if "noepi" in ABLS else epilogue()) + ["s_branch .Lend_%=", ".Lhand_%=:"] + state_store() + [".Lend_%=:"]   # (noepi: measurement only)
     return L
 
 
