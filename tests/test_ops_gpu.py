@@ -534,6 +534,11 @@ def test_attention_streamk_bit_identical(ops, opt, B, H, S, pres):
     ws = ops._sk_workspace()
     assert int(ws.buf[:4096].view(torch.int32).abs().sum()) == 0      # every flag returned to zero, no give-up marker
     ops.streamk_check(sync=True)
+    # without a workspace: the persistent form with whole items only (each unit's exit requests the next item's Q block and first K tiles)
+    with ops.streamk_scope(None):
+        out = torch.full((B, S, D), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.attention(Q, K, VTP, out, B, H, S, Spad, D, S * D, scale, vt_perm=True)
+    assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 136), (1, 2, 1152), (1, 3, 700), (2, 1, 2000), (1, 24, 4608)])

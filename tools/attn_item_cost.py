@@ -11,7 +11,15 @@ from tools.attn_sk_bench import timeit  # noqa: E402
 
 
 def main():
-    _lib.set_option("attn_streamk", 0)
+    for form in ("whole items, one workgroup each", "persistent, whole items"):
+        _lib.set_option("attn_streamk", 0 if form.startswith("whole") else 1)
+        print("==", form)
+        with ops.streamk_scope(None):
+            one_form()
+    _lib.set_option("attn_streamk", 1)
+
+
+def one_form():
     pts = []
     for (B, H, S) in ((16, 27, 1024), (8, 27, 2048), (4, 27, 4096), (4, 24, 4608)):
         Spad, D = ops.pad128(S), H * 128
@@ -27,7 +35,6 @@ def main():
     b = (t1 - t0) / (n1 - n0)
     a = t0 - b * n0
     print(f"per round: {a * 1e6:.2f} us + {b * 1e6:.3f} us per key tile  ->  an item's fixed cost = {a / b:.1f} key tiles")
-    _lib.set_option("attn_streamk", 1)
 
 
 if __name__ == "__main__":

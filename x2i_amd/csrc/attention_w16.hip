@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ O, int H, int S, int Spad, int ldo, long long o_bs, float scale_log2,
                                                        int nbatch, float* __restrict__ lse, int prescale, int nitems, char* __restrict__ slabs,
                                                        unsigned* __restrict__ flags, int sk_c) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [2][16 KiB] | V^T ring [2][16 KiB] | persistent form: the next item's Q block [4 waves][16 KiB]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,36 +77,59 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
   // ---- this workgroup's units: (item id, first key tile, tiles, slab); SK = false: one whole item
   struct Unit { int id, k0, len, slab; };
   const int G = gridDim.x, w = blockIdx.x;
-  int R = 0, n_part = 0, part_e0 = 0, part_step = 0, part_big = 0;
+  int R = 0, n_part = 0, part_e0 = 0, part_step = 0, part_big = 0, r8 = 1;
   if constexpr (SK) {
     R = nitems / G;
-    const int r8 = (nitems - R * G) >> 3;               // last-round items per XCD (the launcher: r % 8 == 0, 0 < r8 < 32)
-    const int x = w & 7, i = w >> 3, others = (G >> 3) - r8;
-    if (i < r8) { part_big = 1; n_part = 1; part_e0 = x * r8 + i; }
-    else { const int k = i - r8; n_part = k < r8 ? (r8 - 1 - k) / others + 1 : 0; part_e0 = x * r8 + k; part_step = others; }
+    const int r = nitems - R * G;
+    if (sk_c > 0) {                                     // the last round's items cut along the key axis (r % 8 == 0, 0 < r8 < 32: launcher)
+      r8 = r >> 3;
+      const int x = w & 7, i = w >> 3, others = (G >> 3) - r8;
+      if (i < r8) { part_big = 1; n_part = 1; part_e0 = x * r8 + i; }
+      else { const int k = i - r8; n_part = k < r8 ? (r8 - 1 - k) / others + 1 : 0; part_e0 = x * r8 + k; part_step = others; }
+    } else {                                            // whole items only (no workspace, or nothing worth cutting): item R G + w closes the list
+      n_part = w < r ? 1 : 0;
+    }
   }
   const int n_units = SK ? R + n_part : 1;
-  for (int ui = 0; ui < n_units; ++ui) {
+  auto unit_at = [&](int ui) -> Unit {
     Unit u = {(int)blockIdx.x, 0, nt_full, -1};
     if constexpr (SK) {
+      if (ui >= n_units) return Unit{-1, 0, 0, -1};
       // an opening part runs in front of the workgroup's LAST whole item: published before any closing part is reached (those follow R whole
       // items), and only that one round of the XCD runs in two phase groups (in front of all R: -2 % at ten rounds instead of +3 %)
       const int pos_big = R > 0 ? R - 1 : 0;
       const int j = ui - ((part_big && ui > pos_big) ? 1 : 0);                   // whole item of round j ...
       u = Unit{w + j * G, 0, nt_full, -1};
-      if (part_big && ui == pos_big) u = Unit{R * G + (part_e0 % ((nitems - R * G) >> 3)) * 8 + part_e0 / ((nitems - R * G) >> 3), 0, sk_c, part_e0};
-      else if (!part_big && ui >= R) {                  // ... or closing part ui - R
-        const int E = part_e0 + (ui - R) * part_step, r8 = (nitems - R * G) >> 3;
-        u = Unit{R * G + (E % r8) * 8 + E / r8, sk_c, nt_full - sk_c, E};
+      if (sk_c > 0) {
+        if (part_big && ui == pos_big) u = Unit{R * G + (part_e0 % r8) * 8 + part_e0 / r8, 0, sk_c, part_e0};
+        else if (!part_big && ui >= R) {                  // ... or closing part ui - R
+          const int E = part_e0 + (ui - R) * part_step;
+          u = Unit{R * G + (E % r8) * 8 + E / r8, sk_c, nt_full - sk_c, E};
+        }
       }
       u = Unit{uni(u.id), uni(u.k0), uni(u.len), uni(u.slab)};
     }
-    int bid = u.id;
-    {
-      const int T = nitems, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int qt = bid % nqt, h = (bid / nqt) % H, b = bid / (nqt * H);
+    return u;
+  };
+  // (b, h, first query) of a work item id: the XCD-contiguous order of every attention kernel here
+  auto place = [&](int id, int& b, int& h, int& qt) {
+    int bid = id;
+    const int T = nitems, q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    qt = bid % nqt; h = (bid / nqt) % H; b = bid / (nqt * H);
+  };
+  auto mk_rsrc = [&](const void* ptr, uint32_t bytes) {   // (workgroup-uniform by construction; readfirstlane makes it provable)
+    const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
+    const unsigned long long au = ((unsigned long long)(unsigned)uni((int)(a >> 32)) << 32) | (unsigned)uni((int)(a & 0xffffffffu));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)au, 0, (uint32_t)uni((int)bytes), 0x00020000);
+  };
+  const uint32_t qdst = __builtin_amdgcn_readfirstlane(sbase + 65536 + wave * 1024);    // the next item's Q block: LDS behind the rings (persistent form)
+  const uint32_t qdel = __builtin_amdgcn_readfirstlane(65536 + wave * 16384);           // ... read back per wave through the K fragment addresses
+  uint32_t pre = 0;
+  for (int ui = 0; ui < n_units; ++ui) {
+    const Unit u = unit_at(ui);
+    int b, h, qt;
+    place(u.id, b, h, qt);
     const int q0 = qt * 256 + wave * 64;
     const long long bh = (long long)b * H + h;
     const bf16_t* Qh = Q + bh * Spad * 128;
@@ -153,6 +176,22 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
         __syncthreads();
       }
     }
+    // the next unit's first loads, requested in front of this unit's epilogue (persistent form; a fresh item behind a unit that ends in an epilogue,
+    // Q already scaled: the kernel's own scaling needs Q in registers)
+    uint32_t nxt = 0, nso0 = 0;
+    __amdgpu_buffer_rsrc_t nq_rsrc = k_rsrc, nk_rsrc = k_rsrc;
+    if constexpr (SK) {
+      const Unit un = unit_at(ui + 1);
+      if (un.id >= 0 && un.k0 == 0 && hand == 0 && prescale == 0) {
+        int nb, nh, nqt_;
+        place(un.id, nb, nh, nqt_);
+        const long long nbh = (long long)nb * H + nh;
+        const int rows = min(256, Spad - nqt_ * 256);
+        nq_rsrc = mk_rsrc(Q + (nbh * Spad + (long long)nqt_ * 256) * 128, (uint32_t)rows * 256u);
+        nk_rsrc = mk_rsrc(K + nbh * Spad * 128, (uint32_t)Spad * 256u);
+        nxt = 1;
+      }
+    }
     uint32_t s_so, s_so2, s_fl;
     unsigned long long s_cnd, s_exs;
     asm volatile(X2I_ATTN_W16_TEXT
@@ -162,8 +201,10 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
                    [kdst] "s"(kdst), [vdst] "s"(vdst), [qo0] "v"(qo[0]), [qo1] "v"(qo[1]), [qo2] "v"(qo[2]), [qo3] "v"(qo[3]), [lo] "v"(lo_), [qv] "v"(q),
                    [lim] "v"(lim), [hi] "v"(g), [kr] "s"(k_rsrc), [vr] "s"(v_rsrc), [qp] "s"(Qh), [op] "s"(Ob), [lp] "s"(Lb), [sc] "s"(scale_log2),
                    [sS] "s"(S), [sSp] "s"(Spad), [nt] "s"(nt), [ostep] "s"(ostep), [lsef] "s"(lsef), [thr] "s"(thr), [pres] "s"(prescale),
-                   [so0] "s"(so0), [so20] "s"(so20), [cont] "s"(cont), [hand] "s"(hand), [sr] "s"(s_rsrc), [sto] "v"(sto)
+                   [so0] "s"(so0), [so20] "s"(so20), [cont] "s"(cont), [hand] "s"(hand), [sr] "s"(s_rsrc), [sto] "v"(sto), [pre] "s"(pre), [nxt] "s"(nxt),
+                   [nqr] "s"(nq_rsrc), [nkr] "s"(nk_rsrc), [nso0] "s"(nso0), [qdst] "s"(qdst), [qdel] "s"(qdel)
                  : "memory", "vcc", "scc", "m0", X2I_ATTN_W16_CLOBBERS);
+    pre = nxt;
     if constexpr (SK) {
       __syncthreads();   // every wave is done with the K / V^T rings (and, for a hand-over, has drained its slab stores) before the next unit
       if (tid == 0 && u.slab >= 0) {
@@ -178,8 +219,9 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
 }  // namespace
 
 // stream-K form: possible (nitems > CUs, a last round of a multiple of 8 items whose shares are long enough) and wanted (a workspace was handed over)?
+// the last round's items cut along the key axis: possible (a last round of a multiple of 8 items, key sequences long enough) and a workspace was handed over?
 static bool w16_streamk(int nitems, int nt, int cus, void* ws, long long ws_bytes) {
-  if (!ws || !x2i_options().attn_streamk || cus != SKA_G || nitems <= cus || nt < 4 * SKA_MIN_TILES) return false;
+  if (!ws || nt < 4 * SKA_MIN_TILES) return false;
   const int r = nitems % cus;
   if (r == 0 || (r & 7)) return false;
   return ws_bytes >= 4096 + (long long)r * SKA_SLAB_BYTES && !(((uintptr_t)ws) & 255);
@@ -191,20 +233,26 @@ int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void*
   if ((((uintptr_t)O) & 15) || (ldo & 7) || (o_bs & 7) || (long long)S * ldo * 2 >= 0x7f000000LL) return X2I_ERR_STATE;
   const int nitems = ((S + 255) / 256) * H * B;
   const int cus = x2i_num_cus();
-  if (!lse && w16_streamk(nitems, (S + 63) / 64, cus, workspace, workspace_bytes)) {
-    const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<true>, 65536);
+  // persistent form (one workgroup per CU walks its items, each unit's exit requests the next one's first loads; option attn_streamk): launches of more
+  // than one round on the 256-CU part; with the caller's workspace the last round's items are cut along the key axis as well
+  if (!lse && x2i_options().attn_streamk && cus == SKA_G && nitems > cus) {
+    const int shm = 65536 + 65536;
+    const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<true>, shm);
     if (rc) return rc;
-    // the cut: m = closing parts per closing workgroup, c from c + u = m (nt - c + u) (see the kernel's header)
-    const int nt = (S + 63) / 64, r8 = (nitems % cus) >> 3, others = (cus >> 3) - r8;
-    const int m = (r8 + others - 1) / others;
-    int c = (m * nt + (m - 1) * SKA_UNIT_TILES + (m + 1) / 2) / (m + 1);
+    int c = 0;
+    if (w16_streamk(nitems, (S + 63) / 64, cus, workspace, workspace_bytes)) {
+      // the cut: m = closing parts per closing workgroup, c from c + u = m (nt - c + u) (see the kernel's header)
+      const int nt = (S + 63) / 64, r8 = (nitems % cus) >> 3, others = (cus >> 3) - r8;
+      const int m = (r8 + others - 1) / others;
+      c = (m * nt + (m - 1) * SKA_UNIT_TILES + (m + 1) / 2) / (m + 1);
 #ifdef X2I_ABLATION
-    if (x2i_options().attn_ablate >= 100) c = x2i_options().attn_ablate - 100;   // measurement library only (tools/attn_sk_bench.py --cut): the cut tile
+      if (x2i_options().attn_ablate >= 100) c = x2i_options().attn_ablate - 100;   // measurement library only (tools/attn_sk_bench.py --cut): the cut tile
 #endif
-    c = std::min(std::max(c, SKA_MIN_TILES), nt - SKA_MIN_TILES);
-    hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), 65536, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
-                       ldo, o_bs, scale_log2, B, lse, prescale, nitems, (char*)workspace + 4096, (unsigned*)workspace, c);
-    return x2i_check_launch("attention (w16, stream-K)");
+      c = std::min(std::max(c, SKA_MIN_TILES), nt - SKA_MIN_TILES);
+    }
+    hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
+                       ldo, o_bs, scale_log2, B, lse, prescale, nitems, c ? (char*)workspace + 4096 : (char*)nullptr, c ? (unsigned*)workspace : (unsigned*)nullptr, c);
+    return x2i_check_launch("attention (w16, persistent)");
   }
   const int rc = x2i_ensure_dynamic_smem((const void*)attn_w16_kernel<false>, 65536);
   if (rc) return rc;

@@ -541,6 +541,10 @@ def prologue(cont=False):
         PL += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[kr], %[so] offen lds"]
     if "noprold" in ABLS:      # measurement only (tools/attn_item_parts_build.sh): no Q loads, no first K tiles -- what the prologue's memory latency costs an item
         PL = [x for x in PL if not (x.startswith("global_load") or x.startswith("buffer_load"))]
+    if not cont:
+        # %[pre] (persistent form): the previous unit's exit already requested this item's Q block (into the LDS area behind the rings, K-tile image per
+        # wave) and its first two K tiles -- behind that unit's epilogue, whose final wait covered them
+        L += ["s_cmp_lg_u32 %[pre], 0", "s_cbranch_scc1 .Lpre_%="]
     L += PL
     if cont:
         # the slab: O pieces 0 .. 15 through score set 0 (the raw Q fragments sit in set 1), -m and l through the temporaries
@@ -570,6 +574,18 @@ def prologue(cont=False):
         L += [f"v_lshlrev_b32 {T(0)}, 16, v{QTMP + i}", f"v_and_b32 {T(1)}, 0xffff0000, v{QTMP + i}",
               f"v_mul_f32 {T(0)}, %[sc], {T(0)}", f"v_mul_f32 {T(1)}, %[sc], {T(1)}",
               f"v_cvt_pk_bf16_f32 {T(0)}, {T(0)}, {T(1)}", f"v_accvgpr_write_b32 a{QF + i}, {T(0)}"]
+    if not cont:
+        L += ["s_branch .Lqdone_%=", ".Lpre_%=:"]
+        for db in range(8):
+            for qb in range(4):
+                L += [f"v_accvgpr_write_b32 {O(db, qb, r)}, 0" for r in range(4)]
+        L += ["s_barrier"]                                 # every wave's pieces of the Q image have landed (each waited for its own at the previous exit)
+        L += [f"v_add_u32 {T(ds)}, %[qdel], %[ka{ds}]" for ds in range(4)]
+        for qb in range(4):
+            for ds in range(4):
+                b = QF + (qb * 4 + ds) * 4
+                L.append(f"ds_read_b128 a[{b}:{b + 3}], {T(ds)} offset:{qb * 4096}")
+        L += ["s_waitcnt lgkmcnt(0)"]
     L += [f".Lqdone{sfx}_%=:"]
     if cont:
         # O pieces 16 .. 31 (accumulator registers 64 .. 127) through score set 1, now that the raw Q fragments have left it
@@ -583,6 +599,26 @@ def prologue(cont=False):
     # S(t0) = K(t0) Q~^T alone (score set 0; raw for a fresh item: the first softmax subtracts its maxima itself; with the running maximum
     # subtracted, like every other tile's scores, for a continued one)
     L += solo((True, False), 0, 0, False, c_init=cont)
+    return L
+
+
+def next_item_requests():
+    """%[nxt] (persistent form): in FRONT of the epilogue, request the next work item's Q block (%[nqr]: 256 rows; as four K-tile images, one per wave's 64
+    rows, into the LDS area at %[qdst]) and its first two K tiles (%[nkr], %[nso0]; ring slots 0 / 1): the epilogue's ~3 us of conversions and stores hide
+    the ~3.7 us these loads cost an item when its prologue has to wait for them (tools/attn_item_cost.py on the noepi / noprold builds).  The stale
+    pieces behind the last tile (sync_dma) must have landed in every wave before a ring slot is written again: wait + barrier first."""
+    L = ["s_cmp_lg_u32 %[nxt], 0", "s_cbranch_scc0 .Lnonxt_%=", "s_waitcnt vmcnt(0)", "s_barrier"]
+    for t in range(4):
+        L += [f"s_mov_b32 %[so], {t * 16384}"]
+        for j in range(4):
+            L += [f"s_add_u32 m0, %[qdst], {t * 16384 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[nqr], %[so] offen lds"]
+    L += ["s_mov_b32 %[so], %[nso0]"]
+    for j in range(4):
+        L += [f"s_add_u32 m0, %[kdst], {j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[nkr], %[so] offen lds"]
+    L += ["s_add_u32 %[so], %[nso0], 0x4000"]
+    for j in range(4):
+        L += [f"s_add_u32 m0, %[kdst], {0x4000 + j * 4096}", "s_nop 0", f"buffer_load_dwordx4 %[kd{j}], %[nkr], %[so] offen lds"]
+    L += [".Lnonxt_%=:"]
     return L
 
 
@@ -683,7 +719,7 @@ def build():
     L += iteration(0, True, False, False, False, [(True, LASTK, ".Llast1_%="), (False, MIDK, ".Lmid1_%=")], force_rescale=True)
     for par in (1, 0):
         L += [f".Ltail{par}_%=:"] + solo((False, True), 0, par, True) + ["s_branch .Lepi_%="]
-    L += [".Lepi_%=:", "s_cmp_lg_u32 %[hand], 0", "s_cbranch_scc1 .Lhand_%="] + ([] if "noepi" in ABLS else epilogue()) + ["s_branch .Lend_%=", ".Lhand_%=:"] + state_store() + [".Lend_%=:"]   # (noepi: measurement only)
+    L += [".Lepi_%=:", "s_cmp_lg_u32 %[hand], 0", "s_cbranch_scc1 .Lhand_%="] + next_item_requests() + ([] if "noepi" in ABLS else epilogue()) + ["s_branch .Lend_%=", ".Lhand_%=:"] + state_store() + [".Lend_%=:"]   # (noepi: measurement only)
     return L
 
 
