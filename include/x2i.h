@@ -17,9 +17,8 @@
  *     workspace_size query") -- weights are consumed in the reference's own nn.Linear [N,K] layout, fused only by
  *     row-concatenation on the host side, and every scratch buffer is a caller-owned argument sized by a query:
  *     x2i_groupnorm_scratch_floats, x2i_streamk_workspace_bytes (x2i_gemm_args.workspace, x2i_attention_vp_ws_bf16).  Process-wide state, all of it
- *     mutex-protected: the option table below, a per-kernel "dynamic LDS size already raised" cache, and ONE HIP object set per
- *     device that holds no memory -- a side stream with two events, created on the first x2i_attention_bwd_bf16 call that runs
- *     its dQ pass beside the dK / dV pass (option "attn_bwd_overlap"; training row N4 only, never on the sampling path).
+ *     mutex-protected: the option table below and a per-kernel "dynamic LDS size already raised" cache.  (The measurement library additionally keeps one
+ *     side stream with two events per device for the two-stream A/B form of the attention backward.)
  *   - ABI version 5 (x2i_abi_version; 5 adds x2i_attention_vp_ws_bf16 -- no struct changed; 4 appended `w_group` to x2i_gemm_args, 0 = what version 3 did, and added the *_grouped entry points).  Since version 1: x2i_gemm_args grew `workspace` / `workspace_bytes`, x2i_qkv_desc `q_scale`
  *     and x2i_conv_desc a ninth field (version 2); version 3 re-defines that field as `pad_w_p1` (0 = same padding as `pad`, so that a
  *     zero-initialised descriptor means what it meant in version 1), appends `out_w`, `out_h`, `out_row_pitch` (0 = computed / dense) and the `moments` fields (NULL = off) to it, gives `up` the value 2, and appends `vt_perm` to x2i_qkv_desc (0 = the old layout).  A caller built against another version must not load this
@@ -67,11 +66,11 @@ const char* x2i_last_error(void);
  * through the CALLER's workspace, x2i_gemm_args.workspace -- bit-identical to the one-tile kernel; 0, or no workspace: the peeled
  * 128^2 tail launch), "gemm_pair" (1: x2i_gemm_pair_bf16 / x2i_gemm_qkv_pair_bf16 group their two problems into one launch when they can),
  * "attn_w16" (1: x2i_attention_prefers_vt_perm may answer 1 -- the sampling path then uses the 16 x 16 x 32 attention kernel; 0: never; 2: at any size -- tests),
- * "attn_bwd_overlap" (1: the dQ and the dK / dV pass of x2i_attention_bwd_bf16 fill each other's partly filled last rounds -- as one launch when both run
- * software-pipelined ("attn_bwd_pipe" = 1, the default), else the dQ pass on a library-owned side stream, forked and joined by events on the caller's
- * stream (capturable); 0: one after the other), "attn_bwd_dq64" (1: the dQ pass of x2i_attention_bwd_bf16 keeps 64 query rows per wave; 0: 32; bit-identical),
- * "attn_streamk" (1: x2i_attention_vp_ws_bf16 cuts the items of a partly filled last round along the key axis, chained through the workspace; 0: whole items),
- * "attn_bwd_pipe" (1: the dK / dV pass runs software-pipelined -- element-wise section under the MFMAs; 0: phase after phase; bit-identical),
+ * "attn_bwd_overlap" (1: the dQ and the dK / dV pass of x2i_attention_bwd_bf16 run as ONE launch, dQ blocks in front, so that their partly filled last
+ * rounds fill each other; 0: one after the other; bit-identical),
+ * "attn_streamk" (1: the 16 x 16 x 32 attention kernel runs persistent -- one workgroup per CU, each unit's exit requests the next item's first loads -- for
+ * launches of more than one round, and x2i_attention_vp_ws_bf16 cuts the items of a partly filled last round along the key axis, chained through the
+ * workspace; 0: one workgroup per item; bit-identical),
  * "train_rows_wg" (1: x2i_ln_mod_bwd_bf16 / x2i_gate_bwd_bf16 run a workgroup per row group with a thread per eight columns; 0: a wave per row --
  * same values up to the summation order of the row statistics),
  * "conv256" (1), "conv_w4" (1: convolutions with >= 256 output channels take the persistent four-wave kernel with the hand-scheduled K-loop,

@@ -470,30 +470,24 @@ def test_fused_attention_backward_vs_autograd(ops, B, H, S):
     ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ2, dK2, dV2, B, H, S, Spad, scale, have_lse=True)
     for a, b_ in ((dQ2, dQ), (dK2, dK), (dV2, dV)):
         assert rel_l2(a[:, :, :S], b_[:, :, :S].float().cpu()) < 2e-3
-    # the dQ pass with 64 query rows per wave (default) against the 32-row form: the same arithmetic per row, bit for bit
+    # the two passes as one launch (default) and one after the other: the same blocks, bit for bit
     from x2i_amd import _lib
-    old = _lib.set_option("attn_bwd_dq64", 0)
+    old = _lib.set_option("attn_bwd_overlap", 0)
     try:
         dQ3, dK3, dV3 = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
         ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ3, dK3, dV3, B, H, S, Spad, scale, have_lse=True)
     finally:
-        _lib.set_option("attn_bwd_dq64", old)
+        _lib.set_option("attn_bwd_overlap", old)
     assert torch.equal(dQ3, dQ2) and torch.equal(dK3, dK2) and torch.equal(dV3, dV2)
-    # the software-pipelined dK / dV pass (default) against the phase-after-phase kernel: the same MFMA order per accumulator and the same
-    # element-wise operations, bit for bit
-    old = _lib.set_option("attn_bwd_pipe", 0)
-    try:
-        dQ4, dK4, dV4 = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
-        ops.attention_bwd(Qg, Kg, Vg, QT, KT, dOh, dOT, lse_f, Dv, dQ4, dK4, dV4, B, H, S, Spad, scale, have_lse=True)
-    finally:
-        _lib.set_option("attn_bwd_pipe", old)
-    assert torch.equal(dQ4, dQ2) and torch.equal(dK4, dK2) and torch.equal(dV4, dV2)
 
 
-@pytest.mark.parametrize("S", [4608, 4600])
+@pytest.mark.ablation
+@pytest.mark.parametrize("S", [4608, 4600, 200, 640])
 def test_pipelined_attention_backward_bit_identical_at_model_length(ops, S):
-    """The software-pipelined dQ and dK / dV passes (attn_bwd_pipe = 1, default) against the phase-after-phase kernels at the model's sequence
-    length (72 streamed tiles; S = 4600: a ragged last tile, the masked form of the dQ pass) -- bit for bit, on random operands."""
+    """The software-pipelined dQ and dK / dV passes (the product's; one fused launch) against the round-2 phase-after-phase kernels, which live in the
+    measurement library (X2I_LIB_VARIANT=ablate: options attn_bwd_pipe / attn_bwd_dq64), at the model's sequence length (72 streamed tiles; S = 4600: a
+    ragged last tile, the masked form of the dQ pass) and at short ragged ones -- bit for bit, on random operands; also the 32-row dQ form and the
+    passes one after the other."""
     from x2i_amd import _lib
     B, H = 1, 2
     Spad = ops.pad128(S)
@@ -511,18 +505,22 @@ def test_pipelined_attention_backward_bit_identical_at_model_length(ops, S):
     Dv[:, :, :S] = torch.randn((B, H, S), device=DEV, generator=gen) * 0.1
     lse = torch.empty((B, H, Spad), device=DEV)
     outs = {}
-    for pipe in (1, 0):
-        old = _lib.set_option("attn_bwd_pipe", pipe)
+    forms = {"product": {}, "serial": {"attn_bwd_overlap": 0}, "round 2": {"attn_bwd_pipe": 0}, "round 2, 32-row dQ": {"attn_bwd_pipe": 0, "attn_bwd_dq64": 0},
+             "round 2, serial": {"attn_bwd_pipe": 0, "attn_bwd_overlap": 0}}
+    for name, opts in forms.items():
+        old = {k: _lib.set_option(k, v) for k, v in opts.items()}
         try:
             dQ, dK, dV = (torch.zeros((B, H, Spad, 128), device=DEV, dtype=torch.bfloat16) for _ in range(3))
             ops.attention_bwd(Q, K, V, QT, KT, dOh, dOT, lse, Dv, dQ, dK, dV, B, H, S, Spad, scale)   # (statistics pass included)
             torch.cuda.synchronize()
         finally:
-            _lib.set_option("attn_bwd_pipe", old)
-        outs[pipe] = (dQ, dK, dV)
-    for a, b_ in zip(outs[1], outs[0]):
-        assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0
-        assert torch.equal(a, b_)
+            for k, v in old.items():
+                _lib.set_option(k, v)
+        outs[name] = (dQ, dK, dV)
+    for name in forms:
+        for a, b_ in zip(outs["product"], outs[name]):
+            assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0
+            assert torch.equal(a, b_), name
 
 
 def test_full_width_distillation_gradient_vs_oracle_autograd():

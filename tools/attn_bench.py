@@ -73,7 +73,8 @@ def backward_bench():
     # without the statistics pass (the training step hands over the forward kernel's statistics), per option set; passes one after the other
     # (attn_bwd_overlap = 0) so that each pass's own time shows
     fl7 = (3 + 4) * 2 * B * H * S * S * 128
-    for opts in ({}, {"attn_bwd_pipe": 0}, {"attn_bwd_overlap": 0}, {"attn_bwd_overlap": 0, "attn_bwd_pipe": 0}, {}):
+    abl = bool(_lib.load().x2i_is_ablation_build())   # the round-2 kernels (attn_bwd_pipe = 0) live in the measurement library: X2I_LIB_VARIANT=ablate
+    for opts in (({}, {"attn_bwd_pipe": 0}, {"attn_bwd_overlap": 0}, {"attn_bwd_overlap": 0, "attn_bwd_pipe": 0}, {}) if abl else ({}, {"attn_bwd_overlap": 0}, {})):
         old = {k: _lib.set_option(k, v) for k, v in opts.items()}
         t = timeit(lambda: ops.attention_bwd(Q, K_, V, QT, KT, dOh, dOT, L, Dv, dQ, dK, dV, B, H, S, Spad, 1 / math.sqrt(128), have_lse=True))
         for k, v in old.items():

@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libx2i_hip.so")
 # measurement-only library for tools/ (ablation kernels that are "wrong results by design", the k-half-unit GEMM form):
 # same sources, the files below recompiled with -DX2I_ABLATION.  Never loaded by the product package.
 LIB_ABLATE = os.path.join(HERE, "libx2i_hip_ablate.so")
-ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm_r2.hip", "gemm256w.hip", "gemm256p.hip", "attention.hip", "attention16.hip", "attention_pp.hip", "attention_w16.hip", "c_api.hip")
+ABLATE_SRCS = ("gemm.hip", "gemm_ablate.hip", "gemm_r2.hip", "gemm256w.hip", "gemm256p.hip", "attention.hip", "attention16.hip", "attention_pp.hip", "attention_w16.hip", "attention_bwd.hip", "c_api.hip")
 # A/B kernels that no product path selects (round 6 prune): compiled and linked ONLY into the measurement library -- gemm_r2.hip (the "two
 # residents" GEMM, measured 1.6x slower), attention16.hip (compiler-scheduled 16 x 16 x 32 attention, superseded by the generated attention_w16.hip)
 ABLATE_ONLY_SRCS = ("gemm_r2.hip", "attention16.hip")

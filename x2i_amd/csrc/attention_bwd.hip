@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   }
 }
 
+#ifdef X2I_ABLATION   // (measurement library only since the pipelined passes: the A/B reference of attn_bwd_dq_kernel)
 // dQ with 64 persistent query rows per wave (two 32-row blocks qb): every streamed fragment feeds TWO MFMAs, so the LDS traffic per
 // MFMA is half that of attn_bwd_kernel<0> (whose one-fragment-per-MFMA stream sits at the LDS roof with the matrix pipe half idle).
 // 256 query rows per workgroup; same tiles, fragments, arithmetic and rounding per row as the 32-row form (bit-identical results).
@@ -514,6 +515,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __r
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) store_rows(dQ + hoff + (long long)r0[qb] * 128, oacc[qb], scale, G.hi, r0[qb] < S);
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // dK / dV pass, SOFTWARE-PIPELINED over the two 32-row halves u of a streamed tile (round 6).  attn_bwd_kernel<1> runs a tile as
@@ -968,11 +971,16 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        Spad, scale, scale_log2, B);
   }
   // The dQ pass and the dK / dV pass are independent (both read Q, K, V, dO and the statistics; they write different tensors) and each
-  // ends in a partly filled round of one-workgroup-per-CU blocks (B = 1: 1.7 and 3.4 rounds): dQ goes to a side stream, forked and
-  // joined by events, so that the two launches fill each other's tails.  (Option attn_bwd_overlap = 0: one after the other.)
-  if (x2i_options().attn_bwd_pipe && x2i_options().attn_bwd_dq64 && x2i_options().attn_bwd_overlap) {
-    // the software-pipelined passes as ONE launch (attn_bwd_fused_kernel): dQ blocks in front, dK / dV blocks behind them -- each CU takes the next
-    // block as soon as one ends, whichever pass it belongs to (the two-stream form below leaves that to two queues that each want whole CUs)
+  // ends in a partly filled round of one-workgroup-per-CU blocks (B = 1: 1.7 and 3.4 rounds).  Product: the software-pipelined kernels, as ONE launch
+  // (attn_bwd_fused_kernel: dQ blocks in front, dK / dV blocks behind them -- a CU takes the next block as soon as one ends, whichever pass it belongs
+  // to) or, option attn_bwd_overlap = 0, one after the other.  The round-2 kernels (phase after phase; 32-row dQ form) and the two-stream form are
+  // compiled into the measurement library only (options attn_bwd_pipe / attn_bwd_dq64 there; bit-identical, tests behind the `ablation` marker).
+#ifdef X2I_ABLATION
+  const bool pipe = x2i_options().attn_bwd_pipe != 0, dq64 = x2i_options().attn_bwd_dq64 != 0;
+#else
+  const bool pipe = true, dq64 = true;
+#endif
+  if (pipe && dq64 && x2i_options().attn_bwd_overlap) {
     const int shm = 2 * KV_STAGE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_fused_kernel, shm);
     if (rc) return rc;
@@ -982,18 +990,23 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        scale_log2, n_dq);
     return x2i_check_launch("attention_bwd (fused passes)");
   }
+  hipStream_t qs = stream;
+#ifdef X2I_ABLATION
   hipStream_t side = stream;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   const bool overlap = x2i_options().attn_bwd_overlap && x2i_side_stream(stream, &side, &ev_fork, &ev_join) &&
                        hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess;
-  hipStream_t qs = overlap ? side : stream;
-  if (x2i_options().attn_bwd_dq64 && x2i_options().attn_bwd_pipe) {   // dQ: 64 query rows per wave, software-pipelined (attn_bwd_dq_kernel)
+  qs = overlap ? side : stream;
+#endif
+  if (dq64 && pipe) {   // dQ: 64 query rows per wave, software-pipelined (attn_bwd_dq_kernel)
     const int shm = 2 * 3 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dq_kernel, shm);
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((Spad + 255) / 256) * H * B), dim3(256), shm, qs, (const bf16_t*)Q, (const bf16_t*)dOh,
                        (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)KT, (const float*)L2, Dv, (bf16_t*)dQ, H, S, Spad, scale, scale_log2, B);
-  } else if (x2i_options().attn_bwd_dq64) {  // phase after phase (attn_bwd_dq64_kernel); option attn_bwd_dq64 = 0: the 32-row form (A/B, bit-identical)
+  }
+#ifdef X2I_ABLATION
+  else if (dq64) {  // phase after phase (attn_bwd_dq64_kernel); option attn_bwd_dq64 = 0: the 32-row form (A/B, bit-identical)
     const int shm = 2 * 3 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dq64_kernel, shm);
     if (rc) return rc;
@@ -1007,13 +1020,16 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        (const bf16_t*)KT, (const bf16_t*)nullptr, L2, Dv, (bf16_t*)dQ, (bf16_t*)nullptr, H, S, Spad, scale, scale_log2, B);
   }
   if (overlap) (void)hipEventRecord(ev_join, side);
-  if (x2i_options().attn_bwd_pipe) {   // dK / dV: software-pipelined (attn_bwd_dkdv_kernel); option 0 = attn_bwd_kernel<1> (A/B, bit-identical)
+#endif
+  if (pipe) {   // dK / dV: software-pipelined (attn_bwd_dkdv_kernel)
     const int shm = 2 * KV_STAGE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_dkdv_kernel, shm);
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), shm, stream, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Q, (const bf16_t*)dOh,
                        (const bf16_t*)dOT, (const bf16_t*)QT, (const float*)L2, Dv, (bf16_t*)dV, (bf16_t*)dK, H, S, Spad, scale, scale_log2, B);
-  } else {
+  }
+#ifdef X2I_ABLATION
+  else {
     const int shm = 2 * 4 * TILE;
     const int rc = x2i_ensure_dynamic_smem((const void*)attn_bwd_kernel<1>, shm);
     if (rc) return rc;
@@ -1021,6 +1037,7 @@ int x2i_launch_attention_bwd(const void* Q, const void* K, const void* V, const 
                        (const bf16_t*)dOT, (const bf16_t*)QT, L2, Dv, (bf16_t*)dV, (bf16_t*)dK, H, S, Spad, scale, scale_log2, B);
   }
   if (overlap) (void)hipStreamWaitEvent(stream, ev_join, 0);
+#endif
   return x2i_check_launch("attention_bwd");
 }
 

@@ -156,9 +156,9 @@ int x2i_abi_version(void) { return X2I_ABI_VERSION; }
 static long long* opt_slot(X2IOptions& o, const char* name, int** as_int) {
   *as_int = nullptr;
 #define X2I_OPT_INT(N_) if (!strcmp(name, #N_)) { *as_int = &o.N_; return nullptr; }
-  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_fp8_persist) X2I_OPT_INT(gemm_fx) X2I_OPT_INT(gemm_fx_nk) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(train_rows_wg) X2I_OPT_INT(attn_bwd_overlap) X2I_OPT_INT(attn_bwd_dq64) X2I_OPT_INT(attn_bwd_pipe) X2I_OPT_INT(attn_streamk) X2I_OPT_INT(conv256) X2I_OPT_INT(conv_w4) X2I_OPT_INT(conv_korder) X2I_OPT_INT(attn_variant) X2I_OPT_INT(attn_w16) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
+  X2I_OPT_INT(gemm_tile) X2I_OPT_INT(gemm_gm) X2I_OPT_INT(gemm_split_tail) X2I_OPT_INT(gemm_w4) X2I_OPT_INT(gemm_persist) X2I_OPT_INT(gemm_fp8_persist) X2I_OPT_INT(gemm_fx) X2I_OPT_INT(gemm_fx_nk) X2I_OPT_INT(gemm_streamk) X2I_OPT_INT(gemm_pair) X2I_OPT_INT(train_rows_wg) X2I_OPT_INT(attn_bwd_overlap) X2I_OPT_INT(attn_streamk) X2I_OPT_INT(conv256) X2I_OPT_INT(conv_w4) X2I_OPT_INT(conv_korder) X2I_OPT_INT(attn_variant) X2I_OPT_INT(attn_w16) X2I_OPT_INT(conv5_variant) X2I_OPT_INT(fp8) X2I_OPT_INT(last_gemm_tile)
 #ifdef X2I_ABLATION
-  X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate) X2I_OPT_INT(gemm_r2)
+  X2I_OPT_INT(gemm_lform) X2I_OPT_INT(gemm_ablate) X2I_OPT_INT(attn_ablate) X2I_OPT_INT(gemm_r2) X2I_OPT_INT(attn_bwd_dq64) X2I_OPT_INT(attn_bwd_pipe)
 #endif
 #undef X2I_OPT_INT
   if (!strcmp(name, "gemm_min256")) return &o.gemm_min256;
