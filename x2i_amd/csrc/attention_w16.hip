@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256) void attn_w16_kernel(const bf16_t* __restrict_
 
 }  // namespace
 
-// stream-K form: possible (nitems > CUs, a last round of a multiple of 8 items whose shares are long enough) and wanted (a workspace was handed over)?
 // the last round's items cut along the key axis: possible (a last round of a multiple of 8 items, key sequences long enough) and a workspace was handed over?
 static bool w16_streamk(int nitems, int nt, int cus, void* ws, long long ws_bytes) {
   if (!ws || nt < 4 * SKA_MIN_TILES) return false;
@@ -249,6 +248,10 @@ int x2i_launch_attention_w16(const void* Q, const void* K, const void* VT, void*
       if (x2i_options().attn_ablate >= 100) c = x2i_options().attn_ablate - 100;   // measurement library only (tools/attn_sk_bench.py --cut): the cut tile
 #endif
       c = std::min(std::max(c, SKA_MIN_TILES), nt - SKA_MIN_TILES);
+      // worth it?  An almost full last round leaves few closing workgroups with many short closing parts each (r / 8 = 31: one workgroup per XCD with 31 of
+      // them), and every part pays a unit's fixed cost: cut only when the longer kind of workgroup finishes well before a whole item would
+      const int t_parts = std::max(c + SKA_UNIT_TILES, m * (nt - c + SKA_UNIT_TILES)), t_whole = nt + SKA_UNIT_TILES;
+      if (t_parts * 100 > t_whole * 92) c = 0;
     }
     hipLaunchKernelGGL(attn_w16_kernel<true>, dim3(cus), dim3(256), shm, stream, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)VT, (bf16_t*)O, H, S, Spad,
                        ldo, o_bs, scale_log2, B, lse, prescale, nitems, c ? (char*)workspace + 4096 : (char*)nullptr, c ? (unsigned*)workspace : (unsigned*)nullptr, c);
