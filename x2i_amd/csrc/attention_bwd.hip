@@ -537,6 +537,10 @@ __device__ __forceinline__ void sfor(F&& f) {
     f(std::integral_constant<int, N - 1>{});
   }
 }
+// ... with the tile's byte offset as the instruction's scalar offset: the per-lane offset stays loop-invariant (no VALU per piece and tile)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff_bytes, uint32_t soff_bytes, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
+}
 __device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff_bytes, char* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff_bytes, 0, 0, 0);
 }
@@ -567,15 +571,37 @@ struct KvState {
   f32x4_t Lr[2][4], Dr[2][4];           // statistics of the lane's 16 rows per half: [u][a * 2 + half of eight]
 };
 
+// Fragment addresses of a tile: the per-lane part (row, swizzled chunk) of the eight row-fragment and four column-fragment positions is the same for every
+// tile (KvOfs, once per kernel); a tile adds its buffer base (twelve adds) and every read carries the rest -- tile, half, d-block -- as an immediate offset.
+// (Left to itself hipcc re-derived 40 addresses per tile.)
+struct KvOfs { int r[8], c[4]; };
+struct KvAddr { const char* r[8]; const char* c[4]; };
+__device__ __forceinline__ KvOfs kv_ofs(const Geo& G) {
+  KvOfs o;
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) o.r[ds] = G.k_row_off + (((ds * 2 + G.hi) ^ G.k_swz) << 4);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) o.c[g] = G.v_row_off + (((4 * (g >> 1) + 2 * (g & 1) + G.hi) ^ G.v_swz) << 4);
+  return o;
+}
+__device__ __forceinline__ KvAddr kv_addr(const char* cur, const KvOfs& o) {
+  KvAddr a;
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) a.r[ds] = cur + o.r[ds];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) a.c[g] = cur + o.c[g];
+  return a;
+}
+
 template <int M>
-__device__ __forceinline__ bf16x8_t kv_frag(const char* cur, const Geo& G) {
+__device__ __forceinline__ bf16x8_t kv_frag(const KvAddr& A) {
   constexpr int ph = M >> 4, i = M & 15, u = ph & 1;
   if constexpr (ph < 2) {
     constexpr int ds = i >> 1, which = i & 1;
-    return row_frag(cur + which * TILE, G, ds >> 1, u + 2 * (ds & 1));
+    return *(const bf16x8_t*)(A.r[ds] + which * TILE + u * 32 * 256);
   } else {
     constexpr int kt = i >> 3, db = (i >> 1) & 3, which = i & 1;
-    return col_frag(cur + (2 + which) * TILE, G, u * 2 + kt, db);
+    return *(const bf16x8_t*)(A.c[u * 2 + kt] + (2 + which) * TILE + db * 32 * 128);
   }
 }
 
@@ -602,16 +628,16 @@ template <int M>
 __device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, const Rsrc4& R,
                                         __amdgpu_buffer_rsrc_t rL, __amdgpu_buffer_rsrc_t rD, const int (&row_src)[4], const int (&col_src)[4],
                                         int wave, int lane, const Geo& G, const bf16x8_t (&pa)[8], const bf16x8_t (&pb)[8], float scale_log2,
-                                        f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4], KvState& st) {
+                                        f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4], KvState& st, const KvAddr& A) {
   constexpr int ph = M >> 4, i = M & 15, u = ph & 1;
-  if constexpr (M + KV_LEAD < 64) st.fr[(M + KV_LEAD) & 7] = kv_frag<M + KV_LEAD>(cur, G);
+  if constexpr (M + KV_LEAD < 64) st.fr[(M + KV_LEAD) & 7] = kv_frag<M + KV_LEAD>(A);
   if constexpr (ph == 0) {   // the next tile: pieces j = i >> 2 of tile i & 3 (unconditional: behind the last tile they are never read)
     constexpr int j = i >> 2, tl = i & 3;
     char* dst = nxt + tl * TILE + (j * 256 + wave * 64) * 16;
-    if constexpr (tl == 0) dma16(R.a, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
-    if constexpr (tl == 1) dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
-    if constexpr (tl == 2) dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
-    if constexpr (tl == 3) dma16(R.d, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
+    if constexpr (tl == 0) dma16s(R.a, (uint32_t)(row_src[j] * 2), (uint32_t)(s_next * 256), dst);
+    if constexpr (tl == 1) dma16s(R.b, (uint32_t)(row_src[j] * 2), (uint32_t)(s_next * 256), dst);
+    if constexpr (tl == 2) dma16s(R.c, (uint32_t)(col_src[j] * 2), (uint32_t)(s_next * 2), dst);
+    if constexpr (tl == 3) dma16s(R.d, (uint32_t)(col_src[j] * 2), (uint32_t)(s_next * 2), dst);
     if constexpr (i == 15) dma4((wave & 1) ? rD : rL, (uint32_t)((s_next + lane) * 4), nxt + 4 * TILE + wave * 256);
     // statistics of half u0 (needed from slot 18 on), half u1 in phase B
     if constexpr (i >= 8) {
@@ -646,12 +672,13 @@ __device__ __forceinline__ void kv_slot(const char* __restrict__ cur, char* __re
 __device__ __forceinline__ void dkdv_tile(const char* __restrict__ cur, char* __restrict__ nxt, int s_next, const Rsrc4& R, __amdgpu_buffer_rsrc_t rL,
                                           __amdgpu_buffer_rsrc_t rD, const int (&row_src)[4], const int (&col_src)[4], int wave, int lane,
                                           const Geo& G, const bf16x8_t (&pa)[8], const bf16x8_t (&pb)[8], float scale_log2,
-                                          f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4]) {
+                                          f32x16_t (&oacc0)[4], f32x16_t (&oacc1)[4], const KvOfs& ofs) {
   KvState st;
-  sfor<KV_LEAD>([&](auto mc) { st.fr[decltype(mc)::value & 7] = kv_frag<decltype(mc)::value>(cur, G); });
+  const KvAddr A = kv_addr(cur, ofs);
+  sfor<KV_LEAD>([&](auto mc) { st.fr[decltype(mc)::value & 7] = kv_frag<decltype(mc)::value>(A); });
   __builtin_amdgcn_sched_barrier(0);
   sfor<64>([&](auto mc) {
-    kv_slot<decltype(mc)::value>(cur, nxt, s_next, R, rL, rD, row_src, col_src, wave, lane, G, pa, pb, scale_log2, oacc0, oacc1, st);
+    kv_slot<decltype(mc)::value>(cur, nxt, s_next, R, rL, rD, row_src, col_src, wave, lane, G, pa, pb, scale_log2, oacc0, oacc1, st, A);
   });
 }
 
@@ -705,6 +732,7 @@ __device__ __forceinline__ void dkdv_body(char* smem, const bf16_t* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oacc0[i][r] = 0.f; oacc1[i][r] = 0.f; }
   const int nt = (S + KVB - 1) / KVB;
+  const KvOfs ofs = kv_ofs(G);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {   // tile 0
     char* dst = smem + (j * 256 + wave * 64) * 16;
@@ -719,7 +747,7 @@ __device__ __forceinline__ void dkdv_body(char* smem, const bf16_t* __restrict__
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     dkdv_tile(smem + buf * KV_STAGE, smem + (buf ^ 1) * KV_STAGE, (t + 1) * KVB, R, rL, rD, row_src, col_src, wave, lane, G, pa, pb, scale_log2, oacc0,
-              oacc1);
+              oacc1, ofs);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -787,9 +815,9 @@ __device__ __forceinline__ void dq_slot(const char* __restrict__ cur, char* __re
   if constexpr (M < 24 && (M & 1) == 0) {   // the next tile: piece j = (M / 2) >> 2 ... of tile (M / 2) % 3
     constexpr int pc = M >> 1, j = pc / 3, tl = pc % 3;
     char* dst = nxt + tl * TILE + (j * 256 + wave * 64) * 16;
-    if constexpr (tl == 0) dma16(R.a, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
-    if constexpr (tl == 1) dma16(R.b, (uint32_t)(s_next * 256 + row_src[j] * 2), dst);
-    if constexpr (tl == 2) dma16(R.c, (uint32_t)(s_next * 2 + col_src[j] * 2), dst);
+    if constexpr (tl == 0) dma16s(R.a, (uint32_t)(row_src[j] * 2), (uint32_t)(s_next * 256), dst);
+    if constexpr (tl == 1) dma16s(R.b, (uint32_t)(row_src[j] * 2), (uint32_t)(s_next * 256), dst);
+    if constexpr (tl == 2) dma16s(R.c, (uint32_t)(col_src[j] * 2), (uint32_t)(s_next * 2), dst);
   }
   if constexpr (M < 64) {
     constexpr int u = F >> 4, i = F & 15, ds = i >> 1, which = i & 1;
